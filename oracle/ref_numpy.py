@@ -1,0 +1,296 @@
+"""CPU oracle (numpy, float64) for the alproj camera-projection hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``alproj_amd/`` may import this module; it is
+used by ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py``
+as the checker / reported baseline, never as the thing shipped or measured as the product.
+
+It restates, on plain numpy arrays, the arithmetic of the reference (0kam/alproj v1.1.1):
+
+* ``src/alproj/optimize.py:8-44``    intrinsic_mat
+* ``src/alproj/optimize.py:46-96``   extrinsic_mat
+* ``src/alproj/optimize.py:98-120``  _distort
+* ``src/alproj/optimize.py:122-155`` project
+* ``src/alproj/optimize.py:157-178`` rmse (mean Euclidean distance)
+* ``src/alproj/optimize.py:181-212`` huber_loss
+* ``src/alproj/optimize.py:215-237`` compute_residuals
+* ``src/alproj/optimize.py:240-276`` DEFAULT_BOUND_WIDTHS / bounds_to_array
+* ``src/alproj/optimize.py:329-357`` CMAOptimizer._loss_function / _proj_error
+* ``src/alproj/project.py:13-54``    projection_mat
+* ``src/alproj/project.py:56-109``   modelview_mat
+* ``src/alproj/project.py:111-143``  distort (map construction; the gather itself is
+  ``cv2.remap(INTER_NEAREST)`` from opencv-python==4.13.0.90, absent here -> restated from
+  its documented semantics, see ``remap_nearest``)
+
+Parity pinning: the reference ships NO test or golden vector for this path
+(SURVEY.md section 4), so the functions of ``optimize.py`` and the two matrix builders of
+``project.py`` are pinned by fixtures generated from the reference's own source, imported by
+file path in the build container (``tests/golden/gen_golden.py`` -> ``tests/golden/*.npz``).
+``remap_nearest`` (cv2) is **parity unpinned** (dependency absent, no reference fixture).
+"""
+from math import cos, pi, sin, tan
+
+import numpy as np
+
+# Fixed order of the 25 camera parameters: the payload of the C-ABI (include/alproj_hip.h).
+# Keys documented at reference project.py:157-189.
+PARAM_KEYS = ("x", "y", "z", "fov", "pan", "tilt", "roll", "a1", "a2",
+              "k1", "k2", "k3", "k4", "k5", "k6", "p1", "p2",
+              "s1", "s2", "s3", "s4", "w", "h", "cx", "cy")
+
+DIST_KEYS = ("a1", "a2", "k1", "k2", "k3", "k4", "k5", "k6",
+             "p1", "p2", "s1", "s2", "s3", "s4")
+
+# reference optimize.py:240-247
+DEFAULT_BOUND_WIDTHS = dict(
+    fov=45, pan=45, tilt=45, roll=45, x=30, y=30, z=30, a1=0.2, a2=0.2,
+    k1=0.2, k2=0.2, k3=0.2, k4=0.2, k5=0.2, k6=0.2, p1=0.2, p2=0.2,
+    s1=0.2, s2=0.2, s3=0.2, s4=0.2)
+
+
+def params_to_vector(params):
+    return np.array([float(params[k]) for k in PARAM_KEYS], dtype=np.float64)
+
+
+def vector_to_params(vec):
+    return {k: float(v) for k, v in zip(PARAM_KEYS, vec)}
+
+
+# --------------------------------------------------------------------------------------
+# camera matrices
+# --------------------------------------------------------------------------------------
+def intrinsic_mat(fov_x_deg, w, h, cx=None, cy=None):
+    """optimize.py:31-44.  Quirk Q5: fov_y is the fov_x ANGLE scaled by h/w (line 36)."""
+    cx = w / 2 if cx is None else cx
+    cy = h / 2 if cy is None else cy
+    fov_x = fov_x_deg * pi / 180
+    fov_y = fov_x * h / w
+    fx = w / (2 * tan(fov_x / 2))
+    fy = h / (2 * tan(fov_y / 2))
+    return np.array([[fx, 0.0, cx], [0.0, fy, cy], [0.0, 0.0, 1.0]])
+
+
+def extrinsic_mat(pan_deg, tilt_deg, roll_deg, t_x, t_y, t_z):
+    """optimize.py:71-96.  R = Rx(-(tilt+90)) . Ry(-roll) . Rz(pan); t = R.(-cam)."""
+    a = pan_deg * pi / 180
+    b = -(tilt_deg + 90) * pi / 180
+    c = -roll_deg * pi / 180
+    rz = np.array([[cos(a), -sin(a), 0.0], [sin(a), cos(a), 0.0], [0.0, 0.0, 1.0]])
+    rx = np.array([[1.0, 0.0, 0.0], [0.0, cos(b), -sin(b)], [0.0, sin(b), cos(b)]])
+    ry = np.array([[cos(c), 0.0, sin(c)], [0.0, 1.0, 0.0], [-sin(c), 0.0, cos(c)]])
+    rot = np.dot(np.dot(rx, ry), rz)
+    t = np.dot(rot, np.array([[-t_x], [-t_y], [-t_z]]))
+    out = np.zeros((4, 4))
+    out[:3, :3] = rot
+    out[:3, 3:] = t
+    out[3, 3] = 1.0
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# modified Brown-Conrady distortion of pixel coordinates
+# --------------------------------------------------------------------------------------
+def distort_points(points, w, h, a1, a2, k1, k2, k3, k4, k5, k6, p1, p2, s1, s2, s3, s4):
+    """optimize.py:104-120.
+
+    Quirks kept verbatim: centre (w-1)/2,(h-1)/2 rounded to float32 and used both as origin
+    and as scale (Q3); r2/r4/r6 are powers of sqrt(x^2+y^2) (Q2); tangential term is
+    ``2 p1 x y + p2 (r2*2*x^2)`` for x and the same with y^2 for y (Q1); a1/a2 enter the y
+    ratio only (Q8).
+    """
+    c = np.array([(w - 1) / 2, (h - 1) / 2], dtype="float32")
+    x = (points[:, 0] - c[0]) / c[0]
+    y = (points[:, 1] - c[1]) / c[1]
+    r = (x ** 2 + y ** 2) ** 0.5
+    r2 = r ** 2
+    r4 = r ** 4
+    r6 = r ** 6
+    xd = (x * (1 + k1 * r2 + k2 * r4 + k3 * r6) / (1 + k4 * r2 + k5 * r4 + k6 * r6)
+          + 2 * p1 * x * y + p2 * (r2 * 2 * x ** 2) + s1 * r2 + s2 * r4)
+    yd = (y * (1 + a1 + k1 * r2 + k2 * r4 + k3 * r6) / (1 + a2 + k4 * r2 + k5 * r4 + k6 * r6)
+          + 2 * p1 * x * y + p2 * (r2 * 2 * y ** 2) + s3 * r2 + s4 * r4)
+    xd = xd * c[0] + c[0]
+    yd = yd * c[1] + c[1]
+    return np.stack([xd, yd], axis=0).T
+
+
+def _dist_args(params):
+    return [params[k] for k in DIST_KEYS]
+
+
+# --------------------------------------------------------------------------------------
+# forward projection
+# --------------------------------------------------------------------------------------
+def project_points(xyz, params):
+    """optimize.py:139-154 on an (N,3) float64 array -> (N,2) float64 (u, v).
+
+    Q4: u = w - x/z (horizontal mirror).  Q7: no behind-camera culling; z == 0 gives NaN/inf.
+    """
+    xyz = np.asarray(xyz, dtype=np.float64)
+    hom = np.vstack((xyz.T, np.ones((1, xyz.shape[0]))))
+    kmat = intrinsic_mat(params["fov"], params["w"], params["h"], params["cx"], params["cy"])
+    emat = extrinsic_mat(params["pan"], params["tilt"], params["roll"],
+                         params["x"], params["y"], params["z"])
+    cam = np.dot(emat, hom)
+    img = np.dot(kmat, cam[:3, :])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        uv = np.array([params["w"] - img[0, :] / img[2, :], img[1, :] / img[2, :]]).T
+        return distort_points(uv, params["w"], params["h"], *_dist_args(params))
+
+
+# --------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------
+def mean_distance(observed_uv, projected_uv):
+    """optimize.py:176-177 -- the reference calls this "rmse"; it is the MEAN distance (Q6)."""
+    o = np.asarray(observed_uv, dtype=np.float64)
+    p = np.asarray(projected_uv, dtype=np.float64)
+    d = ((o[:, 0] - p[:, 0]) ** 2 + (o[:, 1] - p[:, 1]) ** 2) ** 0.5
+    return np.mean(d)
+
+
+def huber(observed_uv, projected_uv, f_scale=10.0):
+    """optimize.py:203-212."""
+    o = np.asarray(observed_uv, dtype=np.float64)
+    p = np.asarray(projected_uv, dtype=np.float64)
+    r = np.sqrt((o[:, 0] - p[:, 0]) ** 2 + (o[:, 1] - p[:, 1]) ** 2)
+    return np.mean(np.where(r <= f_scale, 0.5 * r ** 2, f_scale * (r - 0.5 * f_scale)))
+
+
+def residual_vector(xyz, observed_uv, params):
+    """optimize.py:233-237: (observed - projected) flattened row-major -> (2N,)."""
+    return (np.asarray(observed_uv, dtype=np.float64) - project_points(xyz, params)).flatten()
+
+
+LOSS_MEAN_DIST = 0
+LOSS_HUBER = 1
+
+
+def loss_of(xyz, observed_uv, params, loss_kind=LOSS_MEAN_DIST, f_scale=10.0):
+    proj = project_points(xyz, params)
+    if loss_kind == LOSS_MEAN_DIST:
+        return mean_distance(observed_uv, proj)
+    return huber(observed_uv, proj, f_scale)
+
+
+# --------------------------------------------------------------------------------------
+# optimiser plumbing
+# --------------------------------------------------------------------------------------
+def bounds_to_array(params_init, target_params, bound_widths=None):
+    """optimize.py:268-276; unknown keys fall back to width 0.2 (line 274)."""
+    widths = {} if bound_widths is None else bound_widths
+    out = np.zeros((len(target_params), 2))
+    for i, key in enumerate(target_params):
+        wd = widths.get(key, DEFAULT_BOUND_WIDTHS.get(key, 0.2))
+        out[i, 0] = params_init[key] - wd
+        out[i, 1] = params_init[key] + wd
+    return out
+
+
+def candidate_params(params_init, target_params, bounds, normalized_x):
+    """optimize.py:341-350: de-normalise x in [0,1]^D and overwrite the target keys."""
+    lower, upper = bounds[:, 0], bounds[:, 1]
+    values = np.asarray(normalized_x, dtype=np.float64) * (upper - lower) + lower
+    p = dict(params_init)
+    p.update(dict(zip(target_params, (float(v) for v in values))))
+    return p
+
+
+def population_losses(xyz, observed_uv, params_init, target_params, bounds, X,
+                      f_scale=None):
+    """The body of the generation loop, optimize.py:420-423, for a whole (P,D) matrix X of
+    normalised candidates: one ``_proj_error`` (optimize.py:347-356) per row.
+
+    Returns (losses (P,), argmin).  argmin follows Q9: first index among ties, which is what
+    a stable in-place sort by value followed by ``solutions[0]`` yields (optimize.py:424-427).
+    NaN losses: ``sorted`` with NaN keys is ill-defined in the reference; here NaN never wins
+    unless every loss is NaN (then index 0).
+    """
+    X = np.asarray(X, dtype=np.float64)
+    losses = np.empty(X.shape[0])
+    for i in range(X.shape[0]):
+        p = candidate_params(params_init, target_params, bounds, X[i])
+        proj = project_points(xyz, p)
+        if f_scale is None:
+            losses[i] = mean_distance(observed_uv, proj)
+        else:
+            losses[i] = huber(observed_uv, proj, f_scale)
+    return losses, first_argmin(losses)
+
+
+def first_argmin(losses):
+    losses = np.asarray(losses, dtype=np.float64)
+    if np.all(np.isnan(losses)):
+        return 0
+    return int(np.nanargmin(losses))
+
+
+# --------------------------------------------------------------------------------------
+# OpenGL-style matrices of the render path
+# --------------------------------------------------------------------------------------
+def projection_mat(fov_x_deg, w, h, near=-1, far=1, cx=None, cy=None):
+    """project.py:40-54: flat 16-vector.  The render call site (project.py:257) passes
+    neither cx/cy nor near/far, and hands the flat vector UNtransposed to a column-major
+    GLSL mat4 (project.py:262) -> quirk Q10."""
+    cx = w / 2 if cx is None else cx
+    cy = h / 2 if cy is None else cy
+    fov_x = fov_x_deg * pi / 180
+    fov_y = fov_x * h / w
+    fx = 1 / tan(fov_x / 2)
+    fy = 1 / tan(fov_y / 2)
+    return np.array([
+        fx, 0, (w - 2 * cx) / w, 0,
+        0, fy, -(h - 2 * cy) / h, 0,
+        0, 0, -(far + near) / (far - near), -2 * far * near / (far - near),
+        0, 0, -1, 0], dtype=np.float64)
+
+
+def modelview_mat(pan_deg, tilt_deg, roll_deg, t_x, t_y, t_z):
+    """project.py:81-109: R = Rz(roll).Rx(tilt).Ry(360-pan); translate by (-tx,-tz,-ty)
+    (vertex order X,Z,Y; Q16); returned transposed+flattened (column-major correct)."""
+    a = (360 - pan_deg) * pi / 180
+    b = tilt_deg * pi / 180
+    c = roll_deg * pi / 180
+    rx = np.array([[1, 0, 0, 0], [0, cos(b), -sin(b), 0], [0, sin(b), cos(b), 0], [0, 0, 0, 1.0]])
+    ry = np.array([[cos(a), 0, sin(a), 0], [0, 1, 0, 0], [-sin(a), 0, cos(a), 0], [0, 0, 0, 1.0]])
+    rz = np.array([[cos(c), -sin(c), 0, 0], [sin(c), cos(c), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]])
+    rot = np.dot(np.dot(rz, rx), ry)
+    tr = np.array([[1, 0, 0, -t_x], [0, 1, 0, -t_z], [0, 0, 1, -t_y], [0, 0, 0, 1.0]])
+    return np.dot(rot, tr).transpose().flatten()
+
+
+# --------------------------------------------------------------------------------------
+# image-space distortion remap (last stage of the render)
+# --------------------------------------------------------------------------------------
+def distort_maps(width, height, coeffs):
+    """project.py:128-140: per-output-pixel source coordinates, float32 (map_x, map_y).
+
+    Q12: approximate inverse = _distort with 1/a1, 1/a2 and every other coefficient negated.
+    """
+    d = np.asarray(coeffs, dtype=np.float64)
+    gx, gy = np.meshgrid(np.arange(width), np.arange(height))
+    grid = np.stack([gx.flatten(), gy.flatten()]).T
+    g = distort_points(grid, width, height, 1 / d[0], 1 / d[1], *(-d[2:14]))
+    m = g.T.reshape([2, height, width]).astype("float32")
+    return m[0], m[1]
+
+
+def remap_nearest(img, map_x, map_y):
+    """Semantics of ``cv2.remap(img, map_x, map_y, INTER_NEAREST)`` (project.py:141) with the
+    default BORDER_CONSTANT value 0: source index = round-half-to-even of the float32 map
+    (OpenCV ``cvRound``), out-of-range -> 0.  PARITY UNPINNED: opencv-python 4.13.0.90 is not
+    installed here and the reference holds no fixture for it."""
+    h, w = img.shape[:2]
+    sx = np.rint(map_x.astype(np.float64))
+    sy = np.rint(map_y.astype(np.float64))
+    ok = (sx >= 0) & (sx < w) & (sy >= 0) & (sy < h)   # NaN compares False
+    ix = np.where(ok, sx, 0).astype(np.int64)
+    iy = np.where(ok, sy, 0).astype(np.int64)
+    out = img[iy, ix]
+    out[~ok] = 0
+    return out
+
+
+def distort_image(img, coeffs):
+    """project.py:111-143."""
+    mx, my = distort_maps(img.shape[1], img.shape[0], coeffs)
+    return remap_nearest(img, mx, my)
