@@ -1,0 +1,92 @@
+"""Build recipe for libalproj_hip.so (hipcc, gfx950 only, in-tree).
+
+Used by ``__graft_entry__.build()`` and ``python -m alproj_amd._build``.  The shared
+library is written next to this file so that it travels with the source tree; it is
+git-ignored (history stays source-only).
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+BUILD = os.path.join(ROOT, "build")
+LIB = os.path.join(HERE, "libalproj_hip.so")
+SOURCES = ["alp_core.hip", "alp_points.hip", "alp_raster.hip"]
+ARCH = "gfx950"
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; libalproj_hip.so cannot be built")
+    return exe
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP translation unit for gfx950 and link libalproj_hip.so."""
+    os.makedirs(BUILD, exist_ok=True)
+    headers = [os.path.join(CSRC, "alp_internal.h"), os.path.join(INCLUDE, "alproj_hip.h"),
+               os.path.abspath(__file__)]
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
+             f"-I{INCLUDE}", f"-I{CSRC}"]
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(BUILD, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            cmd = [hipcc()] + flags + ["-Rpass-analysis=kernel-resource-usage", "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            with open(o + ".log", "w") as f:
+                f.write(r.stderr)
+            if r.returncode != 0:
+                sys.stderr.write(r.stderr)
+                raise RuntimeError(f"hipcc failed on {src}")
+    if force or _stale(LIB, objs):
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + \
+              ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+def resource_usage():
+    """Parse the kernel-resource-usage remarks of the last build: {kernel: {field: value}}."""
+    out = {}
+    for src in SOURCES:
+        log = os.path.join(BUILD, src.replace(".hip", ".o.log"))
+        if not os.path.exists(log):
+            continue
+        cur = None
+        for line in open(log):
+            if "remark:" not in line or "[-Rpass-analysis" not in line:
+                continue
+            body = line.split("remark:", 1)[1].split("[-Rpass")[0].strip()
+            if body.startswith("Function Name:"):
+                cur = body.split(":", 1)[1].strip()
+                out[cur] = {}
+            elif cur and ":" in body:
+                k, v = body.split(":", 1)
+                out[cur][k.strip()] = v.strip()
+    return out
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))
+    for k, v in resource_usage().items():
+        print(k, {a: v[a] for a in v if a in ("VGPRs", "TotalSGPRs", "ScratchSize [bytes/lane]",
+                                               "Occupancy [waves/SIMD]", "LDS Size [bytes/block]")})

@@ -1,0 +1,267 @@
+"""ctypes binding of libalproj_hip.so (the C ABI declared in include/alproj_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or no MI355X-class HIP device
+can be initialised, the first call that needs the device raises ``AlprojHipError``.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libalproj_hip.so")
+
+ALP_F32, ALP_F64, ALP_I32, ALP_I64 = 0, 1, 2, 3
+LOSS_MEAN_DIST, LOSS_HUBER = 0, 1
+NPARAM = 25
+UNIQUE_ID_BYTES = 128
+
+PARAM_KEYS = ("x", "y", "z", "fov", "pan", "tilt", "roll", "a1", "a2",
+              "k1", "k2", "k3", "k4", "k5", "k6", "p1", "p2",
+              "s1", "s2", "s3", "s4", "w", "h", "cx", "cy")
+DIST_KEYS = PARAM_KEYS[7:21]
+
+
+class AlprojHipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libalproj_hip error {code}: {message}")
+        self.code = code
+
+
+_c_void_p = ctypes.c_void_p
+_c_int = ctypes.c_int
+_c_i64 = ctypes.c_int64
+_c_double = ctypes.c_double
+_c_dp = ctypes.POINTER(ctypes.c_double)
+_c_fp = ctypes.POINTER(ctypes.c_float)
+
+# name -> argtypes; every function returns int unless listed in _RESTYPE
+_SIGNATURES = {
+    "alp_abi_version": [],
+    "alp_last_error": [],
+    "alp_init": [_c_int],
+    "alp_shutdown": [],
+    "alp_device_count": [ctypes.POINTER(_c_int)],
+    "alp_device_info": [ctypes.c_char_p, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_i64)],
+    "alp_synchronize": [],
+    "alp_event_record": [_c_int],
+    "alp_event_elapsed_ms": [_c_int, _c_int, _c_fp],
+    "alp_comm_unique_id": [ctypes.c_char_p],
+    "alp_comm_init": [ctypes.c_char_p, _c_int, _c_int],
+    "alp_comm_destroy": [],
+    "alp_comm_info": [ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)],
+    "alp_points_create": [_c_void_p, _c_int, _c_i64, _c_dp, _c_int, ctypes.POINTER(_c_void_p)],
+    "alp_points_destroy": [_c_void_p],
+    "alp_points_count": [_c_void_p, ctypes.POINTER(_c_i64)],
+    "alp_points_set_observed": [_c_void_p, _c_void_p, _c_int],
+    "alp_project": [_c_void_p, _c_dp],
+    "alp_projected_fetch": [_c_void_p, _c_void_p, _c_void_p, _c_int],
+    "alp_projected_fetch_strided": [_c_void_p, _c_i64, _c_i64, _c_i64, _c_dp, _c_dp],
+    "alp_residuals": [_c_void_p, _c_dp, _c_dp],
+    "alp_eval_population": [_c_void_p, _c_dp, _c_i64, _c_int, _c_double, _c_dp, ctypes.POINTER(_c_i64)],
+    "alp_eval_population_enqueue": [_c_void_p, _c_dp, _c_i64, _c_int, _c_double],
+    "alp_eval_population_wait": [_c_void_p, _c_dp, ctypes.POINTER(_c_i64)],
+    "alp_loss_uv": [_c_dp, _c_dp, _c_i64, _c_int, _c_double, _c_dp],
+    "alp_mesh_create": [_c_fp, _c_fp, _c_i64, _c_void_p, _c_int, _c_i64, _c_i64, _c_i64,
+                        ctypes.POINTER(_c_void_p)],
+    "alp_mesh_destroy": [_c_void_p],
+    "alp_render": [_c_void_p, _c_dp, _c_dp, _c_double, _c_fp],
+    "alp_render_enqueue": [_c_void_p, _c_dp, _c_dp, _c_double],
+    "alp_render_fetch": [_c_void_p, _c_fp],
+    "alp_distort_image": [_c_fp, _c_i64, _c_i64, _c_i64, _c_dp, _c_fp],
+}
+_RESTYPE = {"alp_last_error": ctypes.c_char_p}
+
+_lock = threading.Lock()
+_lib = None
+_device = None
+
+
+def load():
+    """dlopen the library and declare prototypes (does not touch the GPU)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise AlprojHipError(
+                    -100, f"{LIB_PATH} not found: build it with "
+                          "`python -m alproj_amd._build` (hipcc, gfx950); there is no CPU fallback")
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, args in _SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.argtypes = args
+                fn.restype = _RESTYPE.get(name, _c_int)
+            _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise AlprojHipError(rc, (load().alp_last_error() or b"").decode(errors="replace"))
+
+
+def init(device=None):
+    """Initialise the library on a device (default: LOCAL_RANK or 0).  Idempotent."""
+    global _device
+    lib = load()
+    if device is None:
+        device = _device if _device is not None else int(os.environ.get("LOCAL_RANK", "0"))
+    check(lib.alp_init(int(device)))
+    _device = int(device)
+    return lib
+
+
+def lib():
+    """The initialised library (initialises device 0 / LOCAL_RANK on first use)."""
+    return init()
+
+
+def device_info():
+    l = lib()
+    name = ctypes.create_string_buffer(128)
+    cu = _c_int()
+    mem = _c_i64()
+    check(l.alp_device_info(name, 128, ctypes.byref(cu), ctypes.byref(mem)))
+    return {"arch": name.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value}
+
+
+def params_vector(params):
+    """dict -> float64[25] in ABI order (raises KeyError on a missing key like the reference)."""
+    return np.array([float(params[k]) for k in PARAM_KEYS], dtype=np.float64)
+
+
+def as_dp(a):
+    return a.ctypes.data_as(_c_dp)
+
+
+def as_fp(a):
+    return a.ctypes.data_as(_c_fp)
+
+
+def dtype_code(a):
+    if a.dtype == np.float64:
+        return ALP_F64
+    if a.dtype == np.float32:
+        return ALP_F32
+    raise TypeError(f"unsupported dtype {a.dtype}")
+
+
+PRECISIONS = {"f32": ALP_F32, "f64": ALP_F64, ALP_F32: ALP_F32, ALP_F64: ALP_F64}
+
+
+class Points:
+    """Device-resident point set (RAII wrapper of alp_points_t)."""
+
+    def __init__(self, xyz, origin, precision="f32"):
+        l = lib()
+        xyz = np.ascontiguousarray(xyz)
+        if xyz.dtype not in (np.float32, np.float64):
+            xyz = xyz.astype(np.float64)
+        if xyz.ndim != 2 or xyz.shape[1] != 3:
+            raise ValueError("xyz must have shape (N, 3)")
+        self.n = int(xyz.shape[0])
+        self.precision = PRECISIONS[precision]
+        self.origin = np.ascontiguousarray(origin, dtype=np.float64).reshape(3)
+        h = _c_void_p()
+        check(l.alp_points_create(xyz.ctypes.data_as(_c_void_p), dtype_code(xyz), self.n,
+                                  as_dp(self.origin), self.precision, ctypes.byref(h)))
+        self._h = h
+        self._lib = l
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.alp_points_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_observed(self, uv):
+        uv = np.ascontiguousarray(uv)
+        if uv.dtype not in (np.float32, np.float64):
+            uv = uv.astype(np.float64)
+        if uv.shape != (self.n, 2):
+            raise ValueError(f"observed uv must have shape ({self.n}, 2)")
+        check(self._lib.alp_points_set_observed(self._h, uv.ctypes.data_as(_c_void_p), dtype_code(uv)))
+
+    def project(self, pvec):
+        pvec = np.ascontiguousarray(pvec, dtype=np.float64)
+        check(self._lib.alp_project(self._h, as_dp(pvec)))
+
+    def fetch(self, dtype=np.float64):
+        u = np.empty(self.n, dtype=dtype)
+        v = np.empty(self.n, dtype=dtype)
+        check(self._lib.alp_projected_fetch(self._h, u.ctypes.data_as(_c_void_p),
+                                            v.ctypes.data_as(_c_void_p), dtype_code(u)))
+        return u, v
+
+    def fetch_strided(self, first, stride, count):
+        u = np.empty(count, dtype=np.float64)
+        v = np.empty(count, dtype=np.float64)
+        check(self._lib.alp_projected_fetch_strided(self._h, first, stride, count, as_dp(u), as_dp(v)))
+        return u, v
+
+    def residuals(self, pvec):
+        pvec = np.ascontiguousarray(pvec, dtype=np.float64)
+        out = np.empty(2 * self.n, dtype=np.float64)
+        check(self._lib.alp_residuals(self._h, as_dp(pvec), as_dp(out)))
+        return out
+
+    def eval_population(self, cand, loss_kind, f_scale=10.0):
+        cand = np.ascontiguousarray(cand, dtype=np.float64)
+        if cand.ndim != 2 or cand.shape[1] != NPARAM:
+            raise ValueError("cand must have shape (P, 25)")
+        P = cand.shape[0]
+        losses = np.empty(P, dtype=np.float64)
+        amin = _c_i64()
+        check(self._lib.alp_eval_population(self._h, as_dp(cand), P, int(loss_kind), float(f_scale),
+                                            as_dp(losses), ctypes.byref(amin)))
+        return losses, int(amin.value)
+
+    def eval_population_enqueue(self, cand, loss_kind, f_scale=10.0):
+        cand = np.ascontiguousarray(cand, dtype=np.float64)
+        check(self._lib.alp_eval_population_enqueue(self._h, as_dp(cand), cand.shape[0],
+                                                    int(loss_kind), float(f_scale)))
+        return cand.shape[0]
+
+    def eval_population_wait(self, P):
+        losses = np.empty(P, dtype=np.float64)
+        amin = _c_i64()
+        check(self._lib.alp_eval_population_wait(self._h, as_dp(losses), ctypes.byref(amin)))
+        return losses, int(amin.value)
+
+
+def synchronize():
+    check(lib().alp_synchronize())
+
+
+def event_record(slot):
+    check(lib().alp_event_record(slot))
+
+
+def event_elapsed_ms(a, b):
+    ms = ctypes.c_float()
+    check(lib().alp_event_elapsed_ms(a, b, ctypes.byref(ms)))
+    return float(ms.value)
+
+
+def comm_unique_id():
+    buf = ctypes.create_string_buffer(UNIQUE_ID_BYTES)
+    check(lib().alp_comm_unique_id(buf))
+    return buf.raw
+
+
+def comm_init(uid, rank, world_size):
+    if len(uid) != UNIQUE_ID_BYTES:
+        raise ValueError("unique id must be 128 bytes")
+    check(lib().alp_comm_init(uid, int(rank), int(world_size)))
+
+
+def comm_destroy():
+    check(lib().alp_comm_destroy())

@@ -1,0 +1,263 @@
+// libalproj_hip.so -- library context: device selection, stream, event timers, RCCL
+// communicator, error reporting, and the float64 host-side folding of one camera pose.
+#include "alp_internal.h"
+
+#include <rccl/rccl.h>
+
+#include <cmath>
+
+namespace alp {
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+Context &ctx() {
+    static Context c;
+    return c;
+}
+
+int require_init() {
+    if (!ctx().ready) return fail(ALP_ENOTINIT, "alp_init has not been called (or failed)");
+    return ALP_OK;
+}
+
+#define ALP_NCCL(expr)                                                                    \
+    do {                                                                                  \
+        ncclResult_t r__ = (expr);                                                        \
+        if (r__ != ncclSuccess)                                                           \
+            return ::alp::fail(ALP_ERCCL, "%s failed: %s (%s:%d)", #expr,                 \
+                               ncclGetErrorString(r__), __FILE__, __LINE__);              \
+    } while (0)
+
+int comm_allreduce_sum_f64(double *dev_buf, int64_t count) {
+    Context &c = ctx();
+    if (!c.comm) return ALP_OK;
+    ALP_NCCL(ncclAllReduce(dev_buf, dev_buf, (size_t)count, ncclDouble, ncclSum,
+                           (ncclComm_t)c.comm, c.stream));
+    return ALP_OK;
+}
+
+// ------------------------------------------------------------------ pose folding
+// Reference arithmetic being folded (all float64, src/alproj/optimize.py):
+//   intrinsic_mat :35-38   fov_x = fov*pi/180; fov_y = fov_x*h/w (Q5);
+//                          fx = w/(2 tan(fov_x/2)); fy = h/(2 tan(fov_y/2))
+//   extrinsic_mat :71-95   R = Rx(-(tilt+90)) . Ry(-roll) . Rz(pan);  t = R.(-cam)
+//   project :144-149       cam = R.p + t;  (x,y,z) = K.cam;  u = w - x/z (Q4);  v = y/z
+//   _distort :104-106      c = float32((w-1)/2, (h-1)/2);  x1 = (u-c0)/c0;  y1 = (v-c1)/c1
+// With p = origin + q:  cam = R.q + R.(origin - cam_pos), and
+//   x1 = ((w-c0)/c0) - (x/z)/c0 = ( ((w-c0)/c0).rowZ - rowx/c0 ) . [q;1] / (rowZ.[q;1])
+//   y1 = (y/z)/c1 - 1          = ( rowy/c1 - rowZ ) . [q;1] / (rowZ.[q;1])
+// where rowx = fx.R0 + cx.R2, rowy = fy.R1 + cy.R2, rowZ = R2 (4-vectors incl. translation).
+// The principal-point cancellation (cx.Z against c0.Z) therefore happens here in float64.
+void fold_pose(const double p[ALP_NPARAM], const double origin[3], double rec[POSE_WORDS]) {
+    const double X = p[0], Y = p[1], Z = p[2], fov = p[3], pan_d = p[4], tilt_d = p[5],
+                 roll_d = p[6];
+    const double w = p[21], h = p[22], cx = p[23], cy = p[24];
+    const double pi = M_PI;
+
+    const double fov_x = fov * pi / 180;
+    const double fov_y = fov_x * h / w;
+    const double fx = w / (2 * std::tan(fov_x / 2));
+    const double fy = h / (2 * std::tan(fov_y / 2));
+
+    const double a = pan_d * pi / 180;
+    const double b = -(tilt_d + 90) * pi / 180;
+    const double c = -roll_d * pi / 180;
+    const double rz[3][3] = {{std::cos(a), -std::sin(a), 0}, {std::sin(a), std::cos(a), 0}, {0, 0, 1}};
+    const double rx[3][3] = {{1, 0, 0}, {0, std::cos(b), -std::sin(b)}, {0, std::sin(b), std::cos(b)}};
+    const double ry[3][3] = {{std::cos(c), 0, std::sin(c)}, {0, 1, 0}, {-std::sin(c), 0, std::cos(c)}};
+    double rxy[3][3], R[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += rx[i][k] * ry[k][j];
+            rxy[i][j] = s;
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += rxy[i][k] * rz[k][j];
+            R[i][j] = s;
+        }
+    const double d[3] = {origin[0] - X, origin[1] - Y, origin[2] - Z};
+    double row[3][4];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) row[i][j] = R[i][j];
+        row[i][3] = R[i][0] * d[0] + R[i][1] * d[1] + R[i][2] * d[2];
+    }
+    const double c0 = (double)(float)((w - 1) / 2);
+    const double c1 = (double)(float)((h - 1) / 2);
+    const double A = (w - c0) / c0;
+    for (int j = 0; j < 4; ++j) {
+        const double rowx = fx * row[0][j] + cx * row[2][j];
+        const double rowy = fy * row[1][j] + cy * row[2][j];
+        rec[0 + j] = A * row[2][j] - rowx / c0;
+        rec[4 + j] = rowy / c1 - row[2][j];
+        rec[8 + j] = row[2][j];
+    }
+    for (int i = 0; i < 6; ++i) rec[12 + i] = p[9 + i];   // k1..k6
+    rec[18] = 1 + p[7];                                    // 1 + a1
+    rec[19] = 1 + p[8];                                    // 1 + a2
+    rec[20] = 2 * p[15];                                   // 2 p1
+    rec[21] = 2 * p[16];                                   // 2 p2
+    for (int i = 0; i < 4; ++i) rec[22 + i] = p[17 + i];  // s1..s4
+    rec[26] = c0;
+    rec[27] = c1;
+    for (int i = 28; i < POSE_WORDS; ++i) rec[i] = 0;
+}
+
+}  // namespace alp
+
+using namespace alp;
+
+extern "C" {
+
+int alp_abi_version(void) { return ALP_ABI_VERSION; }
+
+const char *alp_last_error(void) { return g_err; }
+
+int alp_device_count(int *count) {
+    ALP_REQUIRE(count, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(ALP_ENODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return ALP_OK;
+}
+
+int alp_init(int device) {
+    Context &c = ctx();
+    if (c.ready && c.device == device) return ALP_OK;
+    if (c.ready) return fail(ALP_EINVAL, "already initialised on device %d", c.device);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(ALP_ENODEVICE, "no HIP device available (%s); libalproj_hip has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n)
+        return fail(ALP_ENODEVICE, "device %d out of range (have %d)", device, n);
+    ALP_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    ALP_HIP(hipGetDeviceProperties(&prop, device));
+    c.cu_count = prop.multiProcessorCount;
+    ALP_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    for (auto &ev : c.events) ALP_HIP(hipEventCreate(&ev));
+    c.device = device;
+    c.ready = true;
+    return ALP_OK;
+}
+
+int alp_shutdown(void) {
+    Context &c = ctx();
+    if (!c.ready) return ALP_OK;
+    alp_comm_destroy();
+    hipStreamSynchronize(c.stream);
+    for (auto &ev : c.events) {
+        if (ev) hipEventDestroy(ev);
+        ev = nullptr;
+    }
+    hipStreamDestroy(c.stream);
+    c.stream = nullptr;
+    c.ready = false;
+    c.device = -1;
+    return ALP_OK;
+}
+
+int alp_device_info(char *name, int len, int *cu_count, int64_t *hbm_bytes) {
+    if (int rc = require_init()) return rc;
+    hipDeviceProp_t prop;
+    ALP_HIP(hipGetDeviceProperties(&prop, ctx().device));
+    if (name && len > 0) {
+        strncpy(name, prop.gcnArchName, (size_t)len - 1);
+        name[len - 1] = 0;
+    }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return ALP_OK;
+}
+
+int alp_synchronize(void) {
+    if (int rc = require_init()) return rc;
+    ALP_HIP(hipStreamSynchronize(ctx().stream));
+    return ALP_OK;
+}
+
+int alp_event_record(int slot) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(slot >= 0 && slot < 64, "slot out of range");
+    ALP_HIP(hipEventRecord(ctx().events[slot], ctx().stream));
+    return ALP_OK;
+}
+
+int alp_event_elapsed_ms(int a, int b, float *ms) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(a >= 0 && a < 64 && b >= 0 && b < 64 && ms, "bad slot or NULL");
+    ALP_HIP(hipEventSynchronize(ctx().events[b]));
+    ALP_HIP(hipEventElapsedTime(ms, ctx().events[a], ctx().events[b]));
+    return ALP_OK;
+}
+
+// ------------------------------------------------------------------ RCCL
+int alp_comm_unique_id(char id[ALP_UNIQUE_ID_BYTES]) {
+    ALP_REQUIRE(id, "id is NULL");
+    static_assert(sizeof(ncclUniqueId) == ALP_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId uid;
+    ALP_NCCL(ncclGetUniqueId(&uid));
+    memcpy(id, &uid, sizeof(uid));
+    return ALP_OK;
+}
+
+int alp_comm_init(const char id[ALP_UNIQUE_ID_BYTES], int rank, int world_size) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(id, "id is NULL");
+    ALP_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, "bad rank/world_size");
+    Context &c = ctx();
+    if (c.comm) return fail(ALP_EINVAL, "communicator already exists");
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    ncclComm_t comm;
+    ALP_HIP(hipSetDevice(c.device));
+    ALP_NCCL(ncclCommInitRank(&comm, world_size, uid, rank));
+    c.comm = (void *)comm;
+    c.rank = rank;
+    c.world = world_size;
+    return ALP_OK;
+}
+
+int alp_comm_destroy(void) {
+    Context &c = ctx();
+    if (c.comm) {
+        hipStreamSynchronize(c.stream);
+        ncclCommDestroy((ncclComm_t)c.comm);
+        c.comm = nullptr;
+    }
+    c.rank = 0;
+    c.world = 1;
+    return ALP_OK;
+}
+
+int alp_comm_info(int *rank, int *world_size) {
+    if (rank) *rank = ctx().rank;
+    if (world_size) *world_size = ctx().world;
+    return ALP_OK;
+}
+
+}  // extern "C"

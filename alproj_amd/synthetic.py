@@ -1,0 +1,148 @@
+"""Synthetic DSM, camera and GCP workloads; used by tests, smoke
+and bench.py.  Pure numpy, no device work.
+
+The surface mimics the layout produced by the reference's ``get_colored_surface``
+(src/alproj/surface.py:179-211): a square grid of ``n x n`` vertices, row 0 = north, vertex
+id = row * n + col, ``vert`` in X, Z(up), Y order relative to ``offsets = vert.min(0)``, and
+two triangles per cell ``(a, a+n, a+n+1), (a, a+n+1, a+1)``.
+"""
+import math
+
+import numpy as np
+
+ABS_ORIGIN_XZY = np.array([732000.0, 2000.0, 4048000.0])   # X, Z, Y like `offsets`
+SEED = 20260220
+
+BASE_CAMERA = dict(fov=75.0, pan=95.0, tilt=0.0, roll=0.0, a1=1.0, a2=1.0,
+                   k1=0.0, k2=0.0, k3=0.0, k4=0.0, k5=0.0, k6=0.0, p1=0.0, p2=0.0,
+                   s1=0.0, s2=0.0, s3=0.0, s4=0.0, w=5616, h=3744, cx=2808.0, cy=1872.0)
+
+TARGETS_D9 = ["x", "y", "z", "fov", "pan", "tilt", "roll", "a1", "a2"]
+TARGETS_D21 = TARGETS_D9 + ["k1", "k2", "k3", "k4", "k5", "k6", "p1", "p2", "s1", "s2", "s3", "s4"]
+
+
+def grid_side(n_vertices):
+    return int(math.ceil(math.sqrt(n_vertices)))
+
+
+def _elevation(X, Y):
+    return 300.0 * np.sin(X / 700.0) * np.cos(Y / 500.0) + 40.0 * np.sin(X / 37.0) * np.sin(Y / 53.0)
+
+
+def dsm_rows(n_side, row0, row1, res=1.0, seed=SEED, noise=None):
+    """Vertices of grid rows [row0, row1): float32 (count, 3) in X, Z, Y order relative to
+    the surface minimum being (0, zmin, 0) -- i.e. X = col*res, Y = (n-1-row)*res, Z raw.
+
+    ``noise`` (full-grid N(0, 0.5^2) field, flat) may be passed to avoid regenerating it.
+    """
+    if noise is None:
+        noise = np.random.default_rng(seed).normal(0.0, 0.5, n_side * n_side).astype(np.float32)
+    cols = np.arange(n_side, dtype=np.float64) * res
+    out = np.empty(((row1 - row0) * n_side, 3), dtype=np.float32)
+    step = max(1, (1 << 22) // n_side)
+    for r in range(row0, row1, step):
+        r2 = min(row1, r + step)
+        Y = ((n_side - 1 - np.arange(r, r2, dtype=np.float64)) * res)[:, None]
+        Z = _elevation(cols[None, :], Y) + noise[r * n_side:r2 * n_side].reshape(r2 - r, n_side)
+        sl = slice((r - row0) * n_side, (r2 - row0) * n_side)
+        out[sl, 0] = np.broadcast_to(cols[None, :], Z.shape).ravel()
+        out[sl, 1] = Z.ravel()
+        out[sl, 2] = np.broadcast_to(Y, Z.shape).ravel()
+    return out
+
+
+def z_floor(n_side, res=1.0):
+    """Lower bound used as the Z offset (the analytic minimum minus noise head-room), so
+    that shards generated independently agree on `offsets` without a global min pass."""
+    return -345.0
+
+
+def surface(n_side, res=1.0, seed=SEED, rows=None):
+    """-> dict(vert (N,3) f32 X,Z,Y relative to offsets, offsets (3,) f64, n_side, row0, row1)."""
+    row0, row1 = (0, n_side) if rows is None else rows
+    v = dsm_rows(n_side, row0, row1, res, seed)
+    zf = z_floor(n_side, res)
+    v[:, 1] -= np.float32(zf)
+    offsets = ABS_ORIGIN_XZY + np.array([0.0, zf, 0.0])
+    return dict(vert=v, offsets=offsets, n_side=n_side, row0=row0, row1=row1, res=res)
+
+
+def grid_indices(n_side, dtype=np.int64):
+    """Triangle index array of the full regular grid (surface.py:194-201 on a square grid)."""
+    a = (np.arange(n_side - 1)[None, :] + np.arange(n_side - 1)[:, None] * n_side).ravel()
+    ind = np.stack([a, a + n_side, a + n_side + 1, a, a + n_side + 1, a + 1], axis=1)
+    return ind.reshape(-1, 3).astype(dtype)
+
+
+def colors(n_vertices, seed=SEED):
+    return np.random.default_rng(seed + 1).random((n_vertices, 3)).astype(np.float32)
+
+
+def base_params(n_side, res=1.0):
+    """Camera at the centre of the grid's west edge, 50 m above the local terrain, absolute
+    coordinates (x = easting, y = northing, z = elevation)."""
+    xl = 0.0
+    yl = (n_side - 1) * res / 2.0
+    zl = float(_elevation(np.float64(xl), np.float64(yl))) + 50.0
+    p = dict(BASE_CAMERA)
+    p.update(x=ABS_ORIGIN_XZY[0] + xl, y=ABS_ORIGIN_XZY[2] + yl, z=ABS_ORIGIN_XZY[1] + zl)
+    return p
+
+
+def truth_params(n_side, res=1.0):
+    p = base_params(n_side, res)
+    p.update(x=p["x"] + 5, y=p["y"] - 7, z=p["z"] + 3, fov=p["fov"] - 4, pan=p["pan"] + 3,
+             tilt=p["tilt"] + 2, roll=p["roll"] - 1, a1=1.02, a2=0.98, k1=-0.05, k2=0.01,
+             p1=1e-3, p2=-2e-3)
+    return p
+
+
+def vert_to_xyz_abs(vert, offsets):
+    """(N,3) X,Z,Y relative -> (N,3) float64 absolute x, y, z (easting, northing, elevation)."""
+    v = vert.astype(np.float64)
+    return np.stack([v[:, 0] + offsets[0], v[:, 2] + offsets[2], v[:, 1] + offsets[1]], axis=1)
+
+
+def vert_to_xyz_local(vert):
+    """(N,3) f32 X,Z,Y -> (N,3) f32 x, y, z in the frame of `offsets` (no precision loss)."""
+    return np.ascontiguousarray(vert[:, [0, 2, 1]])
+
+
+def local_params(params, offsets):
+    """Camera parameters with the position expressed in the frame of `offsets`
+    (what persp_proj does at reference project.py:204-207)."""
+    p = dict(params)
+    p["x"] = params["x"] - offsets[0]
+    p["y"] = params["y"] - offsets[2]
+    p["z"] = params["z"] - offsets[1]
+    return p
+
+
+def gcp_set(n, params, seed=1, depth=(80.0, 4000.0), noise_px=1.0, margin=0.05):
+    """n well-conditioned ground control points: sampled inside the image of ``params`` by
+    back-projecting random pixels to random depths (float64, absolute coordinates), plus the
+    observed pixel coordinates = ideal pinhole pixel + N(0, noise_px).
+
+    Used where a GCP-like set (everything in front of the camera, as produced by the
+    reference's set_gcp) is wanted instead of the whole DSM.
+    """
+    from math import cos, pi, sin, tan
+    rng = np.random.default_rng(seed)
+    w, h = params["w"], params["h"]
+    u = rng.uniform(margin * w, (1 - margin) * w, n)
+    v = rng.uniform(margin * h, (1 - margin) * h, n)
+    zc = rng.uniform(depth[0], depth[1], n)
+    fov_x = params["fov"] * pi / 180
+    fx = w / (2 * tan(fov_x / 2))
+    fy = h / (2 * tan(fov_x * h / w / 2))
+    xc = (w - u - params["cx"]) / fx * zc       # u = w - (fx X/Z + cx)
+    yc = (v - params["cy"]) / fy * zc
+    a, b, c = params["pan"] * pi / 180, -(params["tilt"] + 90) * pi / 180, -params["roll"] * pi / 180
+    rz = np.array([[cos(a), -sin(a), 0], [sin(a), cos(a), 0], [0, 0, 1.0]])
+    rx = np.array([[1.0, 0, 0], [0, cos(b), -sin(b)], [0, sin(b), cos(b)]])
+    ry = np.array([[cos(c), 0, sin(c)], [0, 1.0, 0], [-sin(c), 0, cos(c)]])
+    rot = rx @ ry @ rz
+    cam = np.stack([xc, yc, zc], axis=0)
+    xyz = (rot.T @ cam).T + np.array([params["x"], params["y"], params["z"]])
+    uv = np.stack([u, v], axis=1) + rng.normal(0.0, noise_px, (n, 2))
+    return xyz, uv

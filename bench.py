@@ -1,0 +1,299 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the alproj camera-projection hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric: "Gpoints/s projected + CMA-ES iters/s, 100M-vertex DSM,
+1/2/4/8 MI355X"): the 100 M-vertex synthetic DSM of SURVEY.md 8(d), resident in HBM as
+float32 planes, row-sharded over the ranks (strong scaling: the total is fixed).
+
+  leg 1 (the timed "steps", `value`): one step = one single-pose forward projection of the
+        whole DSM (every rank projects its shard, no collective).  Gpoints/s = vertices / t.
+  leg 2 (`cma`): CMA-ES generations (ask -> population evaluation on the GPU(s) with one RCCL
+        all-reduce of the P+1 partial sums -> tell), pop = 2048, D = 21 (BASELINE config 5).
+  `cpu_baseline`: the numpy float64 restatement of the reference (oracle/ref_numpy.py) timed
+        on this host on a bounded sample (rank 0, N=1 only).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 measured copy)
+VALU_PEAK = 157.3e12       # flop/s fp32 vector (MI355X_MICROARCH.md)
+BYTES_PER_VERTEX = {"f32": 20, "f64": 40}     # 3 coords in + 2 pixels out
+EVAL_FLOPS = 82            # flop per point-candidate evaluation (Huber), DESIGN.md kernel K2
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--vertices", type=int, default=100_000_000)
+    ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--pop", type=int, default=2048)
+    ap.add_argument("--dims", type=int, default=21, choices=[9, 21])
+    ap.add_argument("--cma-steps", type=int, default=None, help="generations timed (default min(steps, 10))")
+    ap.add_argument("--no-cma", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+class Control:
+    """Control plane: barrier / max-reduce / byte broadcast across the ranks torchrun started.
+    torch.distributed (gloo) is plumbing only; the data path's one collective is the RCCL
+    all-reduce inside libalproj_hip.so."""
+
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        self.torch = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
+            self.dist, self.torch = dist, torch
+            if torch.cuda.is_available():
+                torch.cuda.set_device(self.local_rank)
+
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+
+    def device_sync(self, L):
+        L.synchronize()
+        if self.torch is not None and self.torch.cuda.is_available():
+            self.torch.cuda.synchronize()
+
+    def max(self, x):
+        if not self.dist:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def sum(self, x):
+        if not self.dist:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t[0])
+
+    def bcast_bytes(self, b, n):
+        if not self.dist:
+            return b
+        t = self.torch.zeros(n, dtype=self.torch.uint8)
+        if self.rank == 0:
+            t = self.torch.tensor(list(b), dtype=self.torch.uint8)
+        self.dist.broadcast(t, src=0)
+        return bytes(t.tolist())
+
+    def close(self):
+        if self.dist:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def timed(ctl, L, fn, steps, warmup):
+    """warmup, then EXACTLY `steps` calls bracketed by barrier + device sync on both sides.
+    Returns (wall seconds as max over ranks, device ms between HIP events on the lib stream)."""
+    for _ in range(warmup):
+        fn()
+    ctl.device_sync(L)
+    ctl.barrier()
+    t0 = time.perf_counter()
+    L.event_record(0)
+    for _ in range(steps):
+        fn()
+    L.event_record(1)
+    ctl.device_sync(L)
+    ctl.barrier()
+    t1 = time.perf_counter()
+    dev_ms = L.event_elapsed_ms(0, 1)
+    return ctl.max(t1 - t0), dev_ms
+
+
+def cpu_baseline(n_sample, truth, base, xyz_l_sample, obs_sample):
+    """numpy float64 port of the reference path on the host cores (oracle = checker only)."""
+    from oracle import ref_numpy as orc
+    xyz = xyz_l_sample.astype(np.float64)
+    best_p, best_l = 1e30, 1e30
+    for i in range(3):
+        t = time.perf_counter()
+        uv = orc.project_points(xyz, truth)
+        t1 = time.perf_counter()
+        orc.huber(obs_sample, uv, 10.0)
+        t2 = time.perf_counter()
+        if i:
+            best_p = min(best_p, t1 - t)
+            best_l = min(best_l, t2 - t)
+    return dict(project_s=best_p, eval_s=best_l, n=n_sample)
+
+
+def main():
+    args = parse()
+    ctl = Control()
+    if ctl.world != args.gpus:
+        if ctl.rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ctl.world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        sys.exit(2)
+
+    from alproj_amd import _lib as L
+    from alproj_amd import synthetic as syn
+    from alproj_amd.cma import CMA
+    from oracle import ref_numpy as orc       # checker / cpu_baseline only
+
+    L.init(ctl.local_rank)
+    if ctl.world > 1:
+        uid = L.comm_unique_id() if ctl.rank == 0 else b"\0" * L.UNIQUE_ID_BYTES
+        uid = ctl.bcast_bytes(uid, L.UNIQUE_ID_BYTES)
+        L.comm_init(uid, ctl.rank, ctl.world)
+    info = L.device_info()
+
+    # ---------------------------------------------------------------- workload
+    n_side = syn.grid_side(args.vertices)
+    r0 = n_side * ctl.rank // ctl.world
+    r1 = n_side * (ctl.rank + 1) // ctl.world
+    t_gen = time.perf_counter()
+    surf = syn.surface(n_side, rows=(r0, r1))
+    xyz_l = syn.vert_to_xyz_local(surf["vert"])
+    del surf["vert"]
+    n_local = xyz_l.shape[0]
+    n_total = n_side * n_side
+    base = syn.local_params(syn.base_params(n_side), surf["offsets"])
+    truth = syn.local_params(syn.truth_params(n_side), surf["offsets"])
+    origin = [base["x"], base["y"], base["z"]]
+    pts = L.Points(xyz_l, origin, args.precision)
+    t_gen = time.perf_counter() - t_gen
+    pv_truth = L.params_vector(truth)
+
+    # ---------------------------------------------------------------- leg 1: projection
+    wall, dev_ms = timed(ctl, L, lambda: pts.project(pv_truth), args.steps, args.warmup)
+    ms_per_step = wall / args.steps * 1e3
+    gpts = n_total / (wall / args.steps) / 1e9
+    kern_s = dev_ms / args.steps / 1e3
+    bpv = BYTES_PER_VERTEX[args.precision]
+    achieved = n_local * bpv / kern_s
+
+    # parity spot check on the bench workload itself (outside the timed region)
+    step = max(1, n_local // 4000)
+    cnt = (n_local - 1) // step
+    u, v = pts.fetch_strided(0, step, cnt)
+    sample = xyz_l[0:cnt * step:step].astype(np.float64)
+    ref = orc.project_points(sample, truth)
+    E = orc.extrinsic_mat(truth["pan"], truth["tilt"], truth["roll"], truth["x"], truth["y"], truth["z"])
+    cam = (E[:3, :3] @ sample.T).T + E[:3, 3]
+    ok = cam[:, 2] > 0.02 * np.linalg.norm(cam, axis=1)
+    err = np.abs(np.stack([u, v], 1) - ref)[ok]
+    rel = err / np.maximum(np.abs(ref[ok]), truth["w"])
+    parity_max_rel = float(rel.max()) if rel.size else 0.0
+
+    out = {
+        "metric": "Gpoints/s projected (pinhole + Brown-Conrady, single pose) over the 100M-vertex DSM; "
+                  "CMA-ES iterations/s in `cma`",
+        "value": gpts, "unit": "Gpoints/s", "n_gpus": ctl.world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"{n_total}-vertex synthetic DSM ({n_side}x{n_side} grid), single-pose forward "
+                               "projection, 5616x3744 camera, vertices resident in HBM as SoA planes",
+                   "vertices": n_total, "vertices_per_gpu": n_local, "sharding": f"rows/{ctl.world}",
+                   "precision": args.precision},
+        "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK, "traffic": None,
+                     "kernel": "project_kernel", "kernel_ms": kern_s * 1e3,
+                     "bytes_per_vertex": bpv, "vertices_per_launch": n_local},
+        "parity": {"checked_vertices": int(ok.sum()), "max_rel_err_vs_f64_oracle": parity_max_rel,
+                   "tolerance": 1e-5},
+        "device": info, "setup_s": t_gen,
+    }
+
+    # ---------------------------------------------------------------- leg 2: CMA-ES generations
+    obs = None
+    if not args.no_cma:
+        uu, vv = pts.fetch(np.float32)
+        rng = np.random.default_rng(1 + ctl.rank)
+        obs = np.stack([uu, vv], 1)
+        del uu, vv
+        obs += rng.normal(0.0, 1.0, obs.shape).astype(np.float32)
+        obs[~np.isfinite(obs)] = 0.0
+        pts.set_observed(obs)
+        targets = syn.TARGETS_D9 if args.dims == 9 else syn.TARGETS_D21
+        bounds = orc.bounds_to_array(base, targets)
+        lower, upper = bounds[:, 0], bounds[:, 1]
+        cols = [L.PARAM_KEYS.index(t) for t in targets]
+        basev = L.params_vector(base)
+        opt = CMA(mean=np.full(len(targets), 0.5), sigma=1.0,
+                  bounds=np.column_stack([np.zeros(len(targets)), np.ones(len(targets))]),
+                  population_size=args.pop, n_max_resampling=100, seed=1234)
+        state = {}
+
+        def generation():
+            X = opt.ask_population()
+            cand = np.tile(basev, (args.pop, 1))
+            cand[:, cols] = X * (upper - lower) + lower
+            losses, amin = pts.eval_population(cand, L.LOSS_HUBER, 10.0)
+            opt.tell([(X[i], losses[i]) for i in range(args.pop)])
+            state["best"] = float(losses[amin])
+
+        k_cma = args.cma_steps or min(args.steps, 10)
+        wall_c, _ = timed(ctl, L, generation, k_cma, min(args.warmup, 2))
+        # kernel-only time of one population evaluation (HIP events around enqueue)
+        cand = np.tile(basev, (args.pop, 1))
+        cand[:, cols] = opt.ask_population() * (upper - lower) + lower
+        L.event_record(2)
+        pts.eval_population_enqueue(cand, L.LOSS_HUBER, 10.0)
+        L.event_record(3)
+        pts.eval_population_wait(args.pop)
+        eval_ms = L.event_elapsed_ms(2, 3)
+        evals = n_local * args.pop
+        out["cma"] = {
+            "iters_per_s": k_cma / wall_c, "ms_per_iter": wall_c / k_cma * 1e3, "generations_timed": k_cma,
+            "population": args.pop, "dims": len(targets), "loss": "huber f_scale=10",
+            "point_candidate_evals_per_s": n_total * args.pop * k_cma / wall_c,
+            "best_loss_last_generation": state.get("best"),
+            "collective": "ncclAllReduce(sum, f64, P+1) per generation" if ctl.world > 1 else "none (1 GPU)",
+            "roofline": {"bound": "valu_fp32", "kernel": "popeval_kernel", "kernel_ms": eval_ms,
+                         "achieved": evals * EVAL_FLOPS / (eval_ms / 1e3) / 1e12, "peak": VALU_PEAK / 1e12,
+                         "unit": "TFLOP/s", "frac": evals * EVAL_FLOPS / (eval_ms / 1e3) / VALU_PEAK,
+                         "flop_per_eval": EVAL_FLOPS,
+                         "hbm_frac": n_local * 20 * max(1, args.pop // 256) / (eval_ms / 1e3) / HBM_PEAK},
+        }
+
+    # ---------------------------------------------------------------- CPU baseline (rank 0, N=1)
+    if ctl.world == 1 and not args.no_cpu_baseline:
+        ns = min(n_local, 2_000_000)
+        sl = slice(0, ns * (n_local // ns), n_local // ns)
+        obs_s = (obs[sl][:ns].astype(np.float64) if obs is not None
+                 else np.zeros((ns, 2)))
+        cb = cpu_baseline(ns, truth, base, xyz_l[sl][:ns], obs_s)
+        out["cpu_baseline"] = {
+            "value": ns / cb["project_s"] / 1e9, "unit": "Gpoints/s", "cores": 1, "kind": "port",
+            "sample": f"numpy float64 restatement (oracle/ref_numpy.project_points) on a {ns}-vertex strided "
+                      f"sample of the same DSM, best of 2 after warm-up; os.cpu_count()={os.cpu_count()}",
+            "cma_iters_per_s_extrapolated": 1.0 / (cb["eval_s"] * (n_total / ns) * args.pop),
+        }
+        out["speedup_vs_cpu_baseline"] = gpts / out["cpu_baseline"]["value"]
+
+    pts.close()
+    ctl.close()
+    if ctl.rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

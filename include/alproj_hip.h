@@ -1,0 +1,198 @@
+/*
+ * alproj_hip.h -- C ABI of libalproj_hip.so: the MI355X (gfx950) implementation of the
+ * camera-projection hot path of 0kam/alproj (reference v1.1.1).
+ *
+ * The reference is pure Python and has no FFI layer; its boundary is its public Python
+ * signatures.  Each entry point below names the reference function it replaces (paths
+ * relative to the reference checkout).  The Python side in alproj_amd/ binds these with
+ * ctypes and keeps the reference's signatures (INTEGRATION.md shows the stub a maintainer
+ * of the reference would add).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative ALP_E* code on failure; the message
+ *     for the calling thread's last failure is alp_last_error().  Numerical problems
+ *     (points behind / at the camera) are NOT errors: they surface as inf/NaN exactly like
+ *     the reference (src/alproj/optimize.py:146-149).
+ *   - camera parameters travel as `const double[25]` in the fixed order ALP_PARAM_ORDER
+ *     (keys documented at src/alproj/project.py:157-189).
+ *   - host buffers belong to the caller and are only touched during the call; device
+ *     memory is owned by opaque handles released by the matching *_destroy.
+ *   - one handle is used from one thread at a time (the reference is single-threaded and
+ *     non-reentrant: src/alproj/optimize.py:341-351).
+ *   - there is NO CPU fallback: without a usable HIP device alp_init fails with
+ *     ALP_ENODEVICE and every other call fails with ALP_ENOTINIT.
+ */
+#ifndef ALPROJ_HIP_H
+#define ALPROJ_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALP_ABI_VERSION 1
+
+/* x,y,z,fov,pan,tilt,roll,a1,a2,k1..k6,p1,p2,s1..s4,w,h,cx,cy */
+#define ALP_NPARAM 25
+#define ALP_PARAM_ORDER "x,y,z,fov,pan,tilt,roll,a1,a2,k1,k2,k3,k4,k5,k6,p1,p2,s1,s2,s3,s4,w,h,cx,cy"
+
+enum alp_error {
+    ALP_OK = 0,
+    ALP_EINVAL = -1,     /* bad argument (NULL pointer, negative size, unknown enum) */
+    ALP_ENOTINIT = -2,   /* alp_init has not succeeded in this process */
+    ALP_ENODEVICE = -3,  /* no HIP device / device index out of range */
+    ALP_EHIP = -4,       /* a HIP runtime call failed (message has the hipError string) */
+    ALP_ERCCL = -5,      /* an RCCL call failed */
+    ALP_ESTATE = -6      /* handle is missing something the call needs (e.g. observed uv) */
+};
+
+enum alp_dtype {
+    ALP_F32 = 0,
+    ALP_F64 = 1,
+    ALP_I32 = 2,
+    ALP_I64 = 3
+};
+
+/* Loss kinds of the population evaluation. */
+enum alp_loss {
+    ALP_LOSS_MEAN_DIST = 0, /* "rmse" of the reference = mean Euclidean distance,
+                               src/alproj/optimize.py:176-177 */
+    ALP_LOSS_HUBER = 1      /* src/alproj/optimize.py:205-212 */
+};
+
+/* ---------------------------------------------------------------- library / device --- */
+
+int alp_abi_version(void);
+const char *alp_last_error(void);
+
+/* Select HIP device `device` for this process, create the library stream and scratch
+ * buffers.  Idempotent for the same device. */
+int alp_init(int device);
+int alp_shutdown(void);
+int alp_device_count(int *count);
+/* name[len] receives the gcnArchName ("gfx950:sramecc+:xnack-"); cu_count the CU number. */
+int alp_device_info(char *name, int len, int *cu_count, int64_t *hbm_bytes);
+/* Block until everything queued on the library stream is done. */
+int alp_synchronize(void);
+
+/* HIP-event timer slots on the library stream (what bench.py brackets kernels with).
+ * slot in [0, 64). */
+int alp_event_record(int slot);
+int alp_event_elapsed_ms(int slot_start, int slot_stop, float *ms); /* synchronises on stop */
+
+/* ---------------------------------------------------------------- multi-GPU (RCCL) ---- */
+/* One process per GPU.  Rank 0 calls alp_comm_unique_id and ships the 128 bytes to the
+ * other ranks by any means (the Python side uses the torchrun rendezvous); every rank then
+ * calls alp_comm_init.  With a communicator present, alp_eval_population sums the
+ * per-candidate partial losses and the vertex counts of all ranks with ONE
+ * ncclAllReduce(sum, double, P+1) per call, on the library stream. */
+#define ALP_UNIQUE_ID_BYTES 128
+int alp_comm_unique_id(char id[ALP_UNIQUE_ID_BYTES]);
+int alp_comm_init(const char id[ALP_UNIQUE_ID_BYTES], int rank, int world_size);
+int alp_comm_destroy(void);
+int alp_comm_info(int *rank, int *world_size); /* 0,1 when no communicator */
+
+/* ---------------------------------------------------------------- point sets ---------- */
+/* Device-resident set of 3-D points (GCPs or DSM vertices) -- the `obj_points` DataFrame
+ * of src/alproj/optimize.py:122-141 -- plus, optionally, observed image points
+ * (`img_points`, src/alproj/optimize.py:173-174).
+ *
+ * xyz     n x 3 row-major host array (x, y, z = easting, northing, elevation), in_dtype
+ *         ALP_F32 or ALP_F64, ABSOLUTE coordinates.
+ * origin  local origin subtracted (in float64) before the coordinates are stored; choose
+ *         it near the camera so that float32 storage does not lose the near field.
+ * precision ALP_F32: coordinates, arithmetic and outputs float32 (20 B/vertex streamed);
+ *           ALP_F64: everything float64 (parity mode, 40 B/vertex).
+ */
+typedef struct alp_points alp_points_t;
+
+int alp_points_create(const void *xyz, int in_dtype, int64_t n, const double origin[3],
+                      int precision, alp_points_t **out);
+int alp_points_destroy(alp_points_t *pts);
+int alp_points_count(const alp_points_t *pts, int64_t *n);
+/* uv: n x 2 row-major host array of observed pixel coordinates (u, v). */
+int alp_points_set_observed(alp_points_t *pts, const void *uv, int in_dtype);
+
+/* Forward projection: replaces project(), src/alproj/optimize.py:122-155 (intrinsic_mat
+ * :8-44, extrinsic_mat :46-96 and _distort :98-120 fused into one kernel).
+ * Results stay on the device (planar u[], v[] in the set's precision) ... */
+int alp_project(alp_points_t *pts, const double params[ALP_NPARAM]);
+/* ... until fetched: u_out/v_out are host arrays of n elements of out_dtype (F32/F64). */
+int alp_projected_fetch(alp_points_t *pts, void *u_out, void *v_out, int out_dtype);
+/* Fetch a strided sample (indices first, first+stride, ...; count elements). */
+int alp_projected_fetch_strided(alp_points_t *pts, int64_t first, int64_t stride,
+                                int64_t count, double *u_out, double *v_out);
+
+/* Residual vector (observed - projected), interleaved du0,dv0,du1,dv1,... (2n doubles):
+ * replaces compute_residuals(), src/alproj/optimize.py:215-237.  Needs observed uv. */
+int alp_residuals(alp_points_t *pts, const double params[ALP_NPARAM], double *out);
+
+/* Population-wide reprojection error: replaces the inner loop of CMAOptimizer.optimize,
+ * src/alproj/optimize.py:420-423, i.e. P calls of _proj_error (:347-356) = project +
+ * rmse (:157-178) or huber_loss (:181-212).
+ *
+ * cand      P x 25 row-major candidate parameter vectors (already de-normalised).
+ * loss_out  P doubles: mean over ALL vertices (of all ranks when a communicator exists).
+ * argmin_out index of the smallest loss, first index on ties, NaN never wins unless all
+ *           are NaN (then 0) -- the contract of solutions[0] after CMA.tell's stable sort,
+ *           src/alproj/optimize.py:424-427.
+ */
+int alp_eval_population(alp_points_t *pts, const double *cand, int64_t P, int loss_kind,
+                        double f_scale, double *loss_out, int64_t *argmin_out);
+/* Same, but only enqueues the work on the library stream (H2D of the candidate records,
+ * kernels, all-reduce, D2H into an internal pinned buffer).  alp_eval_population_wait
+ * synchronises and delivers the results of the last enqueue. */
+int alp_eval_population_enqueue(alp_points_t *pts, const double *cand, int64_t P,
+                                int loss_kind, double f_scale);
+int alp_eval_population_wait(alp_points_t *pts, double *loss_out, int64_t *argmin_out);
+
+/* Loss of two host arrays of pixel coordinates (n x 2 row-major doubles each): replaces the
+ * stand-alone rmse(), src/alproj/optimize.py:157-178 (loss_kind ALP_LOSS_MEAN_DIST) and
+ * huber_loss(), :181-212 (ALP_LOSS_HUBER).  Float64 arithmetic on the device. */
+int alp_loss_uv(const double *observed, const double *projected, int64_t n, int loss_kind,
+                double f_scale, double *loss_out);
+
+/* ---------------------------------------------------------------- mesh render --------- */
+/* Device-resident triangle mesh: the vbo/cbo/ibo of src/alproj/project.py:213-215.
+ *
+ * vert   n_vert x 3 float32, X, Z(up), Y order, relative to `offsets`
+ *        (src/alproj/surface.py:189-190, :211).
+ * value  n_vert x 3 float32 per-vertex values (colours, or the vertices themselves for
+ *        reverse_proj, src/alproj/project.py:360); NULL means value == vert.
+ * ind    n_tri x 3 indices (ind_dtype ALP_I32 or ALP_I64), or NULL for the implicit
+ *        regular grid of src/alproj/surface.py:194-201 with grid_h x grid_w vertices
+ *        (n_vert == grid_h * grid_w; vertex id = row * grid_w + col).
+ */
+typedef struct alp_mesh alp_mesh_t;
+
+int alp_mesh_create(const float *vert, const float *value, int64_t n_vert,
+                    const void *ind, int ind_dtype, int64_t n_tri,
+                    int64_t grid_h, int64_t grid_w, alp_mesh_t **out);
+int alp_mesh_destroy(alp_mesh_t *mesh);
+
+/* Depth-buffered render + lens-distortion remap: replaces persp_proj(),
+ * src/alproj/project.py:145-294 (OpenGL draw :210-290, distort :111-143).
+ *
+ * params        camera parameters, ABSOLUTE camera position.
+ * offsets       the 3 offsets (X,Z,Y order) subtracted from the camera position
+ *               (src/alproj/project.py:204-207), or NULL.
+ * min_distance  <= 0 disables the near-field mask (src/alproj/project.py:247, :264).
+ * out           h x w x 3 float32 host image, row 0 = top (after the flipud of :281).
+ */
+int alp_render(alp_mesh_t *mesh, const double params[ALP_NPARAM], const double *offsets,
+               double min_distance, float *out);
+/* Same but leaves the image on the device (for timing); fetch with alp_render_fetch. */
+int alp_render_enqueue(alp_mesh_t *mesh, const double params[ALP_NPARAM],
+                       const double *offsets, double min_distance);
+int alp_render_fetch(alp_mesh_t *mesh, float *out);
+
+/* Image-space distortion remap alone: replaces distort(), src/alproj/project.py:111-143.
+ * img/out: h x w x c float32 host images; coeffs: a1,a2,k1..k6,p1,p2,s1..s4. */
+int alp_distort_image(const float *img, int64_t h, int64_t w, int64_t c,
+                      const double coeffs[14], float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALPROJ_HIP_H */

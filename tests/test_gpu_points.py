@@ -1,0 +1,292 @@
+"""GPU parity tests of the point-set path (projection, losses, residuals, population
+evaluation) -- every call goes through the C ABI of libalproj_hip.so via ctypes and is checked
+against the CPU oracle and the golden vectors generated from the reference.
+
+Tolerances (north_star: 1e-5 relative, argmin bit-exact):
+  * precision "f64": rtol 1e-9 (observed ~1e-13) -- the parity mode
+  * precision "f32": |d| <= 1e-5 * max(|ref|, image width): float32 evaluates the distortion
+    polynomial in coordinates normalised by the image half-size, so its error is ~1e-7 of the
+    image size (~1e-3 px), not of the individual value; ill-conditioned points (|Z_cam| tiny)
+    are excluded for f32 and covered by f64.
+"""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from oracle import ref_numpy as orc
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def L():
+    from alproj_amd import _lib
+    _lib.init(0)
+    return _lib
+
+
+def well_conditioned(xyz, p, frac=0.02):
+    """points whose depth along the optical axis is at least `frac` of their distance."""
+    E = orc.extrinsic_mat(p["pan"], p["tilt"], p["roll"], p["x"], p["y"], p["z"])
+    cam = (E[:3, :3] @ xyz.T).T + E[:3, 3]
+    dist = np.linalg.norm(cam, axis=1)
+    return cam[:, 2] > frac * dist
+
+
+def assert_f32_close(got, ref, w):
+    tol = 1e-5 * np.maximum(np.abs(ref), w)
+    bad = np.abs(got - ref) > tol
+    assert not bad.any(), f"{bad.sum()} values off; worst {np.abs(got - ref).max()} px"
+
+
+# ------------------------------------------------------------------ projection
+def test_project_f64_golden(L):
+    g = load("g3_project.npz")
+    for i, pv in enumerate(g["params"]):
+        p = orc.vector_to_params(pv)
+        xyz = g[f"xyz_{i}"][[0, 1] + list(range(3, 1000))]       # drop the at-camera point
+        ref = g[f"uv_{i}"][[0, 1] + list(range(3, 1000))]
+        with L.Points(xyz, [p["x"], p["y"], p["z"]], "f64") as pts:
+            pts.project(pv)
+            u, v = pts.fetch()
+        np.testing.assert_allclose(np.stack([u, v], 1), ref, rtol=1e-9, atol=1e-9)
+
+
+def test_project_f32_golden(L):
+    g = load("g3_project.npz")
+    for i, pv in enumerate(g["params"]):
+        p = orc.vector_to_params(pv)
+        keep = well_conditioned(g[f"xyz_{i}"], p)
+        keep[2] = False
+        xyz, ref = g[f"xyz_{i}"][keep], g[f"uv_{i}"][keep]
+        assert keep.sum() > 300
+        with L.Points(xyz, [p["x"], p["y"], p["z"]], "f32") as pts:
+            pts.project(pv)
+            u, v = pts.fetch()
+        assert_f32_close(np.stack([u, v], 1), ref, p["w"])
+
+
+def test_project_known_answers_and_nan(L):
+    g = load("g3_project.npz")
+    pv = g["params_known"]
+    p = orc.vector_to_params(pv)
+    with L.Points(g["xyz_known"], [p["x"], p["y"], p["z"]], "f64") as pts:
+        pts.project(pv)
+        u, v = pts.fetch()
+    assert abs(u[0] - 2858.677447353897) < 1e-7 and abs(v[0] - 1922.6842974827396) < 1e-7
+    assert abs(u[3] - 2495.822292923295) < 1e-7 and abs(v[3] - 2100.8565488830186) < 1e-7   # behind camera
+    assert np.isnan(u[4]) and np.isnan(v[4])                                                # at camera (Q7)
+
+
+def test_project_python_api(L):
+    from alproj_amd import optimize as opt
+    g = load("g3_project.npz")
+    p = orc.vector_to_params(g["params"][1])
+    xyz = g["xyz_1"][3:]
+    df = opt.project(pd.DataFrame(xyz, columns=["x", "y", "z"]), p)
+    assert list(df.columns) == ["u", "v"] and len(df) == len(xyz)
+    np.testing.assert_allclose(df.to_numpy(), g["uv_1"][3:], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 255, 256, 257, 1023, 1025, 4099])
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_project_ragged_sizes(L, n, prec):
+    from alproj_amd import synthetic as syn
+    p = syn.truth_params(316)
+    xyz, _ = syn.gcp_set(max(n, 1), p, seed=n + 7)
+    xyz = xyz[:n]
+    with L.Points(xyz, [p["x"], p["y"], p["z"]], prec) as pts:
+        pts.project(L.params_vector(p))
+        u, v = pts.fetch()
+    assert u.shape == (n,)
+    if n:
+        ref = orc.project_points(xyz, p)
+        if prec == "f64":
+            np.testing.assert_allclose(np.stack([u, v], 1), ref, rtol=1e-9, atol=1e-9)
+        else:
+            assert_f32_close(np.stack([u, v], 1), ref, p["w"])
+
+
+# ------------------------------------------------------------------ stand-alone losses / residuals
+def test_losses_golden(L):
+    from alproj_amd import optimize as opt
+    g = load("g4_losses.npz")
+    dfo = pd.DataFrame(g["obs"], columns=["u", "v"])
+    dfp = pd.DataFrame(g["proj"], columns=["u", "v"])
+    assert opt.rmse(dfo, dfp) == pytest.approx(float(g["rmse"]), rel=1e-13)
+    assert opt.huber_loss(dfo, dfp) == pytest.approx(float(g["huber_default"]), rel=1e-13)
+    assert opt.huber_loss(dfo, dfp, 1000.0) == pytest.approx(float(g["huber_1000"]), rel=1e-13)
+    assert opt.huber_loss(dfo, dfp, 0.5) == pytest.approx(float(g["huber_0p5"]), rel=1e-13)
+
+
+def test_residuals_golden(L):
+    from alproj_amd import optimize as opt
+    g = load("g8_residuals.npz")
+    p = orc.vector_to_params(g["params"])
+    r = opt.compute_residuals(pd.DataFrame(g["xyz"], columns=["x", "y", "z"]),
+                              pd.DataFrame(g["uv_obs"], columns=["u", "v"]), p)
+    assert r.shape == g["residuals"].shape
+    np.testing.assert_allclose(r, g["residuals"], rtol=1e-9, atol=1e-9)
+
+
+# ------------------------------------------------------------------ population evaluation
+def _cand_matrix(L, init, tgt, bounds, X):
+    base = L.params_vector(init)
+    cand = np.tile(base, (len(X), 1))
+    cols = [L.PARAM_KEYS.index(t) for t in tgt]
+    cand[:, cols] = X * (bounds[:, 1] - bounds[:, 0]) + bounds[:, 0]
+    return cand
+
+
+@pytest.mark.parametrize("name", ["d9", "d12", "d21"])
+@pytest.mark.parametrize("prec,rtol", [("f64", 1e-10), ("f32", 1e-5)])
+def test_population_golden(L, name, prec, rtol):
+    g = load("g5_population.npz")
+    init = orc.vector_to_params(g["params_init"])
+    tgt = [str(t) for t in g[f"{name}_targets"]]
+    cand = _cand_matrix(L, init, tgt, g[f"{name}_bounds"], g[f"{name}_X"])
+    with L.Points(g["xyz"], [init["x"], init["y"], init["z"]], prec) as pts:
+        pts.set_observed(g["uv_obs"])
+        for tag, kind, fs in (("md", L.LOSS_MEAN_DIST, 0.0), ("hub", L.LOSS_HUBER, 10.0)):
+            losses, amin = pts.eval_population(cand, kind, fs)
+            ref = g[f"{name}_{tag}"]
+            np.testing.assert_allclose(losses, ref, rtol=rtol)
+            assert amin == int(np.argmin(ref))          # argmin bit-exact (first index on the tie)
+            assert losses[3] == losses[7]               # identical candidates -> identical sums
+
+
+@pytest.mark.parametrize("n,P", [(1, 1), (63, 3), (256, 256), (257, 257), (2048, 300), (2049, 5), (5000, 513)])
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_population_ragged(L, n, P, prec):
+    """sizes around the 256-point tile, the 256/128-candidate LDS tile and the V-group tail"""
+    from alproj_amd import synthetic as syn
+    truth = syn.truth_params(316)
+    init = syn.base_params(316)
+    xyz, uv = syn.gcp_set(n, truth, seed=n)
+    rng = np.random.default_rng(P)
+    bounds = orc.bounds_to_array(init, syn.TARGETS_D21)
+    X = rng.uniform(0.35, 0.65, (P, 21))
+    cand = _cand_matrix(L, init, syn.TARGETS_D21, bounds, X)
+    with L.Points(xyz, [init["x"], init["y"], init["z"]], prec) as pts:
+        pts.set_observed(uv)
+        losses, amin = pts.eval_population(cand, L.LOSS_HUBER, 10.0)
+    sel = np.unique(np.concatenate([[0, P - 1, P // 2], rng.integers(0, P, 6)]))
+    ref = np.array([orc.huber(uv, orc.project_points(xyz, orc.vector_to_params(cand[i])), 10.0) for i in sel])
+    np.testing.assert_allclose(losses[sel], ref, rtol=1e-10 if prec == "f64" else 1e-5)
+    assert losses.shape == (P,) and np.isfinite(losses).all()
+    assert amin == int(np.argmin(losses))
+
+
+def test_population_nan_semantics(L):
+    """a point AT the camera poisons that candidate's mean like np.mean does (Q7); NaN never
+    wins the argmin"""
+    from alproj_amd import synthetic as syn
+    p = syn.base_params(316)
+    xyz, uv = syn.gcp_set(100, p, seed=3)
+    cands = np.stack([L.params_vector(p), L.params_vector(dict(p, x=p["x"] + 1.0))])
+    xyz[5] = [p["x"], p["y"], p["z"]]            # candidate 0's camera position exactly
+    with L.Points(xyz, [p["x"], p["y"], p["z"]], "f64") as pts:
+        pts.set_observed(uv)
+        losses, amin = pts.eval_population(cands, L.LOSS_MEAN_DIST, 0.0)
+    assert np.isnan(losses[0]) and np.isfinite(losses[1]) and amin == 1
+
+
+def test_population_needs_observed(L):
+    from alproj_amd import synthetic as syn
+    p = syn.base_params(316)
+    xyz, _ = syn.gcp_set(10, p)
+    with L.Points(xyz, [p["x"], p["y"], p["z"]], "f32") as pts:
+        with pytest.raises(L.AlprojHipError) as e:
+            pts.eval_population(L.params_vector(p)[None, :], L.LOSS_MEAN_DIST, 0.0)
+        assert e.value.code == -6
+
+
+# ------------------------------------------------------------------ full-size properties
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_dsm_10m_properties(L, prec):
+    """BASELINE config 2/3 size (10 M vertices): (a) a strided sample of the projection equals
+    the oracle on the same float32 vertices; (b) shard additivity: N * loss(all) ==
+    N1 * loss(first part) + N2 * loss(rest) -- the identity the multi-GPU all-reduce relies on."""
+    from alproj_amd import synthetic as syn
+    n_side = syn.grid_side(10_000_000)
+    s = syn.surface(n_side)
+    xyz_l = syn.vert_to_xyz_local(s["vert"])
+    truth = syn.local_params(syn.truth_params(n_side), s["offsets"])
+    base = syn.local_params(syn.base_params(n_side), s["offsets"])
+    N = len(xyz_l)
+    origin = [base["x"], base["y"], base["z"]]
+    pv = L.params_vector(truth)
+    with L.Points(xyz_l, origin, prec) as pts:
+        pts.project(pv)
+        step = 9973
+        cnt = (N - 1) // step
+        u, v = pts.fetch_strided(0, step, cnt)
+        sample = xyz_l[0:cnt * step:step].astype(np.float64)
+        ref = orc.project_points(sample, truth)
+        ok = well_conditioned(sample, truth) if prec == "f32" else np.ones(cnt, bool)
+        got = np.stack([u, v], 1)
+        if prec == "f64":
+            np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-9, atol=1e-9)
+        else:
+            assert_f32_close(got[ok], ref[ok], truth["w"])
+        # observed = projection of the truth pose (fetched from the device) + 1 px noise
+        uu, vv = pts.fetch()
+        obs = np.stack([uu, vv], 1) + np.random.default_rng(1).normal(0, 1.0, (N, 2))
+        obs[~np.isfinite(obs)] = 0.0
+        pts.set_observed(obs)
+        rng = np.random.default_rng(2)
+        bounds = orc.bounds_to_array(base, syn.TARGETS_D9)
+        cand = _cand_matrix(L, base, syn.TARGETS_D9, bounds, rng.uniform(0.4, 0.6, (8, 9)))
+        whole, amin_w = pts.eval_population(cand, L.LOSS_HUBER, 10.0)
+    cut = 3_777_777
+    parts = []
+    for a, b in ((0, cut), (cut, N)):
+        with L.Points(xyz_l[a:b], origin, prec) as pp:
+            pp.set_observed(obs[a:b])
+            l, _ = pp.eval_population(cand, L.LOSS_HUBER, 10.0)
+            parts.append(l * (b - a))
+    np.testing.assert_allclose((parts[0] + parts[1]) / N, whole, rtol=1e-12 if prec == "f64" else 2e-6)
+
+
+# ------------------------------------------------------------------ optimisers end to end
+def test_cma_optimizer_recovers_pose(L):
+    from alproj_amd import optimize as opt
+    from alproj_amd import synthetic as syn
+    truth = syn.truth_params(316)
+    init = dict(truth, pan=truth["pan"] + 4, tilt=truth["tilt"] - 3, fov=truth["fov"] + 5,
+                roll=truth["roll"] + 2)
+    xyz, uv = syn.gcp_set(1500, truth, seed=11)
+    o = opt.CMAOptimizer(pd.DataFrame(xyz, columns=["x", "y", "z"]), pd.DataFrame(uv, columns=["u", "v"]), init)
+    o.set_target(["fov", "pan", "tilt", "roll"])
+    params, err = o.optimize(generation=80, sigma=0.3, population_size=32, f_scale=10.0, seed=5,
+                             progress=False)
+    assert set(params) == set(init)
+    assert err < 1.6                                       # noise floor: E|N2(0,1)| = 1.2533 px
+    assert abs(params["pan"] - truth["pan"]) < 0.05 and abs(params["fov"] - truth["fov"]) < 0.1
+    # the reported error is the reference's "rmse" of the returned parameters
+    ref = orc.mean_distance(uv, orc.project_points(xyz, params))
+    assert err == pytest.approx(ref, rel=1e-5)
+
+
+def test_lsq_optimizer(L):
+    from alproj_amd import optimize as opt
+    from alproj_amd import synthetic as syn
+    truth = syn.truth_params(316)
+    init = dict(truth, pan=truth["pan"] + 1, tilt=truth["tilt"] - 1, k1=0.0, k2=0.0)
+    xyz, uv = syn.gcp_set(800, truth, seed=12, noise_px=0.5)
+    o = opt.LsqOptimizer(pd.DataFrame(xyz, columns=["x", "y", "z"]), pd.DataFrame(uv, columns=["u", "v"]), init)
+    o.set_target(["pan", "tilt", "k1", "k2"])
+    params, err = o.optimize(method="trf")
+    assert err < 0.8 and abs(params["pan"] - truth["pan"]) < 0.02
+    with pytest.raises(ValueError):
+        o.optimize(method="lm", bound_widths={"pan": 1})
+    with pytest.raises(ValueError):
+        o.optimize(method="lm", loss="huber")
