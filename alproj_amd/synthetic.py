@@ -118,14 +118,12 @@ def local_params(params, offsets):
     return p
 
 
-def gcp_set(n, params, seed=1, depth=(80.0, 4000.0), noise_px=1.0, margin=0.05):
-    """n well-conditioned ground control points: sampled inside the image of ``params`` by
-    back-projecting random pixels to random depths (float64, absolute coordinates), plus the
-    observed pixel coordinates = ideal pinhole pixel + N(0, noise_px).
-
-    Used where a GCP-like set (everything in front of the camera, as produced by the
-    reference's set_gcp) is wanted instead of the whole DSM.
-    """
+def gcp_points(n, params, seed=1, depth=(80.0, 4000.0), margin=0.05):
+    """n well-conditioned ground-control-like points (float64, absolute coordinates): random
+    pixels of the pinhole image of ``params`` back-projected to random depths.  Everything is
+    in front of the camera and inside the image, as produced by the reference's set_gcp.
+    Observed pixel coordinates are NOT produced here (they need a projection: the tests use
+    the oracle, bench.py the device)."""
     from math import cos, pi, sin, tan
     rng = np.random.default_rng(seed)
     w, h = params["w"], params["h"]
@@ -143,6 +141,4 @@ def gcp_set(n, params, seed=1, depth=(80.0, 4000.0), noise_px=1.0, margin=0.05):
     ry = np.array([[cos(c), 0, sin(c)], [0, 1.0, 0], [-sin(c), 0, cos(c)]])
     rot = rx @ ry @ rz
     cam = np.stack([xc, yc, zc], axis=0)
-    xyz = (rot.T @ cam).T + np.array([params["x"], params["y"], params["z"]])
-    uv = np.stack([u, v], axis=1) + rng.normal(0.0, noise_px, (n, 2))
-    return xyz, uv
+    return (rot.T @ cam).T + np.array([params["x"], params["y"], params["z"]])

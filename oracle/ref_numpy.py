@@ -294,3 +294,28 @@ def distort_image(img, coeffs):
     """project.py:111-143."""
     mx, my = distort_maps(img.shape[1], img.shape[0], coeffs)
     return remap_nearest(img, mx, my)
+
+
+# --------------------------------------------------------------------------------------
+# conditioning diagnostics (used by tests to decide which tolerance applies to float32)
+# --------------------------------------------------------------------------------------
+def conditioning(xyz, params):
+    """For one pose: (min |Z_cam|/|p-cam|, min |radial denominator|) over the points.
+
+    The pixel coordinates are rational functions of the point; their float32 evaluation error
+    is ~1e-7 amplified by 1/(Z_cam/|p-cam|) (perspective divide, optimize.py:147-148) and by
+    1/|1 + k4 r2 + k5 r4 + k6 r6| resp. 1/|1 + a2 + ...| (optimize.py:112,115).
+    """
+    xyz = np.asarray(xyz, dtype=np.float64)
+    emat = extrinsic_mat(params["pan"], params["tilt"], params["roll"],
+                         params["x"], params["y"], params["z"])
+    kmat = intrinsic_mat(params["fov"], params["w"], params["h"], params["cx"], params["cy"])
+    cam = emat[:3, :3] @ xyz.T + emat[:3, 3:4]
+    depth_ratio = np.min(np.abs(cam[2]) / np.linalg.norm(cam, axis=0))
+    img = kmat @ cam
+    c = np.array([(params["w"] - 1) / 2, (params["h"] - 1) / 2], dtype="float32")
+    x = ((params["w"] - img[0] / img[2]) - c[0]) / c[0]
+    y = (img[1] / img[2] - c[1]) / c[1]
+    r2 = x * x + y * y
+    den = params["k4"] * r2 + params["k5"] * r2 ** 2 + params["k6"] * r2 ** 3
+    return float(depth_ratio), float(min(np.min(np.abs(1 + den)), np.min(np.abs(1 + params["a2"] + den))))

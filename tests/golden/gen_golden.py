@@ -102,6 +102,19 @@ def points_utm(rng, n, cam):
     return pts
 
 
+def gcp_like(opt, rng, n, p, depth=(60.0, 3500.0)):
+    """n points inside the view of pose p (what set_gcp yields): random pixels of the pinhole
+    image back-projected to random depths through the reference's own K and E matrices."""
+    K = opt.intrinsic_mat(p["fov"], p["w"], p["h"], p["cx"], p["cy"])
+    E = opt.extrinsic_mat(p["pan"], p["tilt"], p["roll"], p["x"], p["y"], p["z"])
+    u = rng.uniform(0.04 * p["w"], 0.96 * p["w"], n)
+    v = rng.uniform(0.04 * p["h"], 0.96 * p["h"], n)
+    z = rng.uniform(depth[0], depth[1], n)
+    img = np.stack([(p["w"] - u) * z, v * z, z])            # u = w - x/z  (optimize.py:147)
+    cam = np.linalg.solve(K, img)
+    return (E[:3, :3].T @ (cam - E[:3, 3:4])).T
+
+
 def main():
     opt, prj = load_reference()
     warnings.simplefilter("ignore")
@@ -144,6 +157,9 @@ def main():
         df = pd.DataFrame(pts, columns=["x", "y", "z"])
         g3[f"xyz_{i}"] = pts
         g3[f"uv_{i}"] = opt.project(df, p).to_numpy()
+        inview = gcp_like(opt, rng, 600, p)
+        g3[f"xyz_inview_{i}"] = inview
+        g3[f"uv_inview_{i}"] = opt.project(pd.DataFrame(inview, columns=["x", "y", "z"]), p).to_numpy()
     # SURVEY 8.2 known answers
     ka = np.array([[733731, 4051071, 2500], [734200.3125, 4050691.75, 2988.827881],
                    [732740.3125, 4051161.75, 2453.355469], [731731, 4051171, 2458],
@@ -172,12 +188,22 @@ def main():
 
     # ---- g5: population loss (the closure of CMAOptimizer._loss_function) -----------------------
     truth = dict(FULL, x=FULL["x"] + 5, y=FULL["y"] - 7, z=FULL["z"] + 3)
-    pts = points_utm(rng, 1200, truth)[3:]          # drop the behind/NaN specials
-    pts = pts[pts[:, 0] > truth["x"] + 50]          # in front of the camera
+    g5_sets = {}
+    # "gcp": GCP-like points inside the image (the optimiser's real input);
+    # "wild": a box around the camera, mostly outside the image, where the distortion
+    #         polynomial explodes (losses ~1e13) -- a float64-only stress case.
+    pts = gcp_like(opt, rng, 1127, truth)
+    wild = points_utm(rng, 1200, truth)[3:]
+    wild = wild[wild[:, 0] > truth["x"] + 50]
+    for tag, pp in (("gcp", pts), ("wild", wild)):
+        dfx_ = pd.DataFrame(pp, columns=["x", "y", "z"])
+        uvo = opt.project(dfx_, truth).to_numpy() + rng.normal(0, 1.0, (len(pp), 2))
+        g5_sets[tag] = (pp, uvo)
+    pts, uv_obs = g5_sets["gcp"]
     dfx = pd.DataFrame(pts, columns=["x", "y", "z"])
-    uv_obs = opt.project(dfx, truth).to_numpy() + rng.normal(0, 1.0, (len(pts), 2))
     dfu = pd.DataFrame(uv_obs, columns=["u", "v"])
-    g5 = dict(xyz=pts, uv_obs=uv_obs, params_init=pvec(FULL))
+    g5 = dict(xyz=pts, uv_obs=uv_obs, params_init=pvec(FULL),
+              wild_xyz=g5_sets["wild"][0], wild_uv_obs=g5_sets["wild"][1])
     targets = {
         "d9": ["x", "y", "z", "fov", "pan", "tilt", "roll", "a1", "a2"],
         "d12": ["k1", "k2", "k3", "k4", "k5", "k6", "p1", "p2", "s1", "s2", "s3", "s4"],
@@ -198,6 +224,13 @@ def main():
         for tag, fs in (("md", None), ("hub", 10.0)):
             f = o._loss_function(bounds, fs)
             g5[f"{name}_{tag}"] = np.array([f(x) for x in X])
+        if name == "d21":
+            ow = opt.CMAOptimizer(pd.DataFrame(g5_sets["wild"][0], columns=["x", "y", "z"]),
+                                  pd.DataFrame(g5_sets["wild"][1], columns=["u", "v"]), dict(FULL))
+            ow.set_target(tgt)
+            for tag, fs in (("md", None), ("hub", 10.0)):
+                f = ow._loss_function(bounds, fs)
+                g5[f"wild_{name}_{tag}"] = np.array([f(x) for x in X])
     np.savez(f"{OUT}/g5_population.npz", **g5)
 
     # ---- g6: bounds_to_array ----------------------------------------------------------------------
