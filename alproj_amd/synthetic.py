@@ -89,6 +89,32 @@ def base_params(n_side, res=1.0):
     return p
 
 
+def standoff_params(n_side, res=1.0):
+    """Camera for the point-set workloads (projection / CMA-ES over EVERY DSM vertex): on the
+    grid's east-west centre line, 0.65 grid lengths west of the west edge, 600 m above the zero
+    plane.  From there the whole surface lies in front of the camera (depth >= 0.6 L) and
+    almost all of it inside the 75-degree image, so every vertex is a well-conditioned GCP.
+
+    (With the camera ON the west edge -- base_params, the render workload -- thousands of
+    vertices sit next to the camera plane; the reference's un-culled projection
+    (optimize.py:146-149, quirk Q7) turns them into 1e6..1e40-pixel residuals that swamp any
+    loss, in float64 as in float32.)"""
+    L = n_side * res
+    p = dict(BASE_CAMERA)
+    p.update(x=ABS_ORIGIN_XZY[0] - 0.65 * L, y=ABS_ORIGIN_XZY[2] + (n_side - 1) * res / 2.0,
+             z=ABS_ORIGIN_XZY[1] + 600.0)
+    return p
+
+
+def perturbed(p):
+    """Ground-truth pose = p + the offsets of SURVEY.md 8(d)."""
+    q = dict(p)
+    q.update(x=p["x"] + 5, y=p["y"] - 7, z=p["z"] + 3, fov=p["fov"] - 4, pan=p["pan"] + 3,
+             tilt=p["tilt"] + 2, roll=p["roll"] - 1, a1=1.02, a2=0.98, k1=-0.05, k2=0.01,
+             p1=1e-3, p2=-2e-3)
+    return q
+
+
 def truth_params(n_side, res=1.0):
     p = base_params(n_side, res)
     p.update(x=p["x"] + 5, y=p["y"] - 7, z=p["z"] + 3, fov=p["fov"] - 4, pan=p["pan"] + 3,
@@ -129,7 +155,7 @@ def gcp_points(n, params, seed=1, depth=(80.0, 4000.0), margin=0.05):
     w, h = params["w"], params["h"]
     u = rng.uniform(margin * w, (1 - margin) * w, n)
     v = rng.uniform(margin * h, (1 - margin) * h, n)
-    zc = rng.uniform(depth[0], depth[1], n)
+    zc = -rng.uniform(depth[0], depth[1], n)     # the reference's camera looks down -Z_cam
     fov_x = params["fov"] * pi / 180
     fx = w / (2 * tan(fov_x / 2))
     fy = h / (2 * tan(fov_x * h / w / 2))

@@ -175,8 +175,8 @@ def main():
     del surf["vert"]
     n_local = xyz_l.shape[0]
     n_total = n_side * n_side
-    base = syn.local_params(syn.base_params(n_side), surf["offsets"])
-    truth = syn.local_params(syn.truth_params(n_side), surf["offsets"])
+    base = syn.local_params(syn.standoff_params(n_side), surf["offsets"])
+    truth = syn.local_params(syn.perturbed(syn.standoff_params(n_side)), surf["offsets"])
     origin = [base["x"], base["y"], base["z"]]
     pts = L.Points(xyz_l, origin, args.precision)
     t_gen = time.perf_counter() - t_gen
@@ -198,7 +198,7 @@ def main():
     ref = orc.project_points(sample, truth)
     E = orc.extrinsic_mat(truth["pan"], truth["tilt"], truth["roll"], truth["x"], truth["y"], truth["z"])
     cam = (E[:3, :3] @ sample.T).T + E[:3, 3]
-    ok = cam[:, 2] > 0.02 * np.linalg.norm(cam, axis=1)
+    ok = np.abs(cam[:, 2]) > 0.02 * np.linalg.norm(cam, axis=1)
     err = np.abs(np.stack([u, v], 1) - ref)[ok]
     rel = err / np.maximum(np.abs(ref[ok]), truth["w"])
     parity_max_rel = float(rel.max()) if rel.size else 0.0

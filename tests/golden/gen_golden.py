@@ -109,7 +109,7 @@ def gcp_like(opt, rng, n, p, depth=(60.0, 3500.0)):
     E = opt.extrinsic_mat(p["pan"], p["tilt"], p["roll"], p["x"], p["y"], p["z"])
     u = rng.uniform(0.04 * p["w"], 0.96 * p["w"], n)
     v = rng.uniform(0.04 * p["h"], 0.96 * p["h"], n)
-    z = rng.uniform(depth[0], depth[1], n)
+    z = -rng.uniform(depth[0], depth[1], n)                 # in front: the camera looks down -Z_cam
     img = np.stack([(p["w"] - u) * z, v * z, z])            # u = w - x/z  (optimize.py:147)
     cam = np.linalg.solve(K, img)
     return (E[:3, :3].T @ (cam - E[:3, 3:4])).T

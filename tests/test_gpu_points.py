@@ -35,11 +35,12 @@ def L():
 
 
 def well_conditioned(xyz, p, frac=0.02):
-    """points whose depth along the optical axis is at least `frac` of their distance."""
+    """points whose |depth| along the optical axis is at least `frac` of their distance (the
+    reference's camera looks down -Z_cam; its pixel maths is symmetric in the sign of Z_cam)."""
     E = orc.extrinsic_mat(p["pan"], p["tilt"], p["roll"], p["x"], p["y"], p["z"])
     cam = (E[:3, :3] @ xyz.T).T + E[:3, 3]
     dist = np.linalg.norm(cam, axis=1)
-    return cam[:, 2] > frac * dist
+    return np.abs(cam[:, 2]) > frac * dist
 
 
 def f32_loss_tolerance(xyz, cand):
@@ -257,8 +258,8 @@ def test_dsm_10m_properties(L, prec):
     n_side = syn.grid_side(10_000_000)
     s = syn.surface(n_side)
     xyz_l = syn.vert_to_xyz_local(s["vert"])
-    truth = syn.local_params(syn.truth_params(n_side), s["offsets"])
-    base = syn.local_params(syn.base_params(n_side), s["offsets"])
+    truth = syn.local_params(syn.perturbed(syn.standoff_params(n_side)), s["offsets"])
+    base = syn.local_params(syn.standoff_params(n_side), s["offsets"])
     N = len(xyz_l)
     origin = [base["x"], base["y"], base["z"]]
     pv = L.params_vector(truth)
