@@ -16,6 +16,9 @@ INCLUDE = os.path.join(ROOT, "include")
 BUILD = os.path.join(ROOT, "build")
 LIB = os.path.join(HERE, "libalproj_hip.so")
 SOURCES = ["alp_core.hip", "alp_points.hip", "alp_raster.hip"]
+# the raster's coverage/visibility arithmetic is specified operation by operation (DESIGN.md
+# section 5): no implicit fused multiply-adds there
+EXTRA_FLAGS = {"alp_raster.hip": ["-ffp-contract=off"]}
 ARCH = "gfx950"
 
 
@@ -36,7 +39,8 @@ def _stale(target, deps):
 def build(force=False, verbose=False):
     """Compile every HIP translation unit for gfx950 and link libalproj_hip.so."""
     os.makedirs(BUILD, exist_ok=True)
-    headers = [os.path.join(CSRC, "alp_internal.h"), os.path.join(INCLUDE, "alproj_hip.h"),
+    headers = [os.path.join(CSRC, "alp_internal.h"), os.path.join(CSRC, "alp_point_kernels.h"),
+               os.path.join(INCLUDE, "alproj_hip.h"),
                os.path.abspath(__file__)]
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
              f"-I{INCLUDE}", f"-I{CSRC}"]
@@ -46,7 +50,8 @@ def build(force=False, verbose=False):
         o = os.path.join(BUILD, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc()] + flags + ["-Rpass-analysis=kernel-resource-usage", "-c", s, "-o", o]
+            cmd = [hipcc()] + flags + EXTRA_FLAGS.get(src, []) + \
+                  ["-Rpass-analysis=kernel-resource-usage", "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)

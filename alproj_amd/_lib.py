@@ -69,6 +69,7 @@ _SIGNATURES = {
     "alp_render": [_c_void_p, _c_dp, _c_dp, _c_double, _c_fp],
     "alp_render_enqueue": [_c_void_p, _c_dp, _c_dp, _c_double],
     "alp_render_fetch": [_c_void_p, _c_fp],
+    "alp_render_fetch_visibility": [_c_void_p, ctypes.POINTER(ctypes.c_uint64)],
     "alp_distort_image": [_c_fp, _c_i64, _c_i64, _c_i64, _c_dp, _c_fp],
 }
 _RESTYPE = {"alp_last_error": ctypes.c_char_p}
@@ -235,6 +236,89 @@ class Points:
         amin = _c_i64()
         check(self._lib.alp_eval_population_wait(self._h, as_dp(losses), ctypes.byref(amin)))
         return losses, int(amin.value)
+
+
+class Mesh:
+    """Device-resident triangle mesh (RAII wrapper of alp_mesh_t).
+
+    ``ind`` may be an (T, 3) int32/int64 array, or None together with ``grid=(rows, cols)`` for
+    the implicit regular grid of the reference's get_colored_surface."""
+
+    def __init__(self, vert, value=None, ind=None, grid=None):
+        l = lib()
+        vert = np.ascontiguousarray(vert, dtype=np.float32)
+        if vert.ndim != 2 or vert.shape[1] != 3:
+            raise ValueError("vert must have shape (N, 3)")
+        if value is not None:
+            value = np.ascontiguousarray(value, dtype=np.float32)
+            if value.shape != vert.shape:
+                raise ValueError("value must have the shape of vert")
+        if ind is None:
+            if grid is None:
+                raise ValueError("either ind or grid=(rows, cols) is required")
+            gh, gw = int(grid[0]), int(grid[1])
+            ind_p, code, n_tri = None, ALP_I32, 0
+        else:
+            ind = np.ascontiguousarray(ind)
+            if ind.dtype not in (np.int32, np.int64):
+                ind = ind.astype(np.int64)
+            if ind.ndim != 2 or ind.shape[1] != 3:
+                raise ValueError("ind must have shape (T, 3)")
+            gh = gw = 0
+            ind_p, code, n_tri = ind.ctypes.data_as(_c_void_p), (ALP_I64 if ind.dtype == np.int64 else ALP_I32), ind.shape[0]
+        h = _c_void_p()
+        check(l.alp_mesh_create(as_fp(vert), None if value is None else as_fp(value), vert.shape[0], ind_p, code,
+                                n_tri, gh, gw, ctypes.byref(h)))
+        self._h, self._lib = h, l
+        self.shape = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.alp_mesh_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def render_enqueue(self, pvec, offsets=None, min_distance=None):
+        pvec = np.ascontiguousarray(pvec, dtype=np.float64)
+        off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.float64)
+        check(self._lib.alp_render_enqueue(self._h, as_dp(pvec), None if off is None else as_dp(off),
+                                           0.0 if min_distance is None else float(min_distance)))
+        self.shape = (int(pvec[22]), int(pvec[21]), 3)
+
+    def fetch(self):
+        out = np.empty(self.shape, dtype=np.float32)
+        check(self._lib.alp_render_fetch(self._h, as_fp(out)))
+        return out
+
+    def fetch_visibility(self):
+        out = np.empty(self.shape[:2], dtype=np.uint64)
+        check(self._lib.alp_render_fetch_visibility(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
+        return out
+
+    def render(self, pvec, offsets=None, min_distance=None):
+        self.render_enqueue(pvec, offsets, min_distance)
+        return self.fetch()
+
+
+def distort_image(img, coeffs):
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    if img.ndim not in (2, 3):
+        raise ValueError("img must be (h, w) or (h, w, c)")
+    h, w = img.shape[:2]
+    c = 1 if img.ndim == 2 else img.shape[2]
+    cf = np.ascontiguousarray(coeffs, dtype=np.float64)
+    if cf.shape != (14,):
+        raise ValueError("distort_coeffs must have 14 entries")
+    out = np.empty_like(img)
+    check(lib().alp_distort_image(as_fp(img), h, w, c, as_dp(cf), as_fp(out)))
+    return out
 
 
 def synchronize():

@@ -1,12 +1,701 @@
-// placeholder until the raster lands
+// libalproj_hip.so -- depth-buffered mesh render + lens-distortion remap: the OpenGL
+// replacement for persp_proj(), src/alproj/project.py:145-294 (call stack in SURVEY.md 3.2).
+//
+// What the reference makes OpenGL do, and where it is restated here:
+//   project.py:203-207  camera position minus offsets (X,Z,Y order)        -> make_view()
+//   project.py:13-54    projection_mat, used WITHOUT cx,cy (:257) and untransposed (:262):
+//                       clip = (fx vx, fy vy, -1, vz) => near plane at view depth 1, no far
+//                       plane, principal point ignored (quirks Q10, Q11)      -> to_window()
+//   project.py:56-109   modelview_mat R = Rz(roll) Rx(tilt) Ry(360-pan)      -> make_view()
+//   project.py:211-212  depth test GL_LESS + back-face culling (CCW front)   -> raster_tri()
+//   project.py:217-253  varyings value, |view_pos|; min_dist mask            -> shade()
+//   project.py:269-281  clear to 0, one indexed TRIANGLES draw, readback, flipud
+//   project.py:111-143  distort(): inverted-coefficient source map, nearest gather, 0 border
+//                                                                         -> remap_source()
+//
+// Pipeline (all on the library stream):
+//   1. clear the 64-bit visibility buffer (one word per pixel: float32 1/vz << 32 | ~triangle id)
+//   2. raster_kernel: one thread per triangle: gather 3 vertices, view transform, near-plane
+//      clip, snap to 1/256 px, exact int64 edge functions; triangles covering at most
+//      SMALL_PIXELS pixel centres are finished in the thread (64-bit atomicMax per covered
+//      pixel), larger ones are split into 64x64-pixel work items appended to a queue
+//   3. raster_large_kernel: one wave per work item, one lane per pixel column
+//   4. resolve_kernel: one thread per OUTPUT pixel: distortion source map (float64), fetch the
+//      winning triangle, perspective-correct interpolation by ray/triangle intersection in view
+//      space, min_distance mask, write h x w x 3 float32 (row 0 = top)
+// The arithmetic that decides coverage and visibility is specified step by step in DESIGN.md
+// section 5 and compiled with -ffp-contract=off so that it is reproducible bit for bit.
+//
+// Rasterisation rules OpenGL leaves to the implementation (sub-pixel snapping, tie-break on
+// shared edges, depth-buffer precision) cannot be pinned against the reference's GL driver:
+// see DESIGN.md "parity unpinned" -- the choices made are watertight and deterministic.
 #include "alp_internal.h"
-using namespace alp;
-struct alp_mesh { int dummy; };
-extern "C" {
-int alp_mesh_create(const float *, const float *, int64_t, const void *, int, int64_t, int64_t, int64_t, alp_mesh_t **) { return fail(ALP_ESTATE, "render not built yet"); }
-int alp_mesh_destroy(alp_mesh_t *) { return ALP_OK; }
-int alp_render(alp_mesh_t *, const double *, const double *, double, float *) { return fail(ALP_ESTATE, "render not built yet"); }
-int alp_render_enqueue(alp_mesh_t *, const double *, const double *, double) { return fail(ALP_ESTATE, "render not built yet"); }
-int alp_render_fetch(alp_mesh_t *, float *) { return fail(ALP_ESTATE, "render not built yet"); }
-int alp_distort_image(const float *, int64_t, int64_t, int64_t, const double *, float *) { return fail(ALP_ESTATE, "render not built yet"); }
+
+#include <cmath>
+#include <vector>
+
+namespace alp {
+
+constexpr int SUB = 256;                     // sub-pixel units per pixel
+constexpr float COORD_LIMIT = 4194304.0f;    // 2^22 px
+constexpr int SMALL_PIXELS = 32;             // bbox pixel count finished inside raster_kernel
+constexpr int TILE = 64;                     // work-item edge for large triangles
+
+struct View {
+    float R[3][3];
+    float camf[3], caml[3];
+    float fx, fy, sx, sy;
+    int w, h;
+    double fxd, fyd;
+};
+
+struct RemapCoef {     // inverted coefficients of project.py:136-137, float64
+    double a1, a2, k1, k2, k3, k4, k5, k6, p1, p2, s1, s2, s3, s4, c0, c1;
+};
+
+static void make_view(const double *p, const double *offsets, View *v, RemapCoef *rc) {
+    double x = p[0], y = p[1], z = p[2];
+    if (offsets) { x -= offsets[0]; y -= offsets[2]; z -= offsets[1]; }
+    const double pi = M_PI;
+    const double pan = (360 - p[4]) * pi / 180, tilt = p[5] * pi / 180, roll = p[6] * pi / 180;
+    const double rx[3][3] = {{1, 0, 0}, {0, std::cos(tilt), -std::sin(tilt)}, {0, std::sin(tilt), std::cos(tilt)}};
+    const double ry[3][3] = {{std::cos(pan), 0, std::sin(pan)}, {0, 1, 0}, {-std::sin(pan), 0, std::cos(pan)}};
+    const double rz[3][3] = {{std::cos(roll), -std::sin(roll), 0}, {std::sin(roll), std::cos(roll), 0}, {0, 0, 1}};
+    double t[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += rz[i][k] * rx[k][j];
+            t[i][j] = s;
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += t[i][k] * ry[k][j];
+            v->R[i][j] = (float)s;
+        }
+    const double cam[3] = {x, z, y};      // vertices are stored X, Z(up), Y
+    for (int i = 0; i < 3; ++i) {
+        v->camf[i] = (float)cam[i];
+        v->caml[i] = (float)(cam[i] - (double)v->camf[i]);
+    }
+    const double w = p[21], h = p[22];
+    const double fov_x = p[3] * pi / 180, fov_y = fov_x * h / w;
+    v->fxd = 1 / std::tan(fov_x / 2);
+    v->fyd = 1 / std::tan(fov_y / 2);
+    v->fx = (float)v->fxd;
+    v->fy = (float)v->fyd;
+    v->w = (int)w;
+    v->h = (int)h;
+    v->sx = 0.5f * (float)v->w;
+    v->sy = 0.5f * (float)v->h;
+    if (rc) {
+        rc->a1 = 1 / p[7]; rc->a2 = 1 / p[8];
+        rc->k1 = -p[9]; rc->k2 = -p[10]; rc->k3 = -p[11]; rc->k4 = -p[12]; rc->k5 = -p[13]; rc->k6 = -p[14];
+        rc->p1 = -p[15]; rc->p2 = -p[16]; rc->s1 = -p[17]; rc->s2 = -p[18]; rc->s3 = -p[19]; rc->s4 = -p[20];
+        rc->c0 = (double)(float)((w - 1) / 2.0);
+        rc->c1 = (double)(float)((h - 1) / 2.0);
+    }
 }
+
+// ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ void to_view(const View &v, float px, float py, float pz, float out[3]) {
+    const float dx = (px - v.camf[0]) - v.caml[0];
+    const float dy = (py - v.camf[1]) - v.caml[1];
+    const float dz = (pz - v.camf[2]) - v.caml[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        out[i] = __builtin_fmaf(v.R[i][0], dx, __builtin_fmaf(v.R[i][1], dy, v.R[i][2] * dz));
+}
+
+__device__ __forceinline__ void to_window(const View &v, const float q[3], float &xw, float &yw, float &iw) {
+    const float i = 1.0f / q[2];
+    iw = i;
+    xw = __builtin_fmaf((v.fx * q[0]) * i, v.sx, v.sx);
+    yw = __builtin_fmaf((v.fy * q[1]) * i, v.sy, v.sy);
+}
+
+__device__ __forceinline__ long long floor_div(long long a, long long b) {
+    long long q = a / b;
+    return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q;
+}
+
+struct Idx3 { long long a, b, c; };
+
+template <bool IMPLICIT>
+__device__ __forceinline__ Idx3 tri_vertices(const int *__restrict__ ind, long long gw, long long t) {
+    Idx3 r;
+    if constexpr (IMPLICIT) {
+        // regular grid of src/alproj/surface.py:194-201: (a, a+gw, a+gw+1), (a, a+gw+1, a+1)
+        const long long cell = t >> 1, row = cell / (gw - 1), col = cell - row * (gw - 1), a = row * gw + col;
+        r.a = a;
+        r.b = (t & 1) ? a + gw + 1 : a + gw;
+        r.c = (t & 1) ? a + 1 : a + gw + 1;
+    } else {
+        r.a = ind[t * 3 + 0];
+        r.b = ind[t * 3 + 1];
+        r.c = ind[t * 3 + 2];
+    }
+    return r;
+}
+
+// integer set-up of one window-space triangle
+struct TriSetup {
+    long long X[3], Y[3];
+    long long area2;
+    int i0, i1, j0, j1;      // pixel bbox (inclusive), already clamped to the viewport
+    float iw[3];
+    bool valid;
+};
+
+__device__ __forceinline__ TriSetup setup_tri(const View &v, const float xw[3], const float yw[3],
+                                              const float iw[3]) {
+    TriSetup s;
+    s.valid = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        s.X[k] = (long long)__builtin_rintf(xw[k] * (float)SUB);
+        s.Y[k] = (long long)__builtin_rintf(yw[k] * (float)SUB);
+        s.iw[k] = iw[k];
+    }
+    s.area2 = (s.X[1] - s.X[0]) * (s.Y[2] - s.Y[0]) - (s.X[2] - s.X[0]) * (s.Y[1] - s.Y[0]);
+    if (s.area2 <= 0) return s;                                   // back face / degenerate
+    long long minx = s.X[0], maxx = s.X[0], miny = s.Y[0], maxy = s.Y[0];
+#pragma unroll
+    for (int k = 1; k < 3; ++k) {
+        minx = s.X[k] < minx ? s.X[k] : minx;
+        maxx = s.X[k] > maxx ? s.X[k] : maxx;
+        miny = s.Y[k] < miny ? s.Y[k] : miny;
+        maxy = s.Y[k] > maxy ? s.Y[k] : maxy;
+    }
+    long long i0 = -floor_div(-(minx - SUB / 2), SUB), i1 = floor_div(maxx - SUB / 2, SUB);
+    long long j0 = -floor_div(-(miny - SUB / 2), SUB), j1 = floor_div(maxy - SUB / 2, SUB);
+    if (i0 < 0) i0 = 0;
+    if (j0 < 0) j0 = 0;
+    if (i1 > v.w - 1) i1 = v.w - 1;
+    if (j1 > v.h - 1) j1 = v.h - 1;
+    if (i0 > i1 || j0 > j1) return s;
+    s.i0 = (int)i0; s.i1 = (int)i1; s.j0 = (int)j0; s.j1 = (int)j1;
+    s.valid = true;
+    return s;
+}
+
+// coverage + depth of pixel (i, j); returns 0 when the centre is not covered
+__device__ __forceinline__ unsigned long long pixel_key(const TriSetup &s, int i, int j, unsigned tri) {
+    const long long px = (long long)i * SUB + SUB / 2, py = (long long)j * SUB + SUB / 2;
+    long long e[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int a = (k + 1) % 3, b = (k + 2) % 3;
+        const long long dx = s.X[b] - s.X[a], dy = s.Y[b] - s.Y[a];
+        e[k] = dx * (py - s.Y[a]) - dy * (px - s.X[a]);
+        if (e[k] < 0 || (e[k] == 0 && !(dy < 0 || (dy == 0 && dx > 0)))) return 0ull;
+    }
+    const float q = __builtin_fmaf((float)e[2], s.iw[2], __builtin_fmaf((float)e[1], s.iw[1], (float)e[0] * s.iw[0])) /
+                    (float)s.area2;
+    return ((unsigned long long)__float_as_uint(q) << 32) | (unsigned long long)(0xFFFFFFFFu - tri);
+}
+
+__device__ __forceinline__ void vis_max(unsigned long long *vis, const View &v, int i, int j, unsigned long long key) {
+    unsigned long long *dst = vis + (size_t)j * v.w + i;
+    if (key > *dst) atomicMax(dst, key);       // values only grow: a stale read only costs an atomic
+}
+
+// float64 homogeneous fallback for triangles beyond the fixed-point range
+__device__ void raster_big(const View &v, const float q[3][3], unsigned tri, unsigned long long *vis) {
+    double xh[3], yh[3], wh[3];
+    for (int k = 0; k < 3; ++k) {
+        wh[k] = q[k][2];
+        xh[k] = ((double)v.fx * q[k][0] + wh[k]) * v.sx;
+        yh[k] = ((double)v.fy * q[k][1] + wh[k]) * v.sy;
+    }
+    const double det = xh[0] * (yh[1] * wh[2] - yh[2] * wh[1]) - yh[0] * (xh[1] * wh[2] - xh[2] * wh[1]) +
+                       wh[0] * (xh[1] * yh[2] - xh[2] * yh[1]);
+    if (!(det > 0)) return;
+    for (int j = 0; j < v.h; ++j)
+        for (int i = 0; i < v.w; ++i) {
+            const double px = i + 0.5, py = j + 0.5;
+            double e[3];
+            bool inside = true;
+            for (int k = 0; k < 3; ++k) {
+                const int a = (k + 1) % 3, b = (k + 2) % 3;
+                e[k] = px * (yh[a] * wh[b] - yh[b] * wh[a]) - py * (xh[a] * wh[b] - xh[b] * wh[a]) +
+                       (xh[a] * yh[b] - xh[b] * yh[a]);
+                if (!(e[k] > 0)) inside = false;
+            }
+            if (!inside) continue;
+            const float qq = (float)((e[0] + e[1] + e[2]) / det);
+            if (!(qq <= 1.0f)) continue;
+            vis_max(vis, v, i, j, ((unsigned long long)__float_as_uint(qq) << 32) | (unsigned long long)(0xFFFFFFFFu - tri));
+        }
+}
+
+struct WorkItem { unsigned tri; unsigned short sub, tx, ty, pad; };   // sub: fan triangle 0/1
+
+// One triangle -> up to two window-space triangles (near-plane clip).  Returns the count and
+// fills xw/yw/iw[0..3] (fan around vertex 0); `big` when the fixed-point range is exceeded.
+__device__ __forceinline__ int clip_project(const View &v, const float q[3][3], float xw[4], float yw[4],
+                                            float iw[4], bool &big) {
+    const bool in0 = q[0][2] >= 1.0f, in1 = q[1][2] >= 1.0f, in2 = q[2][2] >= 1.0f;
+    const int nin = (int)in0 + (int)in1 + (int)in2;
+    big = false;
+    if (nin == 0) return 0;
+    int np = 0;
+    if (nin == 3) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) to_window(v, q[k], xw[k], yw[k], iw[k]);
+        np = 3;
+    } else {
+        float poly[4][3];
+        const bool in[3] = {in0, in1, in2};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int n = (k + 1) % 3;
+            if (in[k]) { poly[np][0] = q[k][0]; poly[np][1] = q[k][1]; poly[np][2] = q[k][2]; ++np; }
+            if (in[k] != in[n]) {
+                const float *pi_ = in[k] ? q[k] : q[n];
+                const float *po = in[k] ? q[n] : q[k];
+                const float t = (1.0f - pi_[2]) / (po[2] - pi_[2]);
+                poly[np][0] = __builtin_fmaf(t, po[0] - pi_[0], pi_[0]);
+                poly[np][1] = __builtin_fmaf(t, po[1] - pi_[1], pi_[1]);
+                poly[np][2] = 1.0f;
+                ++np;
+            }
+        }
+        for (int k = 0; k < np; ++k) to_window(v, poly[k], xw[k], yw[k], iw[k]);
+    }
+    for (int k = 0; k < np; ++k)
+        if (!(fabsf(xw[k]) < COORD_LIMIT) || !(fabsf(yw[k]) < COORD_LIMIT)) big = true;
+    return np - 2;
+}
+
+template <bool IMPLICIT>
+__device__ __forceinline__ void load_view_tri(const View &v, const float *__restrict__ vert,
+                                              const int *__restrict__ ind, long long gw, long long t,
+                                              float q[3][3]) {
+    const Idx3 id = tri_vertices<IMPLICIT>(ind, gw, t);
+    const long long ids[3] = {id.a, id.b, id.c};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float *p = vert + 3 * ids[k];
+        to_view(v, p[0], p[1], p[2], q[k]);
+    }
+}
+
+// ------------------------------------------------------------------ kernel 2: per-triangle raster
+template <bool IMPLICIT>
+__global__ __launch_bounds__(256) void raster_kernel(const float *__restrict__ vert, const int *__restrict__ ind,
+                                                     long long n_tri, long long gw, View v,
+                                                     unsigned long long *__restrict__ vis,
+                                                     WorkItem *__restrict__ queue, unsigned *__restrict__ qcount,
+                                                     unsigned qcap) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n_tri; t += stride) {
+        float q[3][3];
+        load_view_tri<IMPLICIT>(v, vert, ind, gw, t, q);
+        float xw[4], yw[4], iw[4];
+        bool big;
+        const int ntri = clip_project(v, q, xw, yw, iw, big);
+        if (ntri <= 0) continue;
+        if (big) {                       // rare: hand the whole triangle to the large pass
+            const unsigned slot = atomicAdd(qcount, 1u);
+            if (slot < qcap) queue[slot] = WorkItem{(unsigned)t, 0xFFFF, 0, 0, 0};
+            continue;
+        }
+        for (int f = 0; f < ntri; ++f) {
+            const float x3[3] = {xw[0], xw[f + 1], xw[f + 2]}, y3[3] = {yw[0], yw[f + 1], yw[f + 2]},
+                        i3[3] = {iw[0], iw[f + 1], iw[f + 2]};
+            const TriSetup s = setup_tri(v, x3, y3, i3);
+            if (!s.valid) continue;
+            const int bw = s.i1 - s.i0 + 1, bh = s.j1 - s.j0 + 1;
+            if ((long long)bw * bh <= SMALL_PIXELS) {
+                for (int j = s.j0; j <= s.j1; ++j)
+                    for (int i = s.i0; i <= s.i1; ++i) {
+                        const unsigned long long key = pixel_key(s, i, j, (unsigned)t);
+                        if (key) vis_max(vis, v, i, j, key);
+                    }
+            } else {
+                for (int ty = s.j0 / TILE; ty <= s.j1 / TILE; ++ty)
+                    for (int tx = s.i0 / TILE; tx <= s.i1 / TILE; ++tx) {
+                        const unsigned slot = atomicAdd(qcount, 1u);
+                        if (slot < qcap)
+                            queue[slot] = WorkItem{(unsigned)t, (unsigned short)f, (unsigned short)tx, (unsigned short)ty, 0};
+                    }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ kernel 3: large triangles
+// one wave per (triangle, 64x64-pixel tile): lane = pixel column, loop over the rows
+template <bool IMPLICIT>
+__global__ __launch_bounds__(256) void raster_large_kernel(const float *__restrict__ vert,
+                                                           const int *__restrict__ ind, long long gw, View v,
+                                                           unsigned long long *__restrict__ vis,
+                                                           const WorkItem *__restrict__ queue, unsigned count) {
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (unsigned it = wave; it < count; it += nwaves) {
+        const WorkItem wi = queue[it];
+        float q[3][3];
+        load_view_tri<IMPLICIT>(v, vert, ind, gw, (long long)wi.tri, q);
+        if (wi.sub == 0xFFFF) {
+            if (lane == 0) raster_big(v, q, wi.tri, vis);
+            continue;
+        }
+        float xw[4], yw[4], iw[4];
+        bool big;
+        const int ntri = clip_project(v, q, xw, yw, iw, big);
+        const int f = wi.sub;
+        if (f >= ntri) continue;
+        const float x3[3] = {xw[0], xw[f + 1], xw[f + 2]}, y3[3] = {yw[0], yw[f + 1], yw[f + 2]},
+                    i3[3] = {iw[0], iw[f + 1], iw[f + 2]};
+        const TriSetup s = setup_tri(v, x3, y3, i3);
+        if (!s.valid) continue;
+        const int i = wi.tx * TILE + lane;
+        int ja = wi.ty * TILE, jb = ja + TILE - 1;
+        ja = ja < s.j0 ? s.j0 : ja;
+        jb = jb > s.j1 ? s.j1 : jb;
+        if (i < s.i0 || i > s.i1) continue;
+        for (int j = ja; j <= jb; ++j) {
+            const unsigned long long key = pixel_key(s, i, j, wi.tri);
+            if (key) vis_max(vis, v, i, j, key);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ kernel 4: resolve + remap
+__device__ __forceinline__ bool remap_source(const RemapCoef &c, int w, int h, int x, int y, int &sx, int &sy) {
+    const double x1 = (x - c.c0) / c.c0, y1 = (y - c.c1) / c.c1;
+    const double r = __builtin_sqrt(x1 * x1 + y1 * y1), r2 = r * r, r4 = r2 * r2, r6 = r4 * r2;
+    const double xd = x1 * (1 + c.k1 * r2 + c.k2 * r4 + c.k3 * r6) / (1 + c.k4 * r2 + c.k5 * r4 + c.k6 * r6) +
+                      2 * c.p1 * x1 * y1 + c.p2 * (r2 * 2 * x1 * x1) + c.s1 * r2 + c.s2 * r4;
+    const double yd = y1 * (1 + c.a1 + c.k1 * r2 + c.k2 * r4 + c.k3 * r6) / (1 + c.a2 + c.k4 * r2 + c.k5 * r4 + c.k6 * r6) +
+                      2 * c.p1 * x1 * y1 + c.p2 * (r2 * 2 * y1 * y1) + c.s3 * r2 + c.s4 * r4;
+    const float mx = (float)(xd * c.c0 + c.c0), my = (float)(yd * c.c1 + c.c1);
+    const double rx = __builtin_rint((double)mx), ry = __builtin_rint((double)my);
+    if (!(rx >= 0 && rx < w && ry >= 0 && ry < h)) return false;
+    sx = (int)rx;
+    sy = (int)ry;
+    return true;
+}
+
+template <bool IMPLICIT>
+__global__ __launch_bounds__(256) void resolve_kernel(const float *__restrict__ vert, const float *__restrict__ value,
+                                                      const int *__restrict__ ind, long long gw, View v,
+                                                      RemapCoef rc, double min_distance,
+                                                      const unsigned long long *__restrict__ vis,
+                                                      float *__restrict__ out) {
+    const long long npix = (long long)v.w * v.h;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += stride) {
+        const int y = (int)(p / v.w), x = (int)(p - (long long)y * v.w);
+        float o[3] = {0.0f, 0.0f, 0.0f};
+        int sx, sy;
+        if (remap_source(rc, v.w, v.h, x, y, sx, sy)) {
+            const int j = v.h - 1 - sy;                               // flipud: image row -> GL row
+            const unsigned long long key = vis[(size_t)j * v.w + sx];
+            if (key) {
+                const long long t = (long long)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+                const Idx3 id = tri_vertices<IMPLICIT>(ind, gw, t);
+                const long long ids[3] = {id.a, id.b, id.c};
+                float qf[3][3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float *pp = vert + 3 * ids[k];
+                    to_view(v, pp[0], pp[1], pp[2], qf[k]);
+                }
+                const double A[3] = {qf[0][0], qf[0][1], qf[0][2]}, B[3] = {qf[1][0], qf[1][1], qf[1][2]},
+                             C[3] = {qf[2][0], qf[2][1], qf[2][2]};
+                const double r[3] = {(((double)sx + 0.5) / v.sx - 1.0) / v.fxd,
+                                     (((double)j + 0.5) / v.sy - 1.0) / v.fyd, 1.0};
+                const double e1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
+                const double pv[3] = {r[1] * e2[2] - r[2] * e2[1], r[2] * e2[0] - r[0] * e2[2], r[0] * e2[1] - r[1] * e2[0]};
+                const double det = e1[0] * pv[0] + e1[1] * pv[1] + e1[2] * pv[2];
+                const double tv[3] = {-A[0], -A[1], -A[2]};
+                const double beta = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) / det;
+                const double qv[3] = {tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0]};
+                const double gamma = (r[0] * qv[0] + r[1] * qv[1] + r[2] * qv[2]) / det;
+                const double alpha = 1.0 - beta - gamma;
+                bool masked = false;
+                if (min_distance > 0) {
+                    const double dA = __builtin_sqrt(A[0] * A[0] + A[1] * A[1] + A[2] * A[2]);
+                    const double dB = __builtin_sqrt(B[0] * B[0] + B[1] * B[1] + B[2] * B[2]);
+                    const double dC = __builtin_sqrt(C[0] * C[0] + C[1] * C[1] + C[2] * C[2]);
+                    masked = alpha * dA + beta * dB + gamma * dC < min_distance;
+                }
+                if (!masked) {
+                    const float *val = value ? value : vert;
+                    const float *va = val + 3 * ids[0], *vb = val + 3 * ids[1], *vc = val + 3 * ids[2];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) o[c] = (float)(alpha * va[c] + beta * vb[c] + gamma * vc[c]);
+                }
+            }
+        }
+        out[p * 3 + 0] = o[0];
+        out[p * 3 + 1] = o[1];
+        out[p * 3 + 2] = o[2];
+    }
+}
+
+// stand-alone distort(): gather of an h x w x c image
+__global__ __launch_bounds__(256) void distort_image_kernel(const float *__restrict__ img, int w, int h, int c,
+                                                            RemapCoef rc, float *__restrict__ out) {
+    const long long npix = (long long)w * h;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += stride) {
+        const int y = (int)(p / w), x = (int)(p - (long long)y * w);
+        int sx, sy;
+        const bool ok = remap_source(rc, w, h, x, y, sx, sy);
+        for (int k = 0; k < c; ++k) out[p * c + k] = ok ? img[((long long)sy * w + sx) * c + k] : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void narrow_indices_kernel(const long long *__restrict__ src, long long count,
+                                                             long long dst_off, int *__restrict__ dst) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+        dst[dst_off + i] = (int)src[i];
+}
+
+}  // namespace alp
+
+using namespace alp;
+
+struct alp_mesh {
+    int64_t n_vert = 0, n_tri = 0, grid_h = 0, grid_w = 0;
+    bool implicit = false;
+    float *vert = nullptr, *value = nullptr;
+    int *ind = nullptr;
+    // per-render state (sized on first use)
+    int w = 0, h = 0;
+    unsigned long long *vis = nullptr;
+    float *image = nullptr;
+    WorkItem *queue = nullptr;
+    unsigned qcap = 0;
+    unsigned *qcount_dev = nullptr;
+    unsigned *qcount_host = nullptr;   // pinned
+    bool rendered = false;
+};
+
+namespace {
+
+int upload_chunked(void *dst, const void *src, size_t bytes) {
+    const size_t CH = (size_t)256 << 20;
+    for (size_t off = 0; off < bytes; off += CH) {
+        const size_t n = bytes - off < CH ? bytes - off : CH;
+        ALP_HIP(hipMemcpyAsync((char *)dst + off, (const char *)src + off, n, hipMemcpyHostToDevice, ctx().stream));
+    }
+    ALP_HIP(hipStreamSynchronize(ctx().stream));
+    return ALP_OK;
+}
+
+int ensure_frame(alp_mesh *m, int w, int h) {
+    if (m->w == w && m->h == h && m->vis) return ALP_OK;
+    if (m->vis) hipFree(m->vis);
+    if (m->image) hipFree(m->image);
+    m->vis = nullptr;
+    m->image = nullptr;
+    ALP_HIP(hipMalloc((void **)&m->vis, (size_t)w * h * sizeof(unsigned long long)));
+    ALP_HIP(hipMalloc((void **)&m->image, (size_t)w * h * 3 * sizeof(float)));
+    m->w = w;
+    m->h = h;
+    return ALP_OK;
+}
+
+int ensure_queue(alp_mesh *m, unsigned cap) {
+    if (m->queue && m->qcap >= cap) return ALP_OK;
+    if (m->queue) hipFree(m->queue);
+    m->queue = nullptr;
+    ALP_HIP(hipMalloc((void **)&m->queue, (size_t)cap * sizeof(WorkItem)));
+    m->qcap = cap;
+    return ALP_OK;
+}
+
+template <bool IMPLICIT>
+int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_distance) {
+    hipStream_t st = ctx().stream;
+    const int cu = ctx().cu_count;
+    ALP_HIP(hipMemsetAsync(m->vis, 0, (size_t)v.w * v.h * sizeof(unsigned long long), st));
+    if (m->n_tri > 0) {
+        const long long want = (m->n_tri + 255) / 256;
+        const int grid = (int)(want < (long long)cu * 16 ? want : (long long)cu * 16);
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            ALP_HIP(hipMemsetAsync(m->qcount_dev, 0, sizeof(unsigned), st));
+            hipLaunchKernelGGL((raster_kernel<IMPLICIT>), dim3(grid), dim3(256), 0, st, m->vert, m->ind,
+                               (long long)m->n_tri, (long long)m->grid_w, v, m->vis, m->queue, m->qcount_dev, m->qcap);
+            ALP_HIP(hipGetLastError());
+            ALP_HIP(hipMemcpyAsync(m->qcount_host, m->qcount_dev, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+            ALP_HIP(hipStreamSynchronize(st));
+            if (*m->qcount_host <= m->qcap) break;
+            // the queue was too small: the small triangles are already in (max is idempotent);
+            // grow it and redo the pass so that every large work item is recorded
+            if (int e = ensure_queue(m, *m->qcount_host + 1024)) return e;
+        }
+        const unsigned count = *m->qcount_host;
+        if (count > 0) {
+            const unsigned waves = count;
+            const unsigned blocks = (waves + 3) / 4;
+            const unsigned g = blocks < (unsigned)cu * 8 ? blocks : (unsigned)cu * 8;
+            hipLaunchKernelGGL((raster_large_kernel<IMPLICIT>), dim3(g), dim3(256), 0, st, m->vert, m->ind,
+                               (long long)m->grid_w, v, m->vis, m->queue, count);
+            ALP_HIP(hipGetLastError());
+        }
+    }
+    const long long npix = (long long)v.w * v.h;
+    const long long want = (npix + 255) / 256;
+    const int grid = (int)(want < (long long)cu * 16 ? want : (long long)cu * 16);
+    hipLaunchKernelGGL((resolve_kernel<IMPLICIT>), dim3(grid), dim3(256), 0, st, m->vert, m->value, m->ind,
+                       (long long)m->grid_w, v, rc, min_distance, m->vis, m->image);
+    ALP_HIP(hipGetLastError());
+    m->rendered = true;
+    return ALP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int alp_mesh_create(const float *vert, const float *value, int64_t n_vert, const void *ind, int ind_dtype,
+                    int64_t n_tri, int64_t grid_h, int64_t grid_w, alp_mesh_t **out) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    ALP_REQUIRE(vert && n_vert > 0, "vert is NULL or empty");
+    ALP_REQUIRE(n_vert < ((int64_t)1 << 31), "more than 2^31 vertices");
+    const bool implicit = ind == nullptr;
+    if (implicit) {
+        ALP_REQUIRE(grid_h >= 2 && grid_w >= 2 && grid_h * grid_w == n_vert, "implicit grid: grid_h*grid_w != n_vert");
+        n_tri = 2 * (grid_h - 1) * (grid_w - 1);
+    } else {
+        ALP_REQUIRE(ind_dtype == ALP_I32 || ind_dtype == ALP_I64, "ind_dtype must be ALP_I32 or ALP_I64");
+        ALP_REQUIRE(n_tri >= 0, "n_tri is negative");
+    }
+    ALP_REQUIRE(n_tri < ((int64_t)1 << 32) - 1, "more than 2^32-2 triangles");
+    alp_mesh *m = new alp_mesh();
+    m->n_vert = n_vert;
+    m->n_tri = n_tri;
+    m->grid_h = grid_h;
+    m->grid_w = grid_w;
+    m->implicit = implicit;
+    int rc = ALP_OK;
+    auto bail = [&](int code) { alp_mesh_destroy(m); return code; };
+    if (hipMalloc((void **)&m->vert, (size_t)n_vert * 12) != hipSuccess) return bail(fail(ALP_EHIP, "hipMalloc vert"));
+    if ((rc = upload_chunked(m->vert, vert, (size_t)n_vert * 12))) return bail(rc);
+    if (value) {
+        if (hipMalloc((void **)&m->value, (size_t)n_vert * 12) != hipSuccess) return bail(fail(ALP_EHIP, "hipMalloc value"));
+        if ((rc = upload_chunked(m->value, value, (size_t)n_vert * 12))) return bail(rc);
+    }
+    if (!implicit && n_tri > 0) {
+        if (hipMalloc((void **)&m->ind, (size_t)n_tri * 12) != hipSuccess) return bail(fail(ALP_EHIP, "hipMalloc ind"));
+        if (ind_dtype == ALP_I32) {
+            if ((rc = upload_chunked(m->ind, ind, (size_t)n_tri * 12))) return bail(rc);
+            // range check on the host copy: an out-of-range index would fault in the kernels
+            const int *h = (const int *)ind;
+            for (int64_t i = 0; i < n_tri * 3; ++i)
+                if (h[i] < 0 || h[i] >= n_vert) return bail(fail(ALP_EINVAL, "index %lld out of range at %lld", (long long)h[i], (long long)i));
+        } else {
+            const long long *h = (const long long *)ind;
+            for (int64_t i = 0; i < n_tri * 3; ++i)
+                if (h[i] < 0 || h[i] >= n_vert) return bail(fail(ALP_EINVAL, "index %lld out of range at %lld", h[i], (long long)i));
+            const int64_t CH = 16 << 20;
+            long long *stage = nullptr;
+            const int64_t total = n_tri * 3;
+            const int64_t ch = total < CH ? total : CH;
+            if (hipMalloc((void **)&stage, (size_t)ch * 8) != hipSuccess) return bail(fail(ALP_EHIP, "hipMalloc stage"));
+            for (int64_t off = 0; off < total && !rc; off += ch) {
+                const int64_t cnt = total - off < ch ? total - off : ch;
+                hipError_t e = hipMemcpyAsync(stage, h + off, (size_t)cnt * 8, hipMemcpyHostToDevice, ctx().stream);
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL(narrow_indices_kernel, dim3(4096), dim3(256), 0, ctx().stream, stage, cnt, off, m->ind);
+                    e = hipStreamSynchronize(ctx().stream);
+                }
+                if (e != hipSuccess) rc = fail(ALP_EHIP, "index upload: %s", hipGetErrorString(e));
+            }
+            hipFree(stage);
+            if (rc) return bail(rc);
+        }
+    }
+    if (hipMalloc((void **)&m->qcount_dev, sizeof(unsigned)) != hipSuccess ||
+        hipHostMalloc((void **)&m->qcount_host, sizeof(unsigned), hipHostMallocDefault) != hipSuccess)
+        return bail(fail(ALP_EHIP, "hipMalloc queue counter"));
+    if ((rc = ensure_queue(m, 1u << 20))) return bail(rc);
+    *out = m;
+    return ALP_OK;
+}
+
+int alp_mesh_destroy(alp_mesh_t *m) {
+    if (!m) return ALP_OK;
+    if (ctx().ready) hipStreamSynchronize(ctx().stream);
+    for (void *p : {(void *)m->vert, (void *)m->value, (void *)m->ind, (void *)m->vis, (void *)m->image,
+                    (void *)m->queue, (void *)m->qcount_dev})
+        if (p) hipFree(p);
+    if (m->qcount_host) hipHostFree(m->qcount_host);
+    delete m;
+    return ALP_OK;
+}
+
+int alp_render_enqueue(alp_mesh_t *m, const double params[ALP_NPARAM], const double *offsets, double min_distance) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(m && params, "NULL argument");
+    ALP_REQUIRE(params[21] >= 1 && params[22] >= 1 && params[21] <= 32768 && params[22] <= 32768,
+                "image size w,h must be in [1, 32768]");
+    View v;
+    RemapCoef rc;
+    make_view(params, offsets, &v, &rc);
+    if (int e = ensure_frame(m, v.w, v.h)) return e;
+    return m->implicit ? render_impl<true>(m, v, rc, min_distance) : render_impl<false>(m, v, rc, min_distance);
+}
+
+int alp_render_fetch(alp_mesh_t *m, float *out) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(m && out, "NULL argument");
+    if (!m->rendered) return fail(ALP_ESTATE, "alp_render_fetch: nothing rendered yet");
+    ALP_HIP(hipMemcpyAsync(out, m->image, (size_t)m->w * m->h * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx().stream));
+    ALP_HIP(hipStreamSynchronize(ctx().stream));
+    return ALP_OK;
+}
+
+int alp_render_fetch_visibility(alp_mesh_t *m, uint64_t *out) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(m && out, "NULL argument");
+    if (!m->rendered) return fail(ALP_ESTATE, "alp_render_fetch_visibility: nothing rendered yet");
+    ALP_HIP(hipMemcpyAsync(out, m->vis, (size_t)m->w * m->h * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx().stream));
+    ALP_HIP(hipStreamSynchronize(ctx().stream));
+    return ALP_OK;
+}
+
+int alp_render(alp_mesh_t *m, const double params[ALP_NPARAM], const double *offsets, double min_distance, float *out) {
+    if (int rc = alp_render_enqueue(m, params, offsets, min_distance)) return rc;
+    return alp_render_fetch(m, out);
+}
+
+int alp_distort_image(const float *img, int64_t h, int64_t w, int64_t c, const double coeffs[14], float *out) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(img && out && coeffs, "NULL argument");
+    ALP_REQUIRE(h >= 1 && w >= 1 && c >= 1 && h <= 32768 && w <= 32768, "bad image shape");
+    double p[ALP_NPARAM] = {0};
+    for (int i = 0; i < 14; ++i) p[7 + i] = coeffs[i];
+    p[3] = 60; p[21] = (double)w; p[22] = (double)h;
+    View v;
+    RemapCoef rc;
+    make_view(p, nullptr, &v, &rc);
+    const size_t bytes = (size_t)h * w * c * sizeof(float);
+    float *dev = nullptr;
+    ALP_HIP(hipMalloc((void **)&dev, 2 * bytes));
+    hipError_t e = hipMemcpyAsync(dev, img, bytes, hipMemcpyHostToDevice, ctx().stream);
+    if (e == hipSuccess) {
+        const long long want = ((long long)h * w + 255) / 256;
+        const int grid = (int)(want < 4096 ? want : 4096);
+        hipLaunchKernelGGL(distort_image_kernel, dim3(grid), dim3(256), 0, ctx().stream, dev, (int)w, (int)h, (int)c, rc,
+                           (float *)((char *)dev + bytes));
+        e = hipMemcpyAsync(out, (char *)dev + bytes, bytes, hipMemcpyDeviceToHost, ctx().stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx().stream);
+    hipFree(dev);
+    if (e != hipSuccess) return fail(ALP_EHIP, "alp_distort_image: %s", hipGetErrorString(e));
+    return ALP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,132 @@
+"""Drop-in counterpart of the render half of the reference module ``alproj.project``
+(src/alproj/project.py): the depth-buffered mesh render that the reference sends through
+OpenGL (moderngl) and the lens-distortion remap it sends through cv2, on an MI355X through
+libalproj_hip.so.
+
+============================  ======================================  =====================
+here                          reference                               device entry point
+============================  ======================================  =====================
+``projection_mat``            project.py:13-54                        (host, 16 scalars)
+``modelview_mat``             project.py:56-109                       (host, 16 scalars)
+``distort``                   project.py:111-143                      alp_distort_image
+``persp_proj``                project.py:145-294                      alp_mesh_create + alp_render
+``sim_image``                 project.py:296-325                      (persp_proj + uint8/BGR)
+``reverse_proj``              project.py:327-374                      (persp_proj + DataFrame)
+============================  ======================================  =====================
+
+``to_geotiff`` (project.py:376-503: rasterio I/O and scipy focal statistics) is outside the
+hot path and not provided.
+
+Extensions (keyword-only, defaults keep the reference behaviour): ``ind=None`` together with
+``grid_shape=(rows, cols)`` renders the regular-grid mesh of ``get_colored_surface`` without
+an index array; a ``Mesh`` object can be passed as ``vert`` to re-render a device-resident
+mesh with new camera parameters (the reference re-uploads everything on every call,
+project.py:210-215).
+"""
+import math
+import warnings
+
+import numpy as np
+import pandas as pd
+
+from . import _lib
+
+__all__ = ["projection_mat", "modelview_mat", "distort", "persp_proj", "sim_image",
+           "reverse_proj", "Mesh"]
+
+Mesh = _lib.Mesh
+
+
+def projection_mat(fov_x_deg, w, h, near=-1, far=1, cx=None, cy=None):
+    """OpenGL-style projection matrix as a flat 16-vector (reference project.py:13-54).
+
+    Kept for API compatibility; the render itself folds these numbers on the host exactly as
+    the reference's call site does (no cx/cy, near=-1, far=1, untransposed upload)."""
+    if cx is None:
+        cx = w / 2
+    if cy is None:
+        cy = h / 2
+    fov_x = fov_x_deg * math.pi / 180
+    fov_y = fov_x * h / w
+    fx = 1 / math.tan(fov_x / 2)
+    fy = 1 / math.tan(fov_y / 2)
+    return np.array([fx, 0, (w - 2 * cx) / w, 0,
+                     0, fy, -(h - 2 * cy) / h, 0,
+                     0, 0, -(far + near) / (far - near), -2 * far * near / (far - near),
+                     0, 0, -1, 0], dtype=np.float64)
+
+
+def modelview_mat(pan_deg, tilt_deg, roll_deg, t_x, t_y, t_z):
+    """OpenGL-style model-view matrix, transposed and flattened (reference project.py:56-109)."""
+    a = (360 - pan_deg) * math.pi / 180
+    b = tilt_deg * math.pi / 180
+    c = roll_deg * math.pi / 180
+    rx = np.array([[1, 0, 0, 0], [0, math.cos(b), -math.sin(b), 0], [0, math.sin(b), math.cos(b), 0], [0, 0, 0, 1.0]])
+    ry = np.array([[math.cos(a), 0, math.sin(a), 0], [0, 1, 0, 0], [-math.sin(a), 0, math.cos(a), 0], [0, 0, 0, 1.0]])
+    rz = np.array([[math.cos(c), -math.sin(c), 0, 0], [math.sin(c), math.cos(c), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]])
+    tr = np.array([[1, 0, 0, -t_x], [0, 1, 0, -t_z], [0, 0, 1, -t_y], [0, 0, 0, 1.0]])
+    return (rz @ rx @ ry @ tr).T.flatten()
+
+
+def distort(img, distort_coeffs):
+    """Distort an (h, w, c) image with the 14 coefficients a1, a2, k1..k6, p1, p2, s1..s4
+    (reference project.py:111-143): nearest-neighbour gather through the inverted-coefficient
+    map, zero outside the image.  float32 images go to the device as they are; other dtypes
+    are converted to float32 and back (exact for uint8/uint16)."""
+    img = np.asarray(img)
+    out = _lib.distort_image(img.astype(np.float32, copy=False), distort_coeffs)
+    return out if img.dtype == np.float32 else out.astype(img.dtype)
+
+
+def _params_checked(params):
+    if params["fov"] > 90:                     # project.py:208-209 (message kept verbatim)
+        warnings.warn("Wider FoV may cause redering fault. Please check the output image carefuly.")
+    return _lib.params_vector(params)
+
+
+def persp_proj(vert, value, ind, params, offsets=None, min_distance=None, *, grid_shape=None):
+    """3D -> 2D perspective render of a triangle mesh with per-vertex values (reference
+    project.py:145-294).  Returns an (h, w, 3) float32 image, row 0 = top, lens distortion
+    applied.
+
+    vert : (N, 3) vertex coordinates in X, Z(vertical), Y order -- or a ``Mesh`` already on
+    the device (then ``value`` and ``ind`` are ignored).
+    """
+    pvec = _params_checked(params)
+    if isinstance(vert, _lib.Mesh):
+        return vert.render(pvec, offsets, min_distance)
+    vert = np.asarray(vert)
+    same = value is vert
+    with _lib.Mesh(vert, None if same else value, ind, grid_shape) as mesh:
+        return mesh.render(pvec, offsets, min_distance)
+
+
+def sim_image(vert, color, ind, params, offsets=None, min_distance=None, *, grid_shape=None):
+    """Simulated landscape image in OpenCV's BGR uint8 layout (reference project.py:296-325)."""
+    raw = persp_proj(vert, color, ind, params, offsets, min_distance=min_distance, grid_shape=grid_shape) * 255
+    raw = raw.astype(np.uint8)
+    return np.ascontiguousarray(raw[:, :, ::-1])          # cv2.COLOR_RGB2BGR
+
+
+def reverse_proj(array, vert, ind, params, offsets=None, chnames=["B", "G", "R"], *, grid_shape=None):
+    """Reverse projection (geo-rectification) of an (h, w, channels) array onto the surface
+    (reference project.py:327-374): a DataFrame with u, v, x, y, z and the channels, one row
+    per pixel that sees the surface (rows with x > 0 in offset-relative coordinates)."""
+    if array.shape[2] != len(chnames):
+        raise ValueError("The array has {} channels but chnames has length of {}. Please set chnames correctly."
+                         .format(array.shape[2], len(chnames)))
+    coord = persp_proj(vert, vert, ind, params, offsets, grid_shape=grid_shape)
+    coord = coord[:, :, [0, 2, 1]]                         # channel: x, z, y -> x, y, z
+    uv = np.meshgrid(np.arange(0, array.shape[1]), np.arange(0, array.shape[0]))
+    uv = np.stack(uv, axis=2)
+    concat = np.concatenate([uv, coord, array], 2).reshape(-1, 5 + array.shape[2])
+    columns = ["u", "v", "x", "y", "z"]
+    columns.extend(chnames)
+    df = pd.DataFrame(concat, columns=columns)
+    df[["u", "v"]] = df[["u", "v"]].astype("int16")
+    df = df[df["x"] > 0]
+    if offsets is not None:
+        df["x"] += offsets[0]
+        df["y"] += offsets[2]
+        df["z"] += offsets[1]
+    return df

@@ -186,6 +186,10 @@ int alp_render(alp_mesh_t *mesh, const double params[ALP_NPARAM], const double *
 int alp_render_enqueue(alp_mesh_t *mesh, const double params[ALP_NPARAM],
                        const double *offsets, double min_distance);
 int alp_render_fetch(alp_mesh_t *mesh, float *out);
+/* The 64-bit visibility buffer of the last render, h x w, OpenGL window orientation (row 0 =
+ * bottom), before the distortion remap: 0 = background, else (float32 bits of 1/depth) << 32 |
+ * (0xFFFFFFFF - index of the winning triangle).  For inspection and parity tests. */
+int alp_render_fetch_visibility(alp_mesh_t *mesh, uint64_t *out);
 
 /* Image-space distortion remap alone: replaces distort(), src/alproj/project.py:111-143.
  * img/out: h x w x c float32 host images; coeffs: a1,a2,k1..k6,p1,p2,s1..s4. */

@@ -1,0 +1,364 @@
+/*
+ * raster_ref.c -- CPU oracle for the depth-buffered mesh render + lens-distortion remap.
+ *
+ * TEST INFRASTRUCTURE ONLY (checker for tests/, __graft_entry__.smoke() and the cpu_baseline
+ * leg of bench.py).  Nothing under alproj_amd/ links, includes or calls this file.
+ *
+ * It restates what the reference's persp_proj() makes OpenGL do
+ * (src/alproj/project.py:145-294), one scalar triangle at a time:
+ *   project.py:203-207  camera position minus offsets (X,Z,Y order, quirk Q16)
+ *   project.py:13-54    projection_mat, called WITHOUT cx,cy (:257) and handed untransposed to
+ *                       a column-major mat4 (:262)  => clip = (fx vx, fy vy, -1, vz): the near
+ *                       plane sits at view depth 1, there is no far plane (Q10, Q11)
+ *   project.py:56-109   modelview_mat: R = Rz(roll) Rx(tilt) Ry(360-pan), then translation
+ *   project.py:211-212  DEPTH_TEST (GL_LESS), CULL_FACE (back faces, CCW = front)
+ *   project.py:217-253  shaders: varyings value and |view_pos|; fragment black if
+ *                       min_dist > 0 and distance < min_dist
+ *   project.py:269-281  RGBA32F target cleared to 0, one indexed TRIANGLES draw, read back,
+ *                       flipud
+ *   project.py:111-143  distort(): source map from _distort with inverted coefficients
+ *                       (optimize.py:98-120), nearest-neighbour gather, zero border
+ *
+ * PARITY UNPINNED against real OpenGL / cv2: moderngl 5.12.0, glcontext 3.0.0, the GL driver
+ * and opencv-python 4.13.0.90 are not part of the reference checkout and are not installed;
+ * the reference holds no fixture for this path.  OpenGL leaves sub-pixel snapping, the
+ * tie-break on shared edges and depth-buffer precision to the implementation; this file fixes
+ * them as follows (the GPU path follows the same written specification):
+ *   - vertices in front of the near plane are projected in float32 and snapped to 1/256 px;
+ *     coverage uses exact 64-bit integer edge functions at pixel centres, a pixel on an edge
+ *     belongs to the triangle whose edge has dy < 0, or dy == 0 and dx > 0 (watertight);
+ *   - triangles crossing the near plane are clipped in view space (Sutherland-Hodgman against
+ *     vz = 1, intersection computed from the inside vertex) and fan-triangulated;
+ *   - depth test on float32 1/vz interpolated affinely in window space (an ideal depth
+ *     buffer; a 24-bit GL buffer z-fights where this does not), ties go to the triangle drawn
+ *     first (GL_LESS);
+ *   - per-pixel values by perspective-correct interpolation = ray/triangle intersection in
+ *     view space (float64).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define SUB 256            /* sub-pixel units per pixel */
+#define COORD_LIMIT 4194304.0f  /* 2^22 px: beyond this a triangle takes the float fallback */
+
+typedef struct {
+    float R[3][3];          /* view rotation */
+    float camf[3], caml[3]; /* camera position hi + lo */
+    float fx, fy, sx, sy;   /* 1/tan(fov/2), 1/tan(fov_y/2), w/2, h/2 */
+    int w, h;
+    double Rd[3][3], camd[3], fxd, fyd;
+} view_t;
+
+static void setup_view(const double *p, const double *offsets, view_t *v) {
+    /* p: x,y,z,fov,pan,tilt,roll,a1,a2,k1..k6,p1,p2,s1..s4,w,h,cx,cy */
+    double x = p[0], y = p[1], z = p[2];
+    if (offsets) { x -= offsets[0]; y -= offsets[2]; z -= offsets[1]; }   /* project.py:204-207 */
+    const double pi = M_PI;
+    const double pan = (360 - p[4]) * pi / 180, tilt = p[5] * pi / 180, roll = p[6] * pi / 180;
+    const double rx[3][3] = {{1, 0, 0}, {0, cos(tilt), -sin(tilt)}, {0, sin(tilt), cos(tilt)}};
+    const double ry[3][3] = {{cos(pan), 0, sin(pan)}, {0, 1, 0}, {-sin(pan), 0, cos(pan)}};
+    const double rz[3][3] = {{cos(roll), -sin(roll), 0}, {sin(roll), cos(roll), 0}, {0, 0, 1}};
+    double t[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += rz[i][k] * rx[k][j];
+            t[i][j] = s;
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += t[i][k] * ry[k][j];
+            v->Rd[i][j] = s;
+            v->R[i][j] = (float)s;
+        }
+    /* translation (-t_x, -t_z, -t_y) on vertices stored X, Z(up), Y (project.py:103-108) */
+    v->camd[0] = x; v->camd[1] = z; v->camd[2] = y;
+    for (int i = 0; i < 3; ++i) {
+        v->camf[i] = (float)v->camd[i];
+        v->caml[i] = (float)(v->camd[i] - (double)v->camf[i]);
+    }
+    const double w = p[21], h = p[22];
+    const double fov_x = p[3] * pi / 180, fov_y = fov_x * h / w;     /* project.py:44-47 */
+    v->fxd = 1 / tan(fov_x / 2);
+    v->fyd = 1 / tan(fov_y / 2);
+    v->fx = (float)v->fxd;
+    v->fy = (float)v->fyd;
+    v->w = (int)w;
+    v->h = (int)h;
+    v->sx = 0.5f * (float)v->w;
+    v->sy = 0.5f * (float)v->h;
+}
+
+static void to_view(const view_t *v, const float *p, float out[3]) {
+    const float dx = (p[0] - v->camf[0]) - v->caml[0];
+    const float dy = (p[1] - v->camf[1]) - v->caml[1];
+    const float dz = (p[2] - v->camf[2]) - v->caml[2];
+    for (int i = 0; i < 3; ++i) out[i] = fmaf(v->R[i][0], dx, fmaf(v->R[i][1], dy, v->R[i][2] * dz));
+}
+
+/* window coordinates of a view-space point with vz >= 1 */
+static void to_window(const view_t *v, const float q[3], float *xw, float *yw, float *iw) {
+    const float i = 1.0f / q[2];
+    *iw = i;
+    *xw = fmaf((v->fx * q[0]) * i, v->sx, v->sx);
+    *yw = fmaf((v->fy * q[1]) * i, v->sy, v->sy);
+}
+
+static inline uint32_t fbits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+static inline int64_t floor_div(int64_t a, int64_t b) { int64_t q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
+
+/* rasterise one window-space triangle (already in front of the near plane) into the
+ * visibility buffer: key = depth bits << 32 | (0xFFFFFFFF - tri), larger wins */
+static void raster_tri(const view_t *v, const float xw[3], const float yw[3], const float iw[3], uint32_t tri,
+                       uint64_t *vis) {
+    int64_t X[3], Y[3];
+    for (int k = 0; k < 3; ++k) {
+        if (!(fabsf(xw[k]) < COORD_LIMIT) || !(fabsf(yw[k]) < COORD_LIMIT)) return;   /* see raster_big */
+        X[k] = (int64_t)rintf(xw[k] * (float)SUB);
+        Y[k] = (int64_t)rintf(yw[k] * (float)SUB);
+    }
+    const int64_t area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (X[2] - X[0]) * (Y[1] - Y[0]);
+    if (area2 <= 0) return;                                  /* back face or degenerate: culled */
+    int64_t minx = X[0], maxx = X[0], miny = Y[0], maxy = Y[0];
+    for (int k = 1; k < 3; ++k) {
+        if (X[k] < minx) minx = X[k];
+        if (X[k] > maxx) maxx = X[k];
+        if (Y[k] < miny) miny = Y[k];
+        if (Y[k] > maxy) maxy = Y[k];
+    }
+    /* pixel i has its centre at i*SUB + SUB/2 */
+    int64_t i0 = -floor_div(-(minx - SUB / 2), SUB), i1 = floor_div(maxx - SUB / 2, SUB);
+    int64_t j0 = -floor_div(-(miny - SUB / 2), SUB), j1 = floor_div(maxy - SUB / 2, SUB);
+    if (i0 < 0) i0 = 0;
+    if (j0 < 0) j0 = 0;
+    if (i1 > v->w - 1) i1 = v->w - 1;
+    if (j1 > v->h - 1) j1 = v->h - 1;
+    const float areaf = (float)area2;
+    for (int64_t j = j0; j <= j1; ++j)
+        for (int64_t i = i0; i <= i1; ++i) {
+            const int64_t px = i * SUB + SUB / 2, py = j * SUB + SUB / 2;
+            int64_t e[3];
+            int inside = 1;
+            for (int k = 0; k < 3 && inside; ++k) {
+                const int a = (k + 1) % 3, b = (k + 2) % 3;          /* edge opposite vertex k */
+                const int64_t dx = X[b] - X[a], dy = Y[b] - Y[a];
+                e[k] = dx * (py - Y[a]) - dy * (px - X[a]);
+                if (e[k] < 0 || (e[k] == 0 && !(dy < 0 || (dy == 0 && dx > 0)))) inside = 0;
+            }
+            if (!inside) continue;
+            const float q = fmaf((float)e[2], iw[2], fmaf((float)e[1], iw[1], (float)e[0] * iw[0])) / areaf;
+            const uint64_t key = ((uint64_t)fbits(q) << 32) | (uint64_t)(0xFFFFFFFFu - tri);
+            uint64_t *dst = &vis[(size_t)j * v->w + i];
+            if (key > *dst) *dst = key;
+        }
+}
+
+/* fallback for triangles whose projected coordinates exceed the fixed-point range: float64
+ * homogeneous edge functions evaluated at the pixel centres of the viewport (not snapped;
+ * such triangles graze the near plane far outside the image) */
+static void raster_big(const view_t *v, const float q[3][3], uint32_t tri, uint64_t *vis) {
+    double xh[3], yh[3], wh[3];
+    for (int k = 0; k < 3; ++k) {
+        wh[k] = q[k][2];
+        xh[k] = ((double)v->fx * q[k][0] + wh[k]) * v->sx;
+        yh[k] = ((double)v->fy * q[k][1] + wh[k]) * v->sy;
+    }
+    const double det = xh[0] * (yh[1] * wh[2] - yh[2] * wh[1]) - yh[0] * (xh[1] * wh[2] - xh[2] * wh[1]) +
+                       wh[0] * (xh[1] * yh[2] - xh[2] * yh[1]);
+    if (!(det > 0)) return;
+    for (int j = 0; j < v->h; ++j)
+        for (int i = 0; i < v->w; ++i) {
+            const double px = i + 0.5, py = j + 0.5;
+            double e[3];
+            int inside = 1;
+            for (int k = 0; k < 3; ++k) {
+                const int a = (k + 1) % 3, b = (k + 2) % 3;
+                e[k] = px * (yh[a] * wh[b] - yh[b] * wh[a]) - py * (xh[a] * wh[b] - xh[b] * wh[a]) +
+                       (xh[a] * yh[b] - xh[b] * yh[a]);
+                if (!(e[k] > 0)) inside = 0;
+            }
+            if (!inside) continue;
+            const float qq = (float)((e[0] + e[1] + e[2]) / det);        /* 1/vz at the pixel */
+            if (!(qq <= 1.0f)) continue;                                    /* near plane vz >= 1 */
+            const uint64_t key = ((uint64_t)fbits(qq) << 32) | (uint64_t)(0xFFFFFFFFu - tri);
+            uint64_t *dst = &vis[(size_t)j * v->w + i];
+            if (key > *dst) *dst = key;
+        }
+}
+
+static void draw_triangle(const view_t *v, const float *pa, const float *pb, const float *pc, uint32_t tri,
+                          uint64_t *vis) {
+    float q[3][3];
+    to_view(v, pa, q[0]);
+    to_view(v, pb, q[1]);
+    to_view(v, pc, q[2]);
+    const int in0 = q[0][2] >= 1.0f, in1 = q[1][2] >= 1.0f, in2 = q[2][2] >= 1.0f;
+    const int nin = in0 + in1 + in2;
+    if (nin == 0) return;
+    float xw[4], yw[4], iw[4];
+    if (nin == 3) {
+        int big = 0;
+        for (int k = 0; k < 3; ++k) {
+            to_window(v, q[k], &xw[k], &yw[k], &iw[k]);
+            if (!(fabsf(xw[k]) < COORD_LIMIT) || !(fabsf(yw[k]) < COORD_LIMIT)) big = 1;
+        }
+        if (big) raster_big(v, (const float(*)[3])q, tri, vis);
+        else raster_tri(v, xw, yw, iw, tri, vis);
+        return;
+    }
+    /* clip against vz = 1: walk the edges in order, keep inside vertices, insert crossings */
+    float poly[4][3];
+    int np = 0;
+    const int in[3] = {in0, in1, in2};
+    for (int k = 0; k < 3; ++k) {
+        const int n = (k + 1) % 3;
+        if (in[k]) memcpy(poly[np++], q[k], sizeof(float) * 3);
+        if (in[k] != in[n]) {
+            const float *pi_ = in[k] ? q[k] : q[n];     /* inside endpoint */
+            const float *po = in[k] ? q[n] : q[k];      /* outside endpoint */
+            const float t = (1.0f - pi_[2]) / (po[2] - pi_[2]);
+            poly[np][0] = fmaf(t, po[0] - pi_[0], pi_[0]);
+            poly[np][1] = fmaf(t, po[1] - pi_[1], pi_[1]);
+            poly[np][2] = 1.0f;
+            ++np;
+        }
+    }
+    int big = 0;
+    for (int k = 0; k < np; ++k) {
+        to_window(v, poly[k], &xw[k], &yw[k], &iw[k]);
+        if (!(fabsf(xw[k]) < COORD_LIMIT) || !(fabsf(yw[k]) < COORD_LIMIT)) big = 1;
+    }
+    if (big) { raster_big(v, (const float(*)[3])q, tri, vis); return; }
+    for (int k = 1; k + 1 < np; ++k) {
+        const float x3[3] = {xw[0], xw[k], xw[k + 1]}, y3[3] = {yw[0], yw[k], yw[k + 1]},
+                    i3[3] = {iw[0], iw[k], iw[k + 1]};
+        raster_tri(v, x3, y3, i3, tri, vis);
+    }
+}
+
+static void tri_vertices(const void *ind, int ind_i64, int64_t gw, int64_t t, int64_t idx[3]) {
+    if (ind) {
+        for (int k = 0; k < 3; ++k)
+            idx[k] = ind_i64 ? ((const int64_t *)ind)[t * 3 + k] : (int64_t)((const int32_t *)ind)[t * 3 + k];
+    } else {
+        /* implicit regular grid (surface.py:194-201): cell c -> (a, a+gw, a+gw+1), (a, a+gw+1, a+1) */
+        const int64_t cell = t / 2, r = cell / (gw - 1), c = cell % (gw - 1), a = r * gw + c;
+        if (t % 2 == 0) { idx[0] = a; idx[1] = a + gw; idx[2] = a + gw + 1; }
+        else { idx[0] = a; idx[1] = a + gw + 1; idx[2] = a + 1; }
+    }
+}
+
+/* visibility pass: vis[h*w] (GL window rows, row 0 = bottom), 0 = background */
+int alp_ref_visibility(const float *vert, int64_t n_vert, const void *ind, int ind_i64, int64_t n_tri,
+                       int64_t grid_h, int64_t grid_w, const double *params, const double *offsets,
+                       uint64_t *vis) {
+    view_t v;
+    setup_view(params, offsets, &v);
+    memset(vis, 0, sizeof(uint64_t) * (size_t)v.w * v.h);
+    (void)grid_h;
+    for (int64_t t = 0; t < n_tri; ++t) {
+        int64_t idx[3];
+        tri_vertices(ind, ind_i64, grid_w, t, idx);
+        if (idx[0] < 0 || idx[1] < 0 || idx[2] < 0 || idx[0] >= n_vert || idx[1] >= n_vert || idx[2] >= n_vert)
+            return -1;
+        draw_triangle(&v, vert + 3 * idx[0], vert + 3 * idx[1], vert + 3 * idx[2], (uint32_t)t, vis);
+    }
+    return 0;
+}
+
+/* value at window pixel (i, j): perspective-correct interpolation over the winning triangle */
+static void shade(const view_t *v, const float *vert, const float *value, const void *ind, int ind_i64,
+                  int64_t gw, uint64_t key, int i, int j, double min_distance, float out[3]) {
+    out[0] = out[1] = out[2] = 0.0f;
+    if (!key) return;
+    const int64_t t = (int64_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu));
+    int64_t idx[3];
+    tri_vertices(ind, ind_i64, gw, t, idx);
+    float qf[3][3];
+    double A[3], B[3], C[3];
+    for (int k = 0; k < 3; ++k) to_view(v, vert + 3 * idx[k], qf[k]);
+    for (int c = 0; c < 3; ++c) { A[c] = qf[0][c]; B[c] = qf[1][c]; C[c] = qf[2][c]; }
+    /* ray through the pixel centre: direction r = (xn/fx, yn/fy, 1), xn = (i+0.5)/sx - 1 */
+    const double r[3] = {(((double)i + 0.5) / v->sx - 1.0) / v->fxd, (((double)j + 0.5) / v->sy - 1.0) / v->fyd, 1.0};
+    /* solve A + beta (B-A) + gamma (C-A) = t r  (Cramer) */
+    const double e1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
+    const double pv[3] = {r[1] * e2[2] - r[2] * e2[1], r[2] * e2[0] - r[0] * e2[2], r[0] * e2[1] - r[1] * e2[0]};
+    const double det = e1[0] * pv[0] + e1[1] * pv[1] + e1[2] * pv[2];
+    const double tv[3] = {-A[0], -A[1], -A[2]};
+    const double beta = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) / det;
+    const double qv[3] = {tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0]};
+    const double gamma = (r[0] * qv[0] + r[1] * qv[1] + r[2] * qv[2]) / det;
+    const double alpha = 1.0 - beta - gamma;
+    if (min_distance > 0) {
+        const double dA = sqrt(A[0] * A[0] + A[1] * A[1] + A[2] * A[2]);
+        const double dB = sqrt(B[0] * B[0] + B[1] * B[1] + B[2] * B[2]);
+        const double dC = sqrt(C[0] * C[0] + C[1] * C[1] + C[2] * C[2]);
+        if (alpha * dA + beta * dB + gamma * dC < min_distance) return;      /* project.py:247-248 */
+    }
+    const float *va = (value ? value : vert) + 3 * idx[0], *vb = (value ? value : vert) + 3 * idx[1],
+                *vc = (value ? value : vert) + 3 * idx[2];
+    for (int c = 0; c < 3; ++c) out[c] = (float)(alpha * va[c] + beta * vb[c] + gamma * vc[c]);
+}
+
+/* source pixel of output pixel (x, y) (project.py:128-141 + optimize.py:104-118 with the
+ * inverted coefficients of :136-137); returns 0 when it falls outside the image */
+static int remap_source(int w, int h, const double *p, int x, int y, int *sx, int *sy) {
+    const double a1 = 1 / p[7], a2 = 1 / p[8];
+    const double k1 = -p[9], k2 = -p[10], k3 = -p[11], k4 = -p[12], k5 = -p[13], k6 = -p[14];
+    const double p1 = -p[15], p2 = -p[16], s1 = -p[17], s2 = -p[18], s3 = -p[19], s4 = -p[20];
+    const double c0 = (double)(float)((w - 1) / 2.0), c1 = (double)(float)((h - 1) / 2.0);
+    const double x1 = (x - c0) / c0, y1 = (y - c1) / c1;
+    const double r = sqrt(x1 * x1 + y1 * y1), r2 = r * r, r4 = r2 * r2, r6 = r4 * r2;
+    double xd = x1 * (1 + k1 * r2 + k2 * r4 + k3 * r6) / (1 + k4 * r2 + k5 * r4 + k6 * r6) + 2 * p1 * x1 * y1 +
+                p2 * (r2 * 2 * x1 * x1) + s1 * r2 + s2 * r4;
+    double yd = y1 * (1 + a1 + k1 * r2 + k2 * r4 + k3 * r6) / (1 + a2 + k4 * r2 + k5 * r4 + k6 * r6) +
+                2 * p1 * x1 * y1 + p2 * (r2 * 2 * y1 * y1) + s3 * r2 + s4 * r4;
+    const float mx = (float)(xd * c0 + c0), my = (float)(yd * c1 + c1);       /* astype('float32') */
+    const double rx = rint((double)mx), ry = rint((double)my);               /* cvRound: half to even */
+    if (!(rx >= 0 && rx < w && ry >= 0 && ry < h)) return 0;                   /* NaN fails too */
+    *sx = (int)rx;
+    *sy = (int)ry;
+    return 1;
+}
+
+/* full persp_proj: out = h x w x 3 float32, row 0 = top, lens distortion applied */
+int alp_ref_render(const float *vert, const float *value, int64_t n_vert, const void *ind, int ind_i64,
+                   int64_t n_tri, int64_t grid_h, int64_t grid_w, const double *params, const double *offsets,
+                   double min_distance, float *out) {
+    view_t v;
+    setup_view(params, offsets, &v);
+    uint64_t *vis = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)v.w * v.h);
+    if (!vis) return -2;
+    int rc = alp_ref_visibility(vert, n_vert, ind, ind_i64, n_tri, grid_h, grid_w, params, offsets, vis);
+    if (rc == 0) {
+        for (int y = 0; y < v.h; ++y)
+            for (int x = 0; x < v.w; ++x) {
+                float *o = out + ((size_t)y * v.w + x) * 3;
+                int sx, sy;
+                o[0] = o[1] = o[2] = 0.0f;
+                if (!remap_source(v.w, v.h, params, x, y, &sx, &sy)) continue;
+                const int j = v.h - 1 - sy;                       /* flipud: image row -> GL row */
+                shade(&v, vert, value, ind, ind_i64, grid_w, vis[(size_t)j * v.w + sx], sx, j, min_distance, o);
+            }
+    }
+    free(vis);
+    return rc;
+}
+
+/* distort() alone on an h x w x c float32 image */
+int alp_ref_distort_image(const float *img, int64_t h, int64_t w, int64_t c, const double *coeffs, float *out) {
+    double p[25] = {0};
+    for (int i = 0; i < 14; ++i) p[7 + i] = coeffs[i];
+    for (int64_t y = 0; y < h; ++y)
+        for (int64_t x = 0; x < w; ++x) {
+            int sx, sy;
+            float *o = out + ((size_t)y * w + x) * c;
+            if (!remap_source((int)w, (int)h, p, (int)x, (int)y, &sx, &sy)) { memset(o, 0, sizeof(float) * c); continue; }
+            memcpy(o, img + ((size_t)sy * w + sx) * c, sizeof(float) * c);
+        }
+    return 0;
+}
