@@ -202,7 +202,8 @@ __device__ __forceinline__ void vis_max(unsigned long long *vis, const View &v, 
 }
 
 // float64 homogeneous fallback for triangles beyond the fixed-point range
-__device__ void raster_big(const View &v, const float q[3][3], unsigned tri, unsigned long long *vis) {
+// (executed by a whole wave: lane l takes pixels l, l+64, ...)
+__device__ void raster_big(const View &v, const float q[3][3], unsigned tri, unsigned long long *vis, int lane) {
     double xh[3], yh[3], wh[3];
     for (int k = 0; k < 3; ++k) {
         wh[k] = q[k][2];
@@ -212,8 +213,10 @@ __device__ void raster_big(const View &v, const float q[3][3], unsigned tri, uns
     const double det = xh[0] * (yh[1] * wh[2] - yh[2] * wh[1]) - yh[0] * (xh[1] * wh[2] - xh[2] * wh[1]) +
                        wh[0] * (xh[1] * yh[2] - xh[2] * yh[1]);
     if (!(det > 0)) return;
-    for (int j = 0; j < v.h; ++j)
-        for (int i = 0; i < v.w; ++i) {
+    const long long npix = (long long)v.w * v.h;
+    for (long long p = lane; p < npix; p += 64) {
+        {
+            const int j = (int)(p / v.w), i = (int)(p - (long long)j * v.w);
             const double px = i + 0.5, py = j + 0.5;
             double e[3];
             bool inside = true;
@@ -228,6 +231,7 @@ __device__ void raster_big(const View &v, const float q[3][3], unsigned tri, uns
             if (!(qq <= 1.0f)) continue;
             vis_max(vis, v, i, j, ((unsigned long long)__float_as_uint(qq) << 32) | (unsigned long long)(0xFFFFFFFFu - tri));
         }
+    }
 }
 
 struct WorkItem { unsigned tri; unsigned short sub, tx, ty, pad; };   // sub: fan triangle 0/1
@@ -240,6 +244,18 @@ __device__ __forceinline__ int clip_project(const View &v, const float q[3][3], 
     const int nin = (int)in0 + (int)in1 + (int)in2;
     big = false;
     if (nin == 0) return 0;
+    {   // all three vertices beyond one side plane of the frustum: nothing can reach the viewport
+        bool r = true, l = true, t = true, b = true;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float cx = v.fx * q[k][0], cy = v.fy * q[k][1], cw = q[k][2];
+            r = r && cx > cw;
+            l = l && cx < -cw;
+            t = t && cy > cw;
+            b = b && cy < -cw;
+        }
+        if (r || l || t || b) return 0;
+    }
     int np = 0;
     if (nin == 3) {
 #pragma unroll
@@ -341,7 +357,7 @@ __global__ __launch_bounds__(256) void raster_large_kernel(const float *__restri
         float q[3][3];
         load_view_tri<IMPLICIT>(v, vert, ind, gw, (long long)wi.tri, q);
         if (wi.sub == 0xFFFF) {
-            if (lane == 0) raster_big(v, q, wi.tri, vis);
+            raster_big(v, q, wi.tri, vis, lane);
             continue;
         }
         float xw[4], yw[4], iw[4];

@@ -9,12 +9,14 @@ Workload (BASELINE.json metric: "Gpoints/s projected + CMA-ES iters/s, 100M-vert
 1/2/4/8 MI355X"): the 100 M-vertex synthetic DSM of SURVEY.md 8(d), resident in HBM as
 float32 planes, row-sharded over the ranks (strong scaling: the total is fixed).
 
-  leg 1 (the timed "steps", `value`): one step = one single-pose forward projection of the
+  leg 1 (the timed "steps" -> `value`): one step = one single-pose forward projection of the
         whole DSM (every rank projects its shard, no collective).  Gpoints/s = vertices / t.
-  leg 2 (`cma`): CMA-ES generations (ask -> population evaluation on the GPU(s) with one RCCL
-        all-reduce of the P+1 partial sums -> tell), pop = 2048, D = 21 (BASELINE config 5).
-  `cpu_baseline`: the numpy float64 restatement of the reference (oracle/ref_numpy.py) timed
-        on this host on a bounded sample (rank 0, N=1 only).
+  leg 2 (`cma`): CMA-ES generations = ask -> population evaluation on the GPU(s) with ONE RCCL
+        all-reduce of the P+1 partial sums -> tell; pop = 2048, D = 21 (BASELINE config 5).
+  leg 3 (`raster`, 1 GPU only -- the render does not shard: "replicas only"): depth-buffered
+        render of the same DSM as a triangle mesh onto the 5616x3744 frame (BASELINE config 4).
+  `cpu_baseline` (rank 0, N=1 only): the numpy float64 restatement of the reference
+        (oracle/ref_numpy.py) timed on this host on a bounded sample.
 
 Prints ONE JSON line on rank 0.
 """
@@ -31,8 +33,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 measured copy)
 VALU_PEAK = 157.3e12       # flop/s fp32 vector (MI355X_MICROARCH.md)
-BYTES_PER_VERTEX = {"f32": 20, "f64": 40}     # 3 coords in + 2 pixels out
-EVAL_FLOPS = 82            # flop per point-candidate evaluation (Huber), DESIGN.md kernel K2
+BYTES_PER_VERTEX = {"f32": 20, "f64": 40}     # 3 coordinates in + 2 pixel coordinates out
+EVAL_FLOPS = 82            # flop per point-candidate evaluation (Huber), DESIGN.md section 4 (K2)
 
 
 def parse():
@@ -46,6 +48,8 @@ def parse():
     ap.add_argument("--dims", type=int, default=21, choices=[9, 21])
     ap.add_argument("--cma-steps", type=int, default=None, help="generations timed (default min(steps, 10))")
     ap.add_argument("--no-cma", action="store_true")
+    ap.add_argument("--no-raster", action="store_true")
+    ap.add_argument("--raster-explicit", action="store_true", help="also time the int32 index-array mesh")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -86,19 +90,10 @@ class Control:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t[0])
 
-    def sum(self, x):
-        if not self.dist:
-            return x
-        t = self.torch.tensor([x], dtype=self.torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return float(t[0])
-
-    def bcast_bytes(self, b, n):
+    def bcast_bytes(self, b):
         if not self.dist:
             return b
-        t = self.torch.zeros(n, dtype=self.torch.uint8)
-        if self.rank == 0:
-            t = self.torch.tensor(list(b), dtype=self.torch.uint8)
+        t = self.torch.tensor(list(b), dtype=self.torch.uint8)
         self.dist.broadcast(t, src=0)
         return bytes(t.tolist())
 
@@ -110,7 +105,7 @@ class Control:
 
 def timed(ctl, L, fn, steps, warmup):
     """warmup, then EXACTLY `steps` calls bracketed by barrier + device sync on both sides.
-    Returns (wall seconds as max over ranks, device ms between HIP events on the lib stream)."""
+    Returns (wall seconds, max over ranks; device ms between HIP events on the library stream)."""
     for _ in range(warmup):
         fn()
     ctl.device_sync(L)
@@ -127,10 +122,9 @@ def timed(ctl, L, fn, steps, warmup):
     return ctl.max(t1 - t0), dev_ms
 
 
-def cpu_baseline(n_sample, truth, base, xyz_l_sample, obs_sample):
+def cpu_baseline(orc, truth, xyz_sample, obs_sample):
     """numpy float64 port of the reference path on the host cores (oracle = checker only)."""
-    from oracle import ref_numpy as orc
-    xyz = xyz_l_sample.astype(np.float64)
+    xyz = xyz_sample.astype(np.float64)
     best_p, best_l = 1e30, 1e30
     for i in range(3):
         t = time.perf_counter()
@@ -141,7 +135,7 @@ def cpu_baseline(n_sample, truth, base, xyz_l_sample, obs_sample):
         if i:
             best_p = min(best_p, t1 - t)
             best_l = min(best_l, t2 - t)
-    return dict(project_s=best_p, eval_s=best_l, n=n_sample)
+    return best_p, best_l
 
 
 def main():
@@ -154,25 +148,20 @@ def main():
         sys.exit(2)
 
     from alproj_amd import _lib as L
+    from alproj_amd import dist as adist
     from alproj_amd import synthetic as syn
     from alproj_amd.cma import CMA
     from oracle import ref_numpy as orc       # checker / cpu_baseline only
 
-    L.init(ctl.local_rank)
-    if ctl.world > 1:
-        uid = L.comm_unique_id() if ctl.rank == 0 else b"\0" * L.UNIQUE_ID_BYTES
-        uid = ctl.bcast_bytes(uid, L.UNIQUE_ID_BYTES)
-        L.comm_init(uid, ctl.rank, ctl.world)
+    adist.init_comm(ctl.rank, ctl.world, ctl.bcast_bytes, ctl.local_rank)
     info = L.device_info()
 
     # ---------------------------------------------------------------- workload
     n_side = syn.grid_side(args.vertices)
-    r0 = n_side * ctl.rank // ctl.world
-    r1 = n_side * (ctl.rank + 1) // ctl.world
+    r0, r1 = adist.shard_rows(n_side, ctl.rank, ctl.world)
     t_gen = time.perf_counter()
     surf = syn.surface(n_side, rows=(r0, r1))
     xyz_l = syn.vert_to_xyz_local(surf["vert"])
-    del surf["vert"]
     n_local = xyz_l.shape[0]
     n_total = n_side * n_side
     base = syn.local_params(syn.standoff_params(n_side), surf["offsets"])
@@ -196,12 +185,8 @@ def main():
     u, v = pts.fetch_strided(0, step, cnt)
     sample = xyz_l[0:cnt * step:step].astype(np.float64)
     ref = orc.project_points(sample, truth)
-    E = orc.extrinsic_mat(truth["pan"], truth["tilt"], truth["roll"], truth["x"], truth["y"], truth["z"])
-    cam = (E[:3, :3] @ sample.T).T + E[:3, 3]
-    ok = np.abs(cam[:, 2]) > 0.02 * np.linalg.norm(cam, axis=1)
-    err = np.abs(np.stack([u, v], 1) - ref)[ok]
-    rel = err / np.maximum(np.abs(ref[ok]), truth["w"])
-    parity_max_rel = float(rel.max()) if rel.size else 0.0
+    rel = np.abs(np.stack([u, v], 1) - ref) / np.maximum(np.abs(ref), truth["w"])
+    parity_max_rel = float(rel.max())
 
     out = {
         "metric": "Gpoints/s projected (pinhole + Brown-Conrady, single pose) over the 100M-vertex DSM; "
@@ -217,7 +202,7 @@ def main():
                      "frac": achieved / HBM_PEAK, "traffic": None,
                      "kernel": "project_kernel", "kernel_ms": kern_s * 1e3,
                      "bytes_per_vertex": bpv, "vertices_per_launch": n_local},
-        "parity": {"checked_vertices": int(ok.sum()), "max_rel_err_vs_f64_oracle": parity_max_rel,
+        "parity": {"checked_vertices": int(cnt), "max_err_rel_to_max(|ref|,w)_vs_f64_oracle": parity_max_rel,
                    "tolerance": 1e-5},
         "device": info, "setup_s": t_gen,
     }
@@ -252,7 +237,7 @@ def main():
 
         k_cma = args.cma_steps or min(args.steps, 10)
         wall_c, _ = timed(ctl, L, generation, k_cma, min(args.warmup, 2))
-        # kernel-only time of one population evaluation (HIP events around enqueue)
+        # device time of one population evaluation (HIP events around the enqueue)
         cand = np.tile(basev, (args.pop, 1))
         cand[:, cols] = opt.ask_population() * (upper - lower) + lower
         L.event_record(2)
@@ -267,25 +252,56 @@ def main():
             "point_candidate_evals_per_s": n_total * args.pop * k_cma / wall_c,
             "best_loss_last_generation": state.get("best"),
             "collective": "ncclAllReduce(sum, f64, P+1) per generation" if ctl.world > 1 else "none (1 GPU)",
-            "roofline": {"bound": "valu_fp32", "kernel": "popeval_kernel", "kernel_ms": eval_ms,
+            "roofline": {"bound": "valu_fp32", "kernel": "popeval_kernel (+ reduce, all-reduce, D2H)",
+                         "kernel_ms": eval_ms,
                          "achieved": evals * EVAL_FLOPS / (eval_ms / 1e3) / 1e12, "peak": VALU_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": evals * EVAL_FLOPS / (eval_ms / 1e3) / VALU_PEAK,
                          "flop_per_eval": EVAL_FLOPS,
-                         "hbm_frac": n_local * 20 * max(1, args.pop // 256) / (eval_ms / 1e3) / HBM_PEAK},
+                         "hbm_frac": n_local * 20 * ((args.pop + 127) // 128) / (eval_ms / 1e3) / HBM_PEAK},
         }
+
+    # ---------------------------------------------------------------- leg 3: depth raster (1 GPU)
+    if ctl.world == 1 and not args.no_raster:
+        cam = syn.base_params(n_side)              # camera on the surface's west edge
+        pv_cam = L.params_vector(cam)
+        k_r = min(args.steps, 10)
+        variants = [("implicit_grid", None)]
+        if args.raster_explicit:
+            variants.append(("int32_indices", syn.grid_indices(n_side, np.int32)))
+        n_tri = 2 * (n_side - 1) ** 2
+        W, H = int(cam["w"]), int(cam["h"])
+        out["raster"] = {"frame": f"{W}x{H}", "vertices": n_total, "triangles": n_tri,
+                         "call": "persp_proj(vert, vert, ind, params, offsets) as used by reverse_proj"}
+        for name, ind in variants:
+            mesh = L.Mesh(surf["vert"], None, ind, grid=None if ind is not None else (n_side, n_side))
+            wall_r, dev_r = timed(ctl, L, lambda: mesh.render_enqueue(pv_cam, surf["offsets"]), k_r, 2)
+            img = mesh.fetch()
+            # algorithmic bytes per frame: vertices 12 B (value == vert), indices 12 B per
+            # triangle when explicit, visibility 8 B written + 8 B read per pixel, 12 B per pixel out
+            alg = n_total * 12 + (n_tri * 12 if ind is not None else 0) + W * H * (16 + 12)
+            out["raster"][name] = {
+                "ms_per_frame": wall_r / k_r * 1e3, "device_ms_per_frame": dev_r / k_r,
+                "gvertices_per_s": n_total / (wall_r / k_r) / 1e9, "frames_timed": k_r,
+                "covered_fraction": float((img[:, :, 0] > 0).mean()),
+                "roofline": {"bound": "hbm", "achieved": alg / (dev_r / k_r / 1e3) / 1e9, "peak": HBM_PEAK / 1e9,
+                             "unit": "GB/s", "frac": alg / (dev_r / k_r / 1e3) / HBM_PEAK,
+                             "algorithmic_bytes_per_frame": alg},
+            }
+            mesh.close()
+            del img
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1)
     if ctl.world == 1 and not args.no_cpu_baseline:
         ns = min(n_local, 2_000_000)
         sl = slice(0, ns * (n_local // ns), n_local // ns)
-        obs_s = (obs[sl][:ns].astype(np.float64) if obs is not None
-                 else np.zeros((ns, 2)))
-        cb = cpu_baseline(ns, truth, base, xyz_l[sl][:ns], obs_s)
+        obs_s = obs[sl][:ns].astype(np.float64) if obs is not None else np.zeros((ns, 2))
+        t_proj, t_eval = cpu_baseline(orc, truth, xyz_l[sl][:ns], obs_s)
         out["cpu_baseline"] = {
-            "value": ns / cb["project_s"] / 1e9, "unit": "Gpoints/s", "cores": 1, "kind": "port",
-            "sample": f"numpy float64 restatement (oracle/ref_numpy.project_points) on a {ns}-vertex strided "
-                      f"sample of the same DSM, best of 2 after warm-up; os.cpu_count()={os.cpu_count()}",
-            "cma_iters_per_s_extrapolated": 1.0 / (cb["eval_s"] * (n_total / ns) * args.pop),
+            "value": ns / t_proj / 1e9, "unit": "Gpoints/s", "cores": 1, "kind": "port",
+            "sample": f"numpy float64 restatement of the reference (oracle/ref_numpy.project_points) on a {ns}-vertex "
+                      f"strided sample of the same DSM, best of 2 after warm-up (elementwise numpy is single-"
+                      f"threaded); os.cpu_count()={os.cpu_count()}",
+            "cma_iters_per_s_extrapolated": 1.0 / (t_eval * (n_total / ns) * args.pop),
         }
         out["speedup_vs_cpu_baseline"] = gpts / out["cpu_baseline"]["value"]
 

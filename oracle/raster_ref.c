@@ -190,6 +190,20 @@ static void raster_big(const view_t *v, const float q[3][3], uint32_t tri, uint6
         }
 }
 
+/* all three vertices beyond the same side plane of the view frustum (x_clip > w_clip, ...):
+ * the half-space is convex, so no part of the triangle can reach the viewport */
+static int outside_frustum(const view_t *v, const float q[3][3]) {
+    int r = 1, l = 1, t = 1, b = 1;
+    for (int k = 0; k < 3; ++k) {
+        const float cx = v->fx * q[k][0], cy = v->fy * q[k][1], cw = q[k][2];
+        r &= cx > cw;
+        l &= cx < -cw;
+        t &= cy > cw;
+        b &= cy < -cw;
+    }
+    return r | l | t | b;
+}
+
 static void draw_triangle(const view_t *v, const float *pa, const float *pb, const float *pc, uint32_t tri,
                           uint64_t *vis) {
     float q[3][3];
@@ -199,6 +213,7 @@ static void draw_triangle(const view_t *v, const float *pa, const float *pb, con
     const int in0 = q[0][2] >= 1.0f, in1 = q[1][2] >= 1.0f, in2 = q[2][2] >= 1.0f;
     const int nin = in0 + in1 + in2;
     if (nin == 0) return;
+    if (outside_frustum(v, (const float(*)[3])q)) return;
     float xw[4], yw[4], iw[4];
     if (nin == 3) {
         int big = 0;

@@ -1,0 +1,76 @@
+"""world_size-2 (and 3) test of the vertex-sharded population evaluation on CPU (gloo): shard
+bounds, the P+1 all-reduce contract, NaN poisoning and the replicated argmin."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from alproj_amd import dist as adist
+from alproj_amd import synthetic as syn
+from oracle import ref_numpy as orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_population_matches_single_process(tmp_path, world):
+    port = _free_port()
+    outs = [str(tmp_path / f"r{r}.npz") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), str(r), str(world), port, outs[r]],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, out.decode()[-2000:]
+    res = [np.load(o) for o in outs]
+    # single-process reference over all points
+    truth = syn.truth_params(316)
+    init = syn.base_params(316)
+    n = 3001
+    xyz = syn.gcp_points(n, truth, seed=5)
+    uv = orc.project_points(xyz, truth) + np.random.default_rng(5).normal(0, 1.0, (n, 2))
+    xyz[17] = [init["x"], init["y"], init["z"]]
+    bounds = orc.bounds_to_array(init, syn.TARGETS_D9)
+    X = np.random.default_rng(9).uniform(0.4, 0.6, (12, 9))
+    X[0] = 0.5
+    with np.errstate(all="ignore"):
+        ref, ref_amin = orc.population_losses(xyz, uv, init, syn.TARGETS_D9, bounds, X, 10.0)
+    assert np.isnan(ref[0])                             # poisoned by the at-camera point
+    covered = sorted((int(r["lo"]), int(r["hi"])) for r in res)
+    assert covered[0][0] == 0 and covered[-1][1] == n
+    assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    for r in res:
+        np.testing.assert_allclose(r["losses"], ref, rtol=1e-12, equal_nan=True)
+        assert int(r["amin"]) == ref_amin != 0
+        np.testing.assert_array_equal(r["losses"], res[0]["losses"])      # identical on every rank
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 100_000_000, 10_004_569):
+        for world in (1, 2, 3, 8):
+            b = [adist.shard_bounds(n, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(x[1] == y[0] for x, y in zip(b, b[1:]))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        adist.shard_bounds(10, 2, 2)
+
+
+def test_combine_partials_semantics():
+    red = adist.pack_partials(np.array([30.0, 10.0, np.nan, 10.0]), 10)
+    losses, amin = adist.combine_partials(red)
+    np.testing.assert_array_equal(losses[[0, 1, 3]], [3.0, 1.0, 1.0])
+    assert np.isnan(losses[2]) and amin == 1            # first index on ties, NaN never wins
+    losses, amin = adist.combine_partials(adist.pack_partials(np.array([np.nan, np.nan]), 5))
+    assert amin == 0
+    losses, _ = adist.combine_partials(adist.pack_partials(np.array([0.0]), 0))
+    assert np.isnan(losses[0])                          # np.mean of an empty set

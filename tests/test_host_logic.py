@@ -1,0 +1,154 @@
+"""CPU tests of the host-side mirror of the reference interface: the CMA-ES sampler contract,
+bounds / candidate-matrix construction, the small matrix helpers (against the golden vectors
+generated from the reference) and argument validation.  No GPU work."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from alproj_amd import optimize as opt
+from alproj_amd import project as prj
+from alproj_amd.cma import CMA
+from oracle import ref_numpy as orc
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+# ------------------------------------------------------------------ matrices and bounds
+def test_intrinsic_extrinsic_golden():
+    g = load("g1_matrices.npz")
+    for pv, K, E in zip(g["params"], g["K"], g["E"]):
+        p = orc.vector_to_params(pv)
+        np.testing.assert_allclose(opt.intrinsic_mat(p["fov"], p["w"], p["h"], p["cx"], p["cy"]), K, rtol=1e-15)
+        np.testing.assert_allclose(opt.extrinsic_mat(p["pan"], p["tilt"], p["roll"], p["x"], p["y"], p["z"]),
+                                   E, rtol=1e-13, atol=1e-9)
+    np.testing.assert_allclose(opt.intrinsic_mat(75, 5616, 3744), g["K_default_75_5616_3744"], rtol=1e-15)
+
+
+def test_gl_matrices_golden():
+    g = load("g7_gl_matrices.npz")
+    off = g["cam_offset"]
+    for pv, pm, mv in zip(g["params"], g["proj"], g["view"]):
+        p = orc.vector_to_params(pv)
+        np.testing.assert_array_equal(prj.projection_mat(p["fov"], p["w"], p["h"]), pm)
+        np.testing.assert_allclose(prj.modelview_mat(p["pan"], p["tilt"], p["roll"], p["x"] - off[0],
+                                                     p["y"] - off[1], p["z"] - off[2]), mv, rtol=1e-13, atol=1e-9)
+    np.testing.assert_array_equal(prj.projection_mat(75, 5616, 3744, near=0.5, far=5000.0, cx=2800.0, cy=1880.0),
+                                  g["proj_cxcy_near_far"])
+    # quirk Q10: defaults near=-1, far=1 give rows 3/4 = [0,0,0,1], [0,0,-1,0]
+    pm = prj.projection_mat(75, 5616, 3744)
+    np.testing.assert_allclose(pm[8:], [0, 0, 0, 1, 0, 0, -1, 0], atol=1e-15)
+    assert abs(pm[0] - 1.303225) < 1e-6 and abs(pm[5] - 2.144507) < 1e-6
+
+
+def test_bounds_to_array_golden():
+    g = load("g6_bounds.npz")
+    p = orc.vector_to_params(g["params"])
+    tgt = [str(t) for t in g["targets"]]
+    np.testing.assert_array_equal(opt.bounds_to_array(p, tgt), g["default"])
+    np.testing.assert_array_equal(opt.bounds_to_array(p, tgt, {"fov": 10, "cx": 7.5}), g["override"])
+    np.testing.assert_array_equal(opt.bounds_to_array(p, [str(t) for t in g["all21_targets"]]), g["all21"])
+    assert opt.DEFAULT_BOUND_WIDTHS == orc.DEFAULT_BOUND_WIDTHS
+
+
+def test_set_target_and_candidate_matrix():
+    g = load("g5_population.npz")
+    init = orc.vector_to_params(g["params_init"])
+    o = opt.CMAOptimizer(pd.DataFrame(g["xyz"], columns=["x", "y", "z"]),
+                         pd.DataFrame(g["uv_obs"], columns=["u", "v"]), init)
+    o.set_target()
+    assert o.target_params == ["fov", "pan", "tilt", "roll", "a1", "a2", "k1", "k2", "k3", "k4", "k5", "k6",
+                               "p1", "p2", "s1", "s2", "s3", "s4"]                     # x, y, z excluded
+    tgt = [str(t) for t in g["d9_targets"]]
+    o.set_target(tgt)
+    np.testing.assert_array_equal(o.target_params_init, [init[t] for t in tgt])
+    bounds = g["d9_bounds"]
+    X = g["d9_X"]
+    cand = o._candidate_matrix(X * (bounds[:, 1] - bounds[:, 0]) + bounds[:, 0])
+    assert cand.shape == (len(X), 25)
+    for i in (0, 5, 23):                     # row i == the dict the reference's closure builds
+        ref = orc.candidate_params(init, tgt, bounds, X[i])
+        np.testing.assert_array_equal(cand[i], orc.params_to_vector(ref))
+    res = o._result_params(cand[3][[orc.PARAM_KEYS.index(t) for t in tgt]])
+    assert set(res) == set(init) and res["w"] == init["w"]
+
+
+def test_lsq_argument_errors_need_no_gpu():
+    o = opt.LsqOptimizer(pd.DataFrame(np.zeros((3, 3)), columns=["x", "y", "z"]),
+                         pd.DataFrame(np.zeros((3, 2)), columns=["u", "v"]), {k: 1.0 for k in orc.PARAM_KEYS})
+    o.set_target(["pan"])
+    with pytest.raises(ValueError, match="does not support bounds"):
+        o.optimize(method="lm", bound_widths={"pan": 1})
+    with pytest.raises(ValueError, match="robust loss"):
+        o.optimize(method="lm", loss="huber")
+
+
+def test_reverse_proj_channel_check_needs_no_gpu():
+    with pytest.raises(ValueError, match="channels"):
+        prj.reverse_proj(np.zeros((4, 4, 3)), None, None, {}, chnames=["a"])
+
+
+# ------------------------------------------------------------------ CMA-ES sampler contract
+def test_cma_defaults_and_ask():
+    c = CMA(mean=np.full(9, 0.5), sigma=0.2, seed=1)
+    assert c.population_size == 4 + int(3 * np.log(9)) and c.dim == 9 and c.generation == 0
+    b = np.column_stack([np.zeros(9), np.ones(9)])
+    c = CMA(mean=np.full(9, 0.5), sigma=1.0, bounds=b, population_size=50, n_max_resampling=100, seed=2)
+    xs = np.array([c.ask() for _ in range(200)])
+    assert xs.shape == (200, 9) and (xs >= 0).all() and (xs <= 1).all()
+    X = c.ask_population()
+    assert X.shape == (50, 9) and (X >= 0).all() and (X <= 1).all()
+    # resample-then-clip: with a huge sigma and a single resampling nearly everything is clipped
+    c2 = CMA(mean=np.full(4, 0.5), sigma=50.0, bounds=np.column_stack([np.zeros(4), np.ones(4)]),
+             population_size=64, n_max_resampling=1, seed=3)
+    Y = c2.ask_population()
+    assert (Y >= 0).all() and (Y <= 1).all() and ((Y == 0) | (Y == 1)).mean() > 0.8
+
+
+def test_cma_tell_sorts_in_place_stably():
+    c = CMA(mean=np.zeros(3), sigma=1.0, population_size=6, seed=4)
+    X = c.ask_population()
+    vals = [5.0, 1.0, 3.0, 1.0, float("nan"), 2.0]
+    sol = [(X[i], vals[i]) for i in range(6)]
+    c.tell(sol)
+    assert [s[1] for s in sol[:5]] == [1.0, 1.0, 2.0, 3.0, 5.0] and np.isnan(sol[5][1])
+    assert sol[0][0] is X[1] or np.array_equal(sol[0][0], X[1])       # first of the tie (Q9)
+    assert c.generation == 1
+    with pytest.raises(ValueError):
+        c.tell(sol[:3])
+
+
+def test_cma_reproducible_and_converges():
+    def run(seed, f, d, gens, pop):
+        c = CMA(mean=np.full(d, 0.8), sigma=0.3, bounds=np.column_stack([np.full(d, -2.0), np.full(d, 2.0)]),
+                population_size=pop, seed=seed)
+        best = np.inf
+        for _ in range(gens):
+            X = c.ask_population()
+            v = [f(x) for x in X]
+            best = min(best, min(v))
+            c.tell([(X[i], v[i]) for i in range(pop)])
+        return best, c.mean.copy()
+
+    sphere = lambda x: float(np.sum((x - 0.3) ** 2))
+    b1, m1 = run(7, sphere, 9, 120, 16)
+    b2, m2 = run(7, sphere, 9, 120, 16)
+    assert b1 == b2 and np.array_equal(m1, m2)                      # same seed -> same trajectory
+    assert b1 < 1e-10 and np.allclose(m1, 0.3, atol=1e-4)
+    rosen = lambda x: float(np.sum(100 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2))
+    b3, m3 = run(11, rosen, 5, 400, 24)
+    assert b3 < 1e-8 and np.allclose(m3, 1.0, atol=1e-3)
+
+
+def test_cma_argument_checks():
+    with pytest.raises(ValueError):
+        CMA(mean=np.zeros(3), sigma=0.0)
+    with pytest.raises(ValueError):
+        CMA(mean=np.zeros(3), sigma=1.0, bounds=np.zeros((2, 2)))
+    with pytest.raises(ValueError):
+        CMA(mean=np.zeros(3), sigma=1.0, population_size=0)
