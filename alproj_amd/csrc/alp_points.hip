@@ -102,7 +102,8 @@ int launch_project(alp_points *p, const double params[ALP_NPARAM]) {
     PoseRec<T> pose;
     fold_pose_t<T>(params, p->origin, &pose);
     const int64_t nvec = (p->n + Num<T>::VEC - 1) / Num<T>::VEC;
-    hipLaunchKernelGGL((project_kernel<T>), dim3(stream_grid(nvec)), dim3(256), 0, ctx().stream,
+    const unsigned grid = (unsigned)((nvec + 255) / 256);        // one 16-byte vector per lane
+    hipLaunchKernelGGL((project_kernel<T>), dim3(grid), dim3(256), 0, ctx().stream,
                        (const T *)p->x, (const T *)p->y, (const T *)p->z, (T *)p->u, (T *)p->v, nvec, pose);
     ALP_HIP(hipGetLastError());
     return ALP_OK;

@@ -188,6 +188,13 @@ def main():
     rel = np.abs(np.stack([u, v], 1) - ref) / np.maximum(np.abs(ref), truth["w"])
     parity_max_rel = float(rel.max())
 
+    # HBM traffic of the kernel: PMC passes (FETCH_SIZE / WRITE_SIZE, gfx950-corrected) cannot run
+    # inside this process; the committed rocprofv3 measurement gives bytes per vertex
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "r01_project_pmc_traffic.json")
+    if args.precision == "f32" and os.path.exists(tfile):
+        traffic = json.load(open(tfile))["hbm_bytes_per_vertex"] * n_local
+
     out = {
         "metric": "Gpoints/s projected (pinhole + Brown-Conrady, single pose) over the 100M-vertex DSM; "
                   "CMA-ES iterations/s in `cma`",
@@ -199,7 +206,9 @@ def main():
                    "vertices": n_total, "vertices_per_gpu": n_local, "sharding": f"rows/{ctl.world}",
                    "precision": args.precision},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK, "traffic": None,
+                     "frac": achieved / HBM_PEAK, "traffic": traffic,
+                     "traffic_source": "profiles/r01_project_pmc_traffic.json (rocprofv3 --pmc, bytes/vertex x "
+                                       "vertices per launch)" if traffic else None,
                      "kernel": "project_kernel", "kernel_ms": kern_s * 1e3,
                      "bytes_per_vertex": bpv, "vertices_per_launch": n_local},
         "parity": {"checked_vertices": int(cnt), "max_err_rel_to_max(|ref|,w)_vs_f64_oracle": parity_max_rel,

@@ -1,0 +1,169 @@
+// Development lab for the single-pose projection kernel (HBM-bound): variants of the
+// streaming structure on 100 M vertices.
+#include "alp_point_kernels.h"
+#include <vector>
+namespace alp { void set_error(const char *, ...) {} int fail(int c, const char *, ...) { return c; } }
+using namespace alp;
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load(const float4 *p) { f4v t = __builtin_nontemporal_load((const f4v *)p); return make_float4(t.x, t.y, t.z, t.w); }
+__device__ __forceinline__ void nt_store(float4 a, float4 *p) { f4v t = {a.x, a.y, a.z, a.w}; __builtin_nontemporal_store(t, (f4v *)p); }
+
+// variant B: 2x unrolled grid-stride (6 loads in flight), optional nontemporal accesses
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void project_v(const float *__restrict__ x, const float *__restrict__ y,
+                                                 const float *__restrict__ z, float *__restrict__ u,
+                                                 float *__restrict__ v, int64_t nvec, PoseRec<float> pose) {
+    const float4 *x4 = (const float4 *)x, *y4 = (const float4 *)y, *z4 = (const float4 *)z;
+    float4 *u4 = (float4 *)u, *v4 = (float4 *)v;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < nvec; i += UNROLL * stride) {
+        float4 qx[UNROLL], qy[UNROLL], qz[UNROLL];
+#pragma unroll
+        for (int r = 0; r < UNROLL; ++r) {
+            if (NT) {
+                qx[r] = nt_load(&x4[i + r * stride]);
+                qy[r] = nt_load(&y4[i + r * stride]);
+                qz[r] = nt_load(&z4[i + r * stride]);
+            } else {
+                qx[r] = x4[i + r * stride]; qy[r] = y4[i + r * stride]; qz[r] = z4[i + r * stride];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < UNROLL; ++r) {
+            float4 ou, ov;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float xd, yd;
+                project_norm<float>(pose.v, vget<float>(qx[r], k), vget<float>(qy[r], k), vget<float>(qz[r], k), xd, yd);
+                to_pixels<float>(pose.v, xd, yd, vget<float>(ou, k), vget<float>(ov, k));
+            }
+            if (NT) {
+                nt_store(ou, &u4[i + r * stride]);
+                nt_store(ov, &v4[i + r * stride]);
+            } else {
+                u4[i + r * stride] = ou; v4[i + r * stride] = ov;
+            }
+        }
+    }
+    for (; i < nvec; i += stride) {
+        float4 qx = x4[i], qy = y4[i], qz = z4[i], ou, ov;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float xd, yd;
+            project_norm<float>(pose.v, vget<float>(qx, k), vget<float>(qy, k), vget<float>(qz, k), xd, yd);
+            to_pixels<float>(pose.v, xd, yd, vget<float>(ou, k), vget<float>(ov, k));
+        }
+        u4[i] = ou; v4[i] = ov;
+    }
+}
+
+// pure streaming copy with the same traffic shape (3 planes in, 2 out): the ceiling
+__global__ __launch_bounds__(256) void copy32(const float *__restrict__ x, const float *__restrict__ y,
+                                              const float *__restrict__ z, float *__restrict__ u,
+                                              float *__restrict__ v, int64_t nvec) {
+    const float4 *x4 = (const float4 *)x, *y4 = (const float4 *)y, *z4 = (const float4 *)z;
+    float4 *u4 = (float4 *)u, *v4 = (float4 *)v;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        float4 a = x4[i], b = y4[i], c = z4[i];
+        u4[i] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+        v4[i] = make_float4(b.x + c.x, b.y + c.y, b.z + c.z, b.w + c.w);
+    }
+}
+
+// variant C: no grid-stride; each thread takes VPT float4 chunks spaced one block apart
+template <int VPT, bool NTL, bool NTS, int BS>
+__global__ __launch_bounds__(BS) void project_c(const float *__restrict__ x, const float *__restrict__ y,
+                                                const float *__restrict__ z, float *__restrict__ u,
+                                                float *__restrict__ v, int64_t nvec, PoseRec<float> pose) {
+    const float4 *x4 = (const float4 *)x, *y4 = (const float4 *)y, *z4 = (const float4 *)z;
+    float4 *u4 = (float4 *)u, *v4 = (float4 *)v;
+    const int64_t base = (int64_t)blockIdx.x * (BS * VPT) + threadIdx.x;
+    float4 qx[VPT], qy[VPT], qz[VPT];
+#pragma unroll
+    for (int r = 0; r < VPT; ++r) {
+        const int64_t i = base + r * BS;
+        if (i < nvec) {
+            qx[r] = NTL ? nt_load(&x4[i]) : x4[i];
+            qy[r] = NTL ? nt_load(&y4[i]) : y4[i];
+            qz[r] = NTL ? nt_load(&z4[i]) : z4[i];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < VPT; ++r) {
+        const int64_t i = base + r * BS;
+        if (i < nvec) {
+            float4 ou, ov;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float xd, yd;
+                project_norm<float>(pose.v, vget<float>(qx[r], k), vget<float>(qy[r], k), vget<float>(qz[r], k), xd, yd);
+                to_pixels<float>(pose.v, xd, yd, vget<float>(ou, k), vget<float>(ov, k));
+            }
+            if (NTS) { nt_store(ou, &u4[i]); nt_store(ov, &v4[i]); } else { u4[i] = ou; v4[i] = ov; }
+        }
+    }
+}
+
+template <typename F>
+float timeit(F launch) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9;
+    for (int rep = 0; rep < 6; ++rep) {
+        hipEventRecord(e0);
+        launch();
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+    }
+    return best;
+}
+
+int main(int argc, char **argv) {
+    const int64_t n = argc > 1 ? atoll(argv[1]) : 100000000;
+    const int64_t npad = round_up(n, 1024), nvec = (n + 3) / 4;
+    float *x, *y, *z, *u, *v;
+    hipMalloc(&x, npad * 4); hipMalloc(&y, npad * 4); hipMalloc(&z, npad * 4);
+    hipMalloc(&u, npad * 4); hipMalloc(&v, npad * 4);
+    std::vector<float> h(npad);
+    for (int64_t i = 0; i < npad; ++i) h[i] = 1000.f + (float)(i % 9973);
+    hipMemcpy(x, h.data(), npad * 4, hipMemcpyHostToDevice);
+    for (int64_t i = 0; i < npad; ++i) h[i] = (float)((i * 7) % 1999) - 1000.f;
+    hipMemcpy(y, h.data(), npad * 4, hipMemcpyHostToDevice);
+    hipMemcpy(z, h.data(), npad * 4, hipMemcpyHostToDevice);
+    PoseRec<float> pose;
+    for (int i = 0; i < POSE_WORDS; ++i) pose.v[i] = 0;
+    pose.v[1] = -1.3e-3f; pose.v[3] = 0.1f; pose.v[6] = -2.1e-3f; pose.v[8] = 1e-3f; pose.v[11] = 0.2f;
+    for (int i = 12; i < 18; ++i) pose.v[i] = 0.01f;
+    pose.v[18] = pose.v[19] = 2.f; for (int i = 20; i < 26; ++i) pose.v[i] = 0.001f;
+    pose.v[26] = 2807.5f; pose.v[27] = 1871.5f;
+    const double gb = (double)n * 20 / 1e9;
+    auto report = [&](const char *name, int grid, float ms) {
+        printf("%-34s grid=%6d  %.4f ms  %.0f GB/s  %.1f Gpts/s\n", name, grid, ms, gb / ms * 1e3, n / ms / 1e6);
+    };
+    for (int grid : {2048, 16384}) {
+        report("copy-shaped stream", grid, timeit([&] { copy32<<<grid, 256>>>(x, y, z, u, v, nvec); }));
+        report("current (project_kernel)", grid, timeit([&] { project_kernel<float><<<grid, 256>>>(x, y, z, u, v, nvec, pose); }));
+        report("unroll1 nt", grid, timeit([&] { project_v<1, true><<<grid, 256>>>(x, y, z, u, v, nvec, pose); }));
+        report("unroll2", grid, timeit([&] { project_v<2, false><<<grid, 256>>>(x, y, z, u, v, nvec, pose); }));
+        report("unroll2 nt", grid, timeit([&] { project_v<2, true><<<grid, 256>>>(x, y, z, u, v, nvec, pose); }));
+        report("unroll4 nt", grid, timeit([&] { project_v<4, true><<<grid, 256>>>(x, y, z, u, v, nvec, pose); }));
+    }
+#define RUNC(VPT, NTL, NTS, BS) { const int g = (int)((nvec + (BS) * (VPT) - 1) / ((BS) * (VPT))); \
+        report("C vpt=" #VPT " ntl=" #NTL " nts=" #NTS " bs=" #BS, g, timeit([&] { project_c<VPT, NTL, NTS, BS><<<g, BS>>>(x, y, z, u, v, nvec, pose); })); }
+    for (int pass = 0; pass < 2; ++pass) {
+        RUNC(1, false, false, 256); RUNC(1, false, true, 256); RUNC(1, true, true, 256); RUNC(1, true, false, 256);
+        RUNC(2, false, false, 256); RUNC(2, false, true, 256); RUNC(2, true, true, 256);
+        RUNC(4, false, true, 256); RUNC(4, true, true, 256);
+        RUNC(1, false, false, 512); RUNC(1, false, true, 512); RUNC(2, false, true, 512);
+        RUNC(1, false, false, 1024); RUNC(1, false, true, 1024);
+        RUNC(1, false, false, 128); RUNC(1, false, false, 64); RUNC(2, false, false, 64);
+    }
+    const int full = (int)((nvec + 255) / 256);
+    report("current, one vec per thread", full, timeit([&] { project_kernel<float><<<full, 256>>>(x, y, z, u, v, nvec, pose); }));
+    report("copy, one vec per thread", full, timeit([&] { copy32<<<full, 256>>>(x, y, z, u, v, nvec); }));
+    return 0;
+}
