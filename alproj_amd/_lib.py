@@ -10,7 +10,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libalproj_hip.so")
+LIB_PATH = os.environ.get("ALPROJ_HIP_LIB", os.path.join(_HERE, "libalproj_hip.so"))   # override: dev ablation builds
 
 ALP_F32, ALP_F64, ALP_I32, ALP_I64 = 0, 1, 2, 3
 LOSS_MEAN_DIST, LOSS_HUBER = 0, 1
