@@ -100,7 +100,9 @@ class CMA:
         self._bounds = bounds
         self._n_max_resampling = int(n_max_resampling)
         self._g = 0
-        self._rng = np.random.RandomState(seed)
+        # PCG64 + ziggurat normals: ~4x the throughput of RandomState.randn; the reference's
+        # stream is unseeded and cmaes is absent, so no particular stream has to be reproduced
+        self._rng = np.random.Generator(np.random.PCG64(seed))
 
     # ------------------------------------------------------------------ properties
     @property
@@ -136,7 +138,7 @@ class CMA:
 
     def _sample(self, count):
         b, d = self._eigen()
-        z = self._rng.randn(count, self._n)
+        z = self._rng.standard_normal((count, self._n))
         y = (z * d) @ b.T                      # rows: B diag(D) z
         return self._mean + self._sigma * y
 
@@ -162,14 +164,24 @@ class CMA:
         """All ``population_size`` candidates of one generation as a (P, D) array, with the
         same re-sample-then-clip rule applied row-wise."""
         x = self._sample(self._lam)
-        bad = ~self._feasible(x)
+        bad = np.flatnonzero(~self._feasible(x))
         tries = 1
-        while bad.any() and tries < self._n_max_resampling:
-            x[bad] = self._sample(int(bad.sum()))
-            bad = ~self._feasible(x)
-            tries += 1
-        if bad.any():
-            x[bad] = self._repair(self._sample(int(bad.sum())))
+        batch = 1
+        # rows still infeasible draw their next `batch` re-samples at once (batch doubles), and
+        # keep the FIRST feasible one: the same per-candidate sequence as a round-by-round loop,
+        # in ~log2(n_max_resampling) numpy calls instead of n_max_resampling
+        while bad.size and tries < self._n_max_resampling:
+            r = min(batch, self._n_max_resampling - tries)
+            cand = self._sample(bad.size * r).reshape(bad.size, r, self._n)
+            ok = self._feasible(cand)                         # (bad, r)
+            hit = ok.any(axis=1)
+            first = ok.argmax(axis=1)
+            x[bad[hit]] = cand[hit, first[hit]]
+            bad = bad[~hit]
+            tries += r
+            batch *= 2
+        if bad.size:
+            x[bad] = self._repair(self._sample(bad.size))
         return x
 
     # ------------------------------------------------------------------ update
@@ -178,17 +190,28 @@ class CMA:
         (stable, ascending value; NaN ranks last) -> ``solutions[0]`` is the generation's best."""
         if len(solutions) != self._lam:
             raise ValueError("Must tell popsize-length solutions.")
-        for s in solutions:
-            if not np.all(np.abs(s[0]) < _MEAN_MAX):
-                raise ValueError(f"Abs of all param values must be less than {_MEAN_MAX} to avoid overflow errors")
+        x = np.array([s[0] for s in solutions], dtype=np.float64)
+        values = np.array([s[1] for s in solutions], dtype=np.float64)
+        order = self.tell_population(x, values)
+        solutions[:] = [solutions[i] for i in order]
+
+    def tell_population(self, x, values):
+        """Array form of ``tell`` used by the GPU path: ``x`` (P, D) candidates, ``values`` (P,)
+        losses.  Returns the stable ascending order (NaN last) that ``tell`` applies to its list."""
+        x = np.asarray(x, dtype=np.float64)
+        values = np.asarray(values, dtype=np.float64)
+        if x.shape != (self._lam, self._n) or values.shape != (self._lam,):
+            raise ValueError("Must tell popsize-length solutions.")
+        if not np.all(np.abs(x) < _MEAN_MAX):
+            raise ValueError(f"Abs of all param values must be less than {_MEAN_MAX} to avoid overflow errors")
         self._g += 1
-        solutions.sort(key=lambda s: (math.inf if s[1] != s[1] else s[1]))
+        order = np.argsort(np.where(np.isnan(values), np.inf, values), kind="stable")
 
         b, d = self._eigen()
         self._B, self._D = None, None
         n = self._n
 
-        x_k = np.array([s[0] for s in solutions])
+        x_k = x[order]
         y_k = (x_k - self._mean) / self._sigma
 
         y_w = np.sum(y_k[:self._mu].T * self._weights[:self._mu], axis=1)
@@ -215,3 +238,4 @@ class CMA:
         rank_mu = (y_k.T * w_io) @ y_k
         self._C = ((1 + self._c1 * delta_h - self._c1 - self._cmu * np.sum(self._weights)) * self._C
                    + self._c1 * rank_one + self._cmu * rank_mu)
+        return order

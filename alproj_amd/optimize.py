@@ -237,7 +237,7 @@ class CMAOptimizer(BaseOptimizer):
                 X = optimizer.ask_population()
                 losses, amin = loss_function(X)
                 best_normalized = X[amin].copy()
-                optimizer.tell([(X[i], losses[i]) for i in range(len(X))])
+                optimizer.tell_population(X, losses)
             best_values = best_normalized * (upper - lower) + lower
             params = self._result_params(best_values)
             # final error is always the mean distance (optimize.py:435-437)

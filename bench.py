@@ -241,7 +241,7 @@ def main():
             cand = np.tile(basev, (args.pop, 1))
             cand[:, cols] = X * (upper - lower) + lower
             losses, amin = pts.eval_population(cand, L.LOSS_HUBER, 10.0)
-            opt.tell([(X[i], losses[i]) for i in range(args.pop)])
+            opt.tell_population(X, losses)
             state["best"] = float(losses[amin])
 
         k_cma = args.cma_steps or min(args.steps, 10)
