@@ -346,6 +346,77 @@ __device__ __forceinline__ void load_view_tri(const View &v, const float *__rest
     }
 }
 
+// One snapped window-space triangle (all vertices in front of the near plane, inside the
+// fixed-point range): cheap bounding-box rejection, then either the 32-bit inline walk
+// (triangles under 2^INLINE_LOG2/256 px), the 64-bit inline walk (<= SMALL_PIXELS centres) or
+// 64x64-pixel work items for raster_large_kernel.  `sub` = index in the clip fan.
+#ifndef INLINE_LOG2
+#define INLINE_LOG2 14      // triangles below 2^INLINE_LOG2 / 256 px are finished inside the thread
+#endif
+__device__ __forceinline__ void emit_snapped(const View &v, const int X[3], const int Y[3], const float iw3[3],
+                                             long long t, int sub, unsigned long long *__restrict__ vis,
+                                             WorkItem *__restrict__ queue, unsigned *__restrict__ qcount,
+                                             unsigned qcap) {
+    // cheap rejection before the 64-bit set-up: bounding box without a pixel centre, or
+    // entirely outside the viewport
+    const int minx = min(X[0], min(X[1], X[2])), maxx = max(X[0], max(X[1], X[2]));
+    const int miny = min(Y[0], min(Y[1], Y[2])), maxy = max(Y[0], max(Y[1], Y[2]));
+    const int i0 = (minx + SUB / 2 - 1) >> 8, i1 = (maxx - SUB / 2) >> 8;       // SUB == 256
+    const int j0 = (miny + SUB / 2 - 1) >> 8, j1 = (maxy - SUB / 2) >> 8;
+    if (i0 > i1 || j0 > j1 || i1 < 0 || j1 < 0 || i0 > v.w - 1 || j0 > v.h - 1) return;
+    if (maxx - minx < (1 << INLINE_LOG2) && maxy - miny < (1 << INLINE_LOG2)) {
+        // triangle smaller than 64 px: every product of the set-up fits 32 bits when taken
+        // relative to the first pixel centre -- the same integers as the 64-bit path
+        const int area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (X[2] - X[0]) * (Y[1] - Y[0]);
+        if (area2 <= 0) return;
+        const int ci0 = max(i0, 0), ci1 = min(i1, v.w - 1), cj0 = max(j0, 0), cj1 = min(j1, v.h - 1);
+        const int px0 = ci0 * SUB + SUB / 2, py0 = cj0 * SUB + SUB / 2;
+        int dx[3], dy[3], row[3];
+        bool tl[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int a = (k + 1) % 3, b = (k + 2) % 3;
+            dx[k] = X[b] - X[a];
+            dy[k] = Y[b] - Y[a];
+            row[k] = dx[k] * (py0 - Y[a]) - dy[k] * (px0 - X[a]);
+            tl[k] = dy[k] < 0 || (dy[k] == 0 && dx[k] > 0);
+        }
+        const float areaf = (float)area2;
+        for (int j = cj0; j <= cj1; ++j) {
+            int e0 = row[0], e1 = row[1], e2 = row[2];
+            for (int i = ci0; i <= ci1; ++i) {
+                const bool in0 = e0 > 0 || (e0 == 0 && tl[0]);
+                const bool in1 = e1 > 0 || (e1 == 0 && tl[1]);
+                const bool in2 = e2 > 0 || (e2 == 0 && tl[2]);
+                if (in0 && in1 && in2) {
+                    const float q = __builtin_fmaf((float)e2, iw3[2], __builtin_fmaf((float)e1, iw3[1], (float)e0 * iw3[0])) / areaf;
+                    vis_max(vis, v, i, j, ((unsigned long long)__float_as_uint(q) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)t));
+                }
+                e0 -= dy[0] * SUB;
+                e1 -= dy[1] * SUB;
+                e2 -= dy[2] * SUB;
+            }
+            row[0] += dx[0] * SUB;
+            row[1] += dx[1] * SUB;
+            row[2] += dx[2] * SUB;
+        }
+        return;
+    }
+    const TriSetup s = setup_snapped(v, X, Y, iw3);
+    if (!s.valid) return;
+    const int bw = s.i1 - s.i0 + 1, bh = s.j1 - s.j0 + 1;
+    if ((long long)bw * bh <= SMALL_PIXELS) {
+        raster_bbox(s, (unsigned)t, vis, v);
+    } else {
+        for (int ty = s.j0 / TILE; ty <= s.j1 / TILE; ++ty)
+            for (int tx = s.i0 / TILE; tx <= s.i1 / TILE; ++tx) {
+                const unsigned slot = atomicAdd(qcount, 1u);
+                if (slot < qcap)
+                    queue[slot] = WorkItem{(unsigned)t, (unsigned short)sub, (unsigned short)tx, (unsigned short)ty, 0};
+            }
+    }
+}
+
 // ------------------------------------------------------------------ kernel 2: per-triangle raster
 template <bool IMPLICIT>
 __global__ __launch_bounds__(256) void raster_kernel(const float *__restrict__ vert, const int *__restrict__ ind,
@@ -367,21 +438,10 @@ __global__ __launch_bounds__(256) void raster_kernel(const float *__restrict__ v
             continue;
         }
         for (int f = 0; f < ntri; ++f) {
-            const float x3[3] = {xw[0], xw[f + 1], xw[f + 2]}, y3[3] = {yw[0], yw[f + 1], yw[f + 2]},
-                        i3[3] = {iw[0], iw[f + 1], iw[f + 2]};
-            const TriSetup s = setup_tri(v, x3, y3, i3);
-            if (!s.valid) continue;
-            const int bw = s.i1 - s.i0 + 1, bh = s.j1 - s.j0 + 1;
-            if ((long long)bw * bh <= SMALL_PIXELS) {
-                raster_bbox(s, (unsigned)t, vis, v);
-            } else {
-                for (int ty = s.j0 / TILE; ty <= s.j1 / TILE; ++ty)
-                    for (int tx = s.i0 / TILE; tx <= s.i1 / TILE; ++tx) {
-                        const unsigned slot = atomicAdd(qcount, 1u);
-                        if (slot < qcap)
-                            queue[slot] = WorkItem{(unsigned)t, (unsigned short)f, (unsigned short)tx, (unsigned short)ty, 0};
-                    }
-            }
+            const int X[3] = {snap(xw[0]), snap(xw[f + 1]), snap(xw[f + 2])};
+            const int Y[3] = {snap(yw[0]), snap(yw[f + 1]), snap(yw[f + 2])};
+            const float i3[3] = {iw[0], iw[f + 1], iw[f + 2]};
+            emit_snapped(v, X, Y, i3, t, f, vis, queue, qcount, qcap);
         }
     }
 }
@@ -393,9 +453,6 @@ __global__ __launch_bounds__(256) void raster_kernel(const float *__restrict__ v
 // one thread per cell = two triangles read from LDS; the common case (three vertices in front,
 // inside the fixed-point range) goes straight to the integer set-up, everything else takes
 // the same clip_project path as raster_kernel.  Same arithmetic, same results.
-#ifndef INLINE_LOG2
-#define INLINE_LOG2 14      // triangles below 2^INLINE_LOG2 / 256 px are finished inside the thread
-#endif
 constexpr int GT_W = 32, GT_H = 8, GT_VW = GT_W + 1, GT_VH = GT_H + 1, GT_NV = GT_VW * GT_VH;
 
 __global__ __launch_bounds__(256) void raster_grid_kernel(const float *__restrict__ vert, int gh, int gw, View v,
@@ -444,65 +501,8 @@ __global__ __launch_bounds__(256) void raster_grid_kernel(const float *__restric
         const long long t = 2 * cell + half;
         if (s_flag[k0] & s_flag[k1] & s_flag[k2]) {
             const int X[3] = {s_X[k0], s_X[k1], s_X[k2]}, Y[3] = {s_Y[k0], s_Y[k1], s_Y[k2]};
-            // cheap rejection before the 64-bit set-up: bounding box without a pixel centre, or
-            // entirely outside the viewport
-            const int minx = min(X[0], min(X[1], X[2])), maxx = max(X[0], max(X[1], X[2]));
-            const int miny = min(Y[0], min(Y[1], Y[2])), maxy = max(Y[0], max(Y[1], Y[2]));
-            const int i0 = (minx + SUB / 2 - 1) >> 8, i1 = (maxx - SUB / 2) >> 8;       // SUB == 256
-            const int j0 = (miny + SUB / 2 - 1) >> 8, j1 = (maxy - SUB / 2) >> 8;
-            if (i0 > i1 || j0 > j1 || i1 < 0 || j1 < 0 || i0 > v.w - 1 || j0 > v.h - 1) continue;
             const float iw3[3] = {s_iw[k0], s_iw[k1], s_iw[k2]};
-            if (maxx - minx < (1 << INLINE_LOG2) && maxy - miny < (1 << INLINE_LOG2)) {
-                // triangle smaller than 64 px: every product of the set-up fits 32 bits when taken
-                // relative to the first pixel centre -- the same integers as the 64-bit path
-                const int area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (X[2] - X[0]) * (Y[1] - Y[0]);
-                if (area2 <= 0) continue;
-                const int ci0 = max(i0, 0), ci1 = min(i1, v.w - 1), cj0 = max(j0, 0), cj1 = min(j1, v.h - 1);
-                const int px0 = ci0 * SUB + SUB / 2, py0 = cj0 * SUB + SUB / 2;
-                int dx[3], dy[3], row[3];
-                bool tl[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int a = (k + 1) % 3, b = (k + 2) % 3;
-                    dx[k] = X[b] - X[a];
-                    dy[k] = Y[b] - Y[a];
-                    row[k] = dx[k] * (py0 - Y[a]) - dy[k] * (px0 - X[a]);
-                    tl[k] = dy[k] < 0 || (dy[k] == 0 && dx[k] > 0);
-                }
-                const float areaf = (float)area2;
-                for (int j = cj0; j <= cj1; ++j) {
-                    int e0 = row[0], e1 = row[1], e2 = row[2];
-                    for (int i = ci0; i <= ci1; ++i) {
-                        const bool in0 = e0 > 0 || (e0 == 0 && tl[0]);
-                        const bool in1 = e1 > 0 || (e1 == 0 && tl[1]);
-                        const bool in2 = e2 > 0 || (e2 == 0 && tl[2]);
-                        if (in0 && in1 && in2) {
-                            const float q = __builtin_fmaf((float)e2, iw3[2], __builtin_fmaf((float)e1, iw3[1], (float)e0 * iw3[0])) / areaf;
-                            vis_max(vis, v, i, j, ((unsigned long long)__float_as_uint(q) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)t));
-                        }
-                        e0 -= dy[0] * SUB;
-                        e1 -= dy[1] * SUB;
-                        e2 -= dy[2] * SUB;
-                    }
-                    row[0] += dx[0] * SUB;
-                    row[1] += dx[1] * SUB;
-                    row[2] += dx[2] * SUB;
-                }
-                continue;
-            }
-            const TriSetup s = setup_snapped(v, X, Y, iw3);
-            if (!s.valid) continue;
-            const int bw = s.i1 - s.i0 + 1, bh = s.j1 - s.j0 + 1;
-            if ((long long)bw * bh <= SMALL_PIXELS) {
-                raster_bbox(s, (unsigned)t, vis, v);
-            } else {
-                for (int ty = s.j0 / TILE; ty <= s.j1 / TILE; ++ty)
-                    for (int tx = s.i0 / TILE; tx <= s.i1 / TILE; ++tx) {
-                        const unsigned slot = atomicAdd(qcount, 1u);
-                        if (slot < qcap)
-                            queue[slot] = WorkItem{(unsigned)t, 0, (unsigned short)tx, (unsigned short)ty, 0};
-                    }
-            }
+            emit_snapped(v, X, Y, iw3, t, 0, vis, queue, qcount, qcap);
         } else {
             // near-plane crossing, behind the camera or out of range: the general path
             const float q[3][3] = {{s_q[0][k0], s_q[1][k0], s_q[2][k0]},
@@ -518,21 +518,10 @@ __global__ __launch_bounds__(256) void raster_grid_kernel(const float *__restric
                 continue;
             }
             for (int f = 0; f < ntri; ++f) {
-                const float x3[3] = {xw[0], xw[f + 1], xw[f + 2]}, y3[3] = {yw[0], yw[f + 1], yw[f + 2]},
-                            i3[3] = {iw[0], iw[f + 1], iw[f + 2]};
-                const TriSetup s = setup_tri(v, x3, y3, i3);
-                if (!s.valid) continue;
-                const int bw = s.i1 - s.i0 + 1, bh = s.j1 - s.j0 + 1;
-                if ((long long)bw * bh <= SMALL_PIXELS) {
-                    raster_bbox(s, (unsigned)t, vis, v);
-                } else {
-                    for (int ty = s.j0 / TILE; ty <= s.j1 / TILE; ++ty)
-                        for (int tx = s.i0 / TILE; tx <= s.i1 / TILE; ++tx) {
-                            const unsigned slot = atomicAdd(qcount, 1u);
-                            if (slot < qcap)
-                                queue[slot] = WorkItem{(unsigned)t, (unsigned short)f, (unsigned short)tx, (unsigned short)ty, 0};
-                        }
-                }
+                const int X[3] = {snap(xw[0]), snap(xw[f + 1]), snap(xw[f + 2])};
+                const int Y[3] = {snap(yw[0]), snap(yw[f + 1]), snap(yw[f + 2])};
+                const float i3[3] = {iw[0], iw[f + 1], iw[f + 2]};
+                emit_snapped(v, X, Y, i3, t, f, vis, queue, qcount, qcap);
             }
         }
     }
