@@ -201,8 +201,8 @@ __device__ __forceinline__ unsigned long long pixel_key(const TriSetup &s, int i
         e[k] = dx * (py - s.Y[a]) - dy * (px - s.X[a]);
         if (e[k] < 0 || (e[k] == 0 && !(dy < 0 || (dy == 0 && dx > 0)))) return 0ull;
     }
-    const float q = __builtin_fmaf((float)e[2], s.iw[2], __builtin_fmaf((float)e[1], s.iw[1], (float)e[0] * s.iw[0])) /
-                    (float)s.area2;
+    const float q = __builtin_fmaf((float)e[2], s.iw[2], __builtin_fmaf((float)e[1], s.iw[1], (float)e[0] * s.iw[0])) *
+                    (1.0f / (float)s.area2);
     return ((unsigned long long)__float_as_uint(q) << 32) | (unsigned long long)(0xFFFFFFFFu - tri);
 }
 
@@ -227,7 +227,7 @@ __device__ __forceinline__ void raster_bbox(const TriSetup &s, unsigned tri, uns
         row[k] = dx[k] * (py0 - s.Y[a]) - dy[k] * (px0 - s.X[a]);
         tl[k] = dy[k] < 0 || (dy[k] == 0 && dx[k] > 0);
     }
-    const float inv_area_num = (float)s.area2;
+    const float inv_area = 1.0f / (float)s.area2;
     for (int j = s.j0; j <= s.j1; ++j) {
         long long e0 = row[0], e1 = row[1], e2 = row[2];
         for (int i = s.i0; i <= s.i1; ++i) {
@@ -235,8 +235,8 @@ __device__ __forceinline__ void raster_bbox(const TriSetup &s, unsigned tri, uns
             const bool in1 = e1 > 0 || (e1 == 0 && tl[1]);
             const bool in2 = e2 > 0 || (e2 == 0 && tl[2]);
             if (in0 && in1 && in2) {
-                const float q = __builtin_fmaf((float)e2, s.iw[2], __builtin_fmaf((float)e1, s.iw[1], (float)e0 * s.iw[0])) /
-                                inv_area_num;
+                const float q = __builtin_fmaf((float)e2, s.iw[2], __builtin_fmaf((float)e1, s.iw[1], (float)e0 * s.iw[0])) *
+                                inv_area;
                 vis_max(vis, v, i, j, ((unsigned long long)__float_as_uint(q) << 32) | (unsigned long long)(0xFFFFFFFFu - tri));
             }
             e0 -= dy[0] * SUB;
@@ -371,30 +371,31 @@ __device__ __forceinline__ void emit_snapped(const View &v, const int X[3], cons
         if (area2 <= 0) return;
         const int ci0 = max(i0, 0), ci1 = min(i1, v.w - 1), cj0 = max(j0, 0), cj1 = min(j1, v.h - 1);
         const int px0 = ci0 * SUB + SUB / 2, py0 = cj0 * SUB + SUB / 2;
-        int dx[3], dy[3], row[3];
-        bool tl[3];
+        // the tie rule is folded into the stepped value: w = e - (edge owns its boundary ? 0 : 1),
+        // so "inside" is simply w0, w1, w2 >= 0 = sign bit of (w0 | w1 | w2)
+        int dx[3], dy[3], row[3], bias[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int a = (k + 1) % 3, b = (k + 2) % 3;
             dx[k] = X[b] - X[a];
             dy[k] = Y[b] - Y[a];
-            row[k] = dx[k] * (py0 - Y[a]) - dy[k] * (px0 - X[a]);
-            tl[k] = dy[k] < 0 || (dy[k] == 0 && dx[k] > 0);
+            bias[k] = (dy[k] < 0 || (dy[k] == 0 && dx[k] > 0)) ? 0 : 1;
+            row[k] = dx[k] * (py0 - Y[a]) - dy[k] * (px0 - X[a]) - bias[k];
         }
-        const float areaf = (float)area2;
+        const float inv_area = 1.0f / (float)area2;
+        const unsigned long long lo = (unsigned long long)(0xFFFFFFFFu - (unsigned)t);
         for (int j = cj0; j <= cj1; ++j) {
-            int e0 = row[0], e1 = row[1], e2 = row[2];
+            int w0 = row[0], w1 = row[1], w2 = row[2];
             for (int i = ci0; i <= ci1; ++i) {
-                const bool in0 = e0 > 0 || (e0 == 0 && tl[0]);
-                const bool in1 = e1 > 0 || (e1 == 0 && tl[1]);
-                const bool in2 = e2 > 0 || (e2 == 0 && tl[2]);
-                if (in0 && in1 && in2) {
-                    const float q = __builtin_fmaf((float)e2, iw3[2], __builtin_fmaf((float)e1, iw3[1], (float)e0 * iw3[0])) / areaf;
-                    vis_max(vis, v, i, j, ((unsigned long long)__float_as_uint(q) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)t));
+                if ((w0 | w1 | w2) >= 0) {
+                    const float q = __builtin_fmaf((float)(w2 + bias[2]), iw3[2],
+                                                   __builtin_fmaf((float)(w1 + bias[1]), iw3[1],
+                                                                  (float)(w0 + bias[0]) * iw3[0])) * inv_area;
+                    vis_max(vis, v, i, j, ((unsigned long long)__float_as_uint(q) << 32) | lo);
                 }
-                e0 -= dy[0] * SUB;
-                e1 -= dy[1] * SUB;
-                e2 -= dy[2] * SUB;
+                w0 -= dy[0] * SUB;
+                w1 -= dy[1] * SUB;
+                w2 -= dy[2] * SUB;
             }
             row[0] += dx[0] * SUB;
             row[1] += dx[1] * SUB;

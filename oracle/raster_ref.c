@@ -137,7 +137,7 @@ static void raster_tri(const view_t *v, const float xw[3], const float yw[3], co
     if (j0 < 0) j0 = 0;
     if (i1 > v->w - 1) i1 = v->w - 1;
     if (j1 > v->h - 1) j1 = v->h - 1;
-    const float areaf = (float)area2;
+    const float inv_area = 1.0f / (float)area2;     /* one IEEE division per triangle */
     for (int64_t j = j0; j <= j1; ++j)
         for (int64_t i = i0; i <= i1; ++i) {
             const int64_t px = i * SUB + SUB / 2, py = j * SUB + SUB / 2;
@@ -150,7 +150,7 @@ static void raster_tri(const view_t *v, const float xw[3], const float yw[3], co
                 if (e[k] < 0 || (e[k] == 0 && !(dy < 0 || (dy == 0 && dx > 0)))) inside = 0;
             }
             if (!inside) continue;
-            const float q = fmaf((float)e[2], iw[2], fmaf((float)e[1], iw[1], (float)e[0] * iw[0])) / areaf;
+            const float q = fmaf((float)e[2], iw[2], fmaf((float)e[1], iw[1], (float)e[0] * iw[0])) * inv_area;
             const uint64_t key = ((uint64_t)fbits(q) << 32) | (uint64_t)(0xFFFFFFFFu - tri);
             uint64_t *dst = &vis[(size_t)j * v->w + i];
             if (key > *dst) *dst = key;
