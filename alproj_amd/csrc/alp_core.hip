@@ -118,7 +118,9 @@ void fold_pose(const double p[ALP_NPARAM], const double origin[3], double rec[PO
     for (int i = 0; i < 4; ++i) rec[22 + i] = p[17 + i];  // s1..s4
     rec[26] = c0;
     rec[27] = c1;
-    for (int i = 28; i < POSE_WORDS; ++i) rec[i] = 0;
+    rec[28] = -c0;                                         // residual = (uo - c0) + (-c0) * x1_d
+    rec[29] = -c1;
+    rec[30] = rec[31] = 0;
 }
 
 }  // namespace alp

@@ -59,7 +59,8 @@ int comm_allreduce_sum_f64(double *dev_buf, int64_t count);
 //   20,21  2*p1, 2*p2
 //   22..25 s1..s4
 //   26,27  c0, c1 : float32-rounded image centre (w-1)/2, (h-1)/2
-//   28..31 unused (0)
+//   28,29  -c0, -c1
+//   30,31  unused (0)
 constexpr int POSE_WORDS = 32;
 
 template <typename T>

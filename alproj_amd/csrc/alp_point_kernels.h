@@ -204,13 +204,21 @@ template <typename T> struct PopCfg;
 template <> struct PopCfg<float> : PopCfgT<float, 4, 128, 2> {};
 template <> struct PopCfg<double> : PopCfgT<double, 2, 128, 1> {};
 
-// losses of V points against one pose record r (wave-uniform)
-template <typename T, int LOSS, int V>
-__device__ __forceinline__ void group_losses(const T *r, const T (&qx)[V], const T (&qy)[V], const T (&qz)[V],
-                                             const T (&uo)[V], const T (&vo)[V], T f_scale, T half_f2,
-                                             T (&loss)[V]) {
+// Sum of the losses of V points against one pose record r (wave-uniform).  uoc/voc are the
+// observed pixels minus the image centre (c0, c1 are the same for every candidate of a call:
+// checked on the host), so the residual is one fma: du = uoc - c0*a.
+//
+// Instruction count per point-candidate (float, Huber): 9 fma (folded transform) + 2 mul
+// (perspective) + 3 (x^2, y^2, r2) + 4 fma (radial numerator/denominator polynomials) + 4 fma
+// (+1, +1+a1, +1, +1+a2) + 13 (tangential/prism terms with shared 2p1xy and 2p2r2, ratios) +
+// 4 (residuals, squared distance) + 4 (Huber as 0.5 c (2r - c), c = min(r, f), fused into the
+// accumulation) = 43 full-rate + 4 quarter-rate (1/Z, two denominators, sqrt).
+template <typename T, int LOSS, int V, bool MASKED>
+__device__ __forceinline__ T group_loss_sum(const T *r, const T (&qx)[V], const T (&qy)[V], const T (&qz)[V],
+                                            const T (&uoc)[V], const T (&voc)[V], const bool (&ok)[V],
+                                            T f_scale, T half_f2) {
     using N = Num<T>;
-    T zc[V], x1[V], y1[V], r2[V], xx[V], yy[V], ax[V], ay[V];
+    T zc[V], x1[V], y1[V], r2[V], xx[V], yy[V], d2[V], dist[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {     // rigid transform + K + mirror + centring, folded (rows 0..11)
         zc[j] = N::fma(r[8], qx[j], N::fma(r[9], qy[j], N::fma(r[10], qz[j], r[11])));
@@ -248,37 +256,43 @@ __device__ __forceinline__ void group_losses(const T *r, const T (&qx)[V], const
     }
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-        const T xy = x1[j] * y1[j];
-        const T r4 = r2[j] * r2[j];
-        T a = x1[j] * (nx[j] * dx[j]);
-        a = N::fma(r[20], xy, a);
-        a = N::fma(r[21], r2[j] * xx[j], a);
-        a = N::fma(r[22], r2[j], a);
-        a = N::fma(r[23], r4, a);
-        T b = y1[j] * (ny[j] * dy[j]);
-        b = N::fma(r[20], xy, b);
-        b = N::fma(r[21], r2[j] * yy[j], b);
-        b = N::fma(r[24], r2[j], b);
-        b = N::fma(r[25], r4, b);
-        // pixels (optimize.py:117-118) and residual against the observation
-        const T du = uo[j] - N::fma(a, r[26], r[26]);
-        const T dv = vo[j] - N::fma(b, r[27], r[27]);
-        ax[j] = N::fma(dv, dv, du * du);             // squared distance
+        // x1_d = x1 num/den + 2 p1 x y + 2 p2 r2 x^2 + r2 (s1 + s2 r2)   (optimize.py:112-116, Q1)
+        const T t1 = r[20] * (x1[j] * y1[j]);             // 2 p1 x y       (shared by x and y)
+        const T pp = r[21] * r2[j];                       // 2 p2 r2        (shared)
+        T a = N::fma(pp, xx[j], t1);
+        a = N::fma(N::fma(r[23], r2[j], r[22]), r2[j], a);
+        a = N::fma(x1[j], nx[j] * dx[j], a);
+        T b = N::fma(pp, yy[j], t1);
+        b = N::fma(N::fma(r[25], r2[j], r[24]), r2[j], b);
+        b = N::fma(y1[j], ny[j] * dy[j], b);
+        // pixels u = a c0 + c0 (optimize.py:117-118): residual uo - u = (uo - c0) - c0 a
+        const T du = N::fma(a, r[28], uoc[j]);
+        const T dv = N::fma(b, r[29], voc[j]);
+        d2[j] = N::fma(dv, dv, du * du);
     }
 #pragma unroll
-    for (int j = 0; j < V; ++j) ay[j] = N::sqrt(ax[j]);
+    for (int j = 0; j < V; ++j) dist[j] = N::sqrt(d2[j]);
+    T acc = 0;
 #pragma unroll
     for (int j = 0; j < V; ++j) {
         if constexpr (LOSS == ALP_LOSS_MEAN_DIST) {
-            loss[j] = ay[j];                                          // optimize.py:176
+            acc += (MASKED && !ok[j]) ? (T)0 : dist[j];                                  // optimize.py:176
+        } else if constexpr (sizeof(T) == 4) {
+            // Huber (optimize.py:207-211) without a branch: with c = min(r, f),
+            // 0.5 c (2r - c) = 0.5 r^2 for r <= f and f (r - 0.5 f) beyond; a NaN r gives c = f and
+            // a NaN term, an infinite r an infinite term, like np.where
+            const T c = __builtin_fminf(dist[j], f_scale);
+            const T t = N::fma((T)2, dist[j], -c);
+            if (MASKED && !ok[j]) continue;
+            acc = N::fma((T)0.5 * c, t, acc);
         } else {
-            // optimize.py:207-211: r <= f ? 0.5 r^2 : f (r - 0.5 f); NaN <= f is false ->
-            // the linear branch propagates the NaN like np.where does
-            const T quad = (T)0.5 * (sizeof(T) == 8 ? ay[j] * ay[j] : ax[j]);
-            const T lin = N::fma(f_scale, ay[j], -half_f2);
-            loss[j] = (ay[j] <= f_scale) ? quad : lin;
+            const T quad = (T)0.5 * (dist[j] * dist[j]);
+            const T lin = N::fma(f_scale, dist[j], -half_f2);
+            // NaN <= f is false -> the linear branch propagates the NaN like np.where does
+            acc += (MASKED && !ok[j]) ? (T)0 : ((dist[j] <= f_scale) ? quad : lin);
         }
     }
+    return acc;
 }
 
 template <typename T, int LOSS, int V, bool MASKED>
@@ -289,29 +303,28 @@ __device__ __forceinline__ void pop_group(const T *__restrict__ x, const T *__re
                                           T f_scale, T half_f2) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    T qx[V], qy[V], qz[V], ou[V], ov[V];
+    T qx[V], qy[V], qz[V], uoc[V], voc[V];
     bool ok[V];
+    const T c0 = s_c[0].v[26], c1 = s_c[0].v[27];     // identical in every record of a call
 #pragma unroll
     for (int j = 0; j < V; ++j) {
         int64_t i = base + (int64_t)j * 256 + tid;
         ok[j] = MASKED ? (i < end) : true;
         if (MASKED && !ok[j]) i = base;       // any valid point; its loss is discarded
-        qx[j] = x[i]; qy[j] = y[i]; qz[j] = z[i]; ou[j] = uo[i]; ov[j] = vo[i];
+        qx[j] = x[i]; qy[j] = y[i]; qz[j] = z[i];
+        uoc[j] = uo[i] - c0;
+        voc[j] = vo[i] - c1;
     }
     for (int c = 0; c < tc; ++c) {
-        T r[28];
+        T r[32];
         const typename Num<T>::vec *rv = reinterpret_cast<const typename Num<T>::vec *>(s_c[c].v);
 #pragma unroll
-        for (int k = 0; k < 28 / Num<T>::VEC; ++k) {
+        for (int k = 0; k < 32 / Num<T>::VEC; ++k) {
             typename Num<T>::vec t = rv[k];
 #pragma unroll
             for (int e = 0; e < Num<T>::VEC; ++e) r[k * Num<T>::VEC + e] = vget<T>(t, e);
         }
-        T l[V];
-        group_losses<T, LOSS, V>(r, qx, qy, qz, ou, ov, f_scale, half_f2, l);
-        T acc = 0;
-#pragma unroll
-        for (int j = 0; j < V; ++j) acc += (MASKED && !ok[j]) ? (T)0 : l[j];
+        T acc = group_loss_sum<T, LOSS, V, MASKED>(r, qx, qy, qz, uoc, voc, ok, f_scale, half_f2);
         acc = wave_sum_to_lane63(acc);
         if (lane == 63) s_sum_wave[c] += (double)acc;
     }

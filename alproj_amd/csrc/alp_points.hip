@@ -146,6 +146,11 @@ int enqueue_popeval(alp_points *p, const double *cand, int64_t P, int loss_kind,
     if (rows < nblk) nblk = (int)(rows > 0 ? rows : 1);
     if (int rc = ensure_pop_scratch(p, P, nblk)) return rc;
     PoseRec<T> *h = (PoseRec<T> *)p->cand_host;
+    // the kernel centres the observations once per point: every candidate of a call must share
+    // the image size (the reference never optimises w, h: optimize.py:240-247)
+    for (int64_t i = 1; i < P; ++i)
+        if (cand[i * ALP_NPARAM + 21] != cand[21] || cand[i * ALP_NPARAM + 22] != cand[22])
+            return fail(ALP_EINVAL, "alp_eval_population: candidates %lld and 0 differ in w or h", (long long)i);
     for (int64_t i = 0; i < P; ++i) fold_pose_t<T>(cand + i * ALP_NPARAM, p->origin, &h[i]);
     ALP_HIP(hipMemcpyAsync(p->cand_dev, h, (size_t)P * sizeof(PoseRec<T>), hipMemcpyHostToDevice, ctx().stream));
     if (loss_kind == ALP_LOSS_HUBER)

@@ -45,4 +45,4 @@ for r in range(reps):
     print(f"rep {r}: {ms:.3f} ms")
 ev = len(xyz) * P
 print(f"N={len(xyz)} P={P} {prec}: best {best:.3f} ms  {ev / best / 1e6:.1f} G evals/s  "
-      f"{ev * 82 / best / 1e9:.1f} TFLOP/s(82/eval)  finite losses: {np.isfinite(losses).sum()}/{P}")
+      f"{ev * 77 / best / 1e9:.1f} TFLOP/s(77/eval)  finite losses: {np.isfinite(losses).sum()}/{P}")
