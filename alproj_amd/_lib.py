@@ -59,6 +59,7 @@ _SIGNATURES = {
     "alp_projected_fetch": [_c_void_p, _c_void_p, _c_void_p, _c_int],
     "alp_projected_fetch_strided": [_c_void_p, _c_i64, _c_i64, _c_i64, _c_dp, _c_dp],
     "alp_residuals": [_c_void_p, _c_dp, _c_dp],
+    "alp_residuals_batch": [_c_void_p, _c_dp, _c_i64, _c_dp],
     "alp_eval_population": [_c_void_p, _c_dp, _c_i64, _c_int, _c_double, _c_dp, ctypes.POINTER(_c_i64)],
     "alp_eval_population_enqueue": [_c_void_p, _c_dp, _c_i64, _c_int, _c_double],
     "alp_eval_population_wait": [_c_void_p, _c_dp, ctypes.POINTER(_c_i64)],
@@ -212,6 +213,15 @@ class Points:
         pvec = np.ascontiguousarray(pvec, dtype=np.float64)
         out = np.empty(2 * self.n, dtype=np.float64)
         check(self._lib.alp_residuals(self._h, as_dp(pvec), as_dp(out)))
+        return out
+
+    def residuals_batch(self, cand):
+        """(B, 25) parameter vectors -> (B, 2N) residual vectors, one launch."""
+        cand = np.ascontiguousarray(cand, dtype=np.float64)
+        if cand.ndim != 2 or cand.shape[1] != NPARAM:
+            raise ValueError("cand must have shape (B, 25)")
+        out = np.empty((cand.shape[0], 2 * self.n), dtype=np.float64)
+        check(self._lib.alp_residuals_batch(self._h, as_dp(cand), cand.shape[0], as_dp(out)))
         return out
 
     def eval_population(self, cand, loss_kind, f_scale=10.0):

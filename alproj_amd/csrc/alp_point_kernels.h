@@ -153,6 +153,27 @@ __global__ __launch_bounds__(256) void residual_kernel(const T *__restrict__ x, 
     }
 }
 
+// Residual vectors of B poses at once (finite-difference Jacobian of the least-squares path:
+// scipy's 2-point scheme needs D+1 evaluations per iteration, optimize.py:510-528).  Each point
+// is loaded once; the pose records are read with wave-uniform (scalar) loads.
+// out[b][i] = (uo - u_b, vo - v_b), b-major.
+template <typename T>
+__global__ __launch_bounds__(256) void residual_batch_kernel(const T *__restrict__ x, const T *__restrict__ y,
+                                                             const T *__restrict__ z, const T *__restrict__ uo,
+                                                             const T *__restrict__ vo, double2 *__restrict__ out,
+                                                             int64_t n, const PoseRec<T> *__restrict__ poses, int B) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const T qx = x[i], qy = y[i], qz = z[i], ou = uo[i], ov = vo[i];
+        for (int b = 0; b < B; ++b) {
+            T xd, yd, u, v;
+            project_norm<T>(poses[b].v, qx, qy, qz, xd, yd);
+            to_pixels<T>(poses[b].v, xd, yd, u, v);
+            out[(int64_t)b * n + i] = make_double2((double)(ou - u), (double)(ov - v));
+        }
+    }
+}
+
 // ------------------------------------------------------------------ wave64 sum
 // DPP butterfly inside each row of 16 lanes, then row_bcast15 / row_bcast31: lane 63 ends
 // up with the sum of all 64 lanes.  Fixed order -> bitwise reproducible.

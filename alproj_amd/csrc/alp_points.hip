@@ -341,6 +341,45 @@ int alp_residuals(alp_points_t *p, const double params[ALP_NPARAM], double *out)
     return ALP_OK;
 }
 
+int alp_residuals_batch(alp_points_t *p, const double *cand, int64_t B, double *out) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(p && cand, "NULL argument");
+    ALP_REQUIRE(B >= 1 && B <= 4096, "B out of range");
+    if (!p->uo) return fail(ALP_ESTATE, "alp_residuals_batch: observed uv not set");
+    if (p->n == 0) return ALP_OK;
+    ALP_REQUIRE(out, "out is NULL");
+    const size_t rec = POSE_WORDS * p->esize();
+    const size_t out_bytes = (size_t)B * p->n * sizeof(double2);
+    char *dev = nullptr;
+    ALP_HIP(hipMalloc((void **)&dev, out_bytes + (size_t)B * rec));
+    void *poses_dev = dev + out_bytes;
+    std::vector<char> poses_host((size_t)B * rec);
+    for (int64_t b = 0; b < B; ++b) {
+        if (p->precision == ALP_F64) fold_pose_t<double>(cand + b * ALP_NPARAM, p->origin, (PoseRec<double> *)poses_host.data() + b);
+        else fold_pose_t<float>(cand + b * ALP_NPARAM, p->origin, (PoseRec<float> *)poses_host.data() + b);
+    }
+    hipError_t e = hipMemcpyAsync(poses_dev, poses_host.data(), poses_host.size(), hipMemcpyHostToDevice, ctx().stream);
+    if (e == hipSuccess) {
+        const int grid = stream_grid(p->n);
+        if (p->precision == ALP_F64)
+            hipLaunchKernelGGL(residual_batch_kernel<double>, dim3(grid), dim3(256), 0, ctx().stream,
+                               (const double *)p->x, (const double *)p->y, (const double *)p->z,
+                               (const double *)p->uo, (const double *)p->vo, (double2 *)dev, p->n,
+                               (const PoseRec<double> *)poses_dev, (int)B);
+        else
+            hipLaunchKernelGGL(residual_batch_kernel<float>, dim3(grid), dim3(256), 0, ctx().stream,
+                               (const float *)p->x, (const float *)p->y, (const float *)p->z,
+                               (const float *)p->uo, (const float *)p->vo, (double2 *)dev, p->n,
+                               (const PoseRec<float> *)poses_dev, (int)B);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dev, out_bytes, hipMemcpyDeviceToHost, ctx().stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx().stream);     // poses_host must outlive the H2D copy
+    hipFree(dev);
+    if (e != hipSuccess) return fail(ALP_EHIP, "alp_residuals_batch: %s", hipGetErrorString(e));
+    return ALP_OK;
+}
+
 int alp_loss_uv(const double *observed, const double *projected, int64_t n, int loss_kind, double f_scale,
                 double *loss_out) {
     if (int rc = require_init()) return rc;

@@ -260,6 +260,33 @@ class LsqOptimizer(BaseOptimizer):
         _residuals.points = pts
         return _residuals
 
+    def _jacobian_function(self, pts, bounds=None):
+        """2-point finite-difference Jacobian with scipy's own step rule (relative step
+        sqrt(eps), sign-aware, flipped or shrunk at the bounds), but all D+1 residual vectors
+        come from ONE ``alp_residuals_batch`` launch instead of D+1 sequential calls."""
+        eps = np.finfo(np.float64).eps ** 0.5
+        lb = np.full(len(self.target_params), -np.inf) if bounds is None else np.asarray(bounds[0], dtype=np.float64)
+        ub = np.full(len(self.target_params), np.inf) if bounds is None else np.asarray(bounds[1], dtype=np.float64)
+
+        def _jac(values, *args, **kw):
+            x0 = np.asarray(values, dtype=np.float64)
+            h = eps * np.where(x0 >= 0, 1.0, -1.0) * np.maximum(1.0, np.abs(x0))
+            lower_dist, upper_dist = x0 - lb, ub - x0
+            x = x0 + h
+            violated = (x < lb) | (x > ub)
+            fitting = np.abs(h) <= np.maximum(lower_dist, upper_dist)
+            h = np.where(violated & fitting, -h, h)
+            h = np.where((upper_dist >= lower_dist) & ~fitting, upper_dist, h)
+            h = np.where((upper_dist < lower_dist) & ~fitting, -lower_dist, h)
+            d = len(x0)
+            trial = np.tile(x0, (d + 1, 1))
+            trial[np.arange(1, d + 1), np.arange(d)] += h
+            dx = trial[np.arange(1, d + 1), np.arange(d)] - x0          # the representable step
+            res = pts.residuals_batch(self._candidate_matrix(trial))
+            return ((res[1:] - res[0]) / dx[:, None]).T
+
+        return _jac
+
     def optimize(self, method="trf", bound_widths=None, loss="linear", f_scale=1.0, **kwargs):
         if method == "lm" and bound_widths is not None:
             raise ValueError("method='lm' does not support bounds. Set bound_widths=None or use 'trf'/'dogbox'.")
@@ -270,9 +297,14 @@ class LsqOptimizer(BaseOptimizer):
         pts = residual_func.points
         try:
             if method == "lm":
+                # MINPACK's own forward differences unless the caller asks for the batched ones
+                if kwargs.get("jac") == "batched":
+                    kwargs = dict(kwargs, jac=self._jacobian_function(pts))
                 result = least_squares(residual_func, self.target_params_init, method=method, **kwargs)
             else:
                 bounds = bounds_to_array(self.params_init, self.target_params, bound_widths)
+                if kwargs.get("jac", "batched") == "batched":
+                    kwargs = dict(kwargs, jac=self._jacobian_function(pts, (bounds[:, 0], bounds[:, 1])))
                 result = least_squares(residual_func, self.target_params_init, method=method,
                                        bounds=(bounds[:, 0], bounds[:, 1]), loss=loss,
                                        f_scale=f_scale, **kwargs)

@@ -127,6 +127,10 @@ int alp_projected_fetch_strided(alp_points_t *pts, int64_t first, int64_t stride
 /* Residual vector (observed - projected), interleaved du0,dv0,du1,dv1,... (2n doubles):
  * replaces compute_residuals(), src/alproj/optimize.py:215-237.  Needs observed uv. */
 int alp_residuals(alp_points_t *pts, const double params[ALP_NPARAM], double *out);
+/* The same for B parameter vectors in one launch (cand: B x 25 row-major; out: B x 2n doubles,
+ * row b = residual vector of pose b): the D+1 evaluations of a 2-point finite-difference
+ * Jacobian for LsqOptimizer, src/alproj/optimize.py:461-463, :510-528. */
+int alp_residuals_batch(alp_points_t *pts, const double *cand, int64_t B, double *out);
 
 /* Population-wide reprojection error: replaces the inner loop of CMAOptimizer.optimize,
  * src/alproj/optimize.py:420-423, i.e. P calls of _proj_error (:347-356) = project +
