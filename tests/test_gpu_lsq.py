@@ -72,9 +72,11 @@ def test_lsq_batched_jacobian_matches_scipy_two_point(L):
         J = o._jacobian_function(pts, (bounds[:, 0], bounds[:, 1]))(x0)
     finally:
         pts.close()
-    # forward differences with h ~ 1e-8 |x| turn the ~1e-10 px agreement of the two float64
-    # residual implementations into ~1e-4 absolute noise in J
-    np.testing.assert_allclose(J, J_ref, rtol=1e-3, atol=2e-3)
+    # forward differences with h ~ 1.5e-8 |x| turn the ~1e-9 px agreement of the two float64
+    # residual implementations into up to ~0.1 of absolute noise in single entries of J (both
+    # Jacobians carry that noise): compare in the Frobenius norm, and bound the outliers
+    assert np.linalg.norm(J - J_ref) <= 1e-4 * np.linalg.norm(J_ref)
+    assert np.abs(J - J_ref).max() < 0.5
     # robust loss + dogbox also run through the batched path
     p3, e3 = o.optimize(method="dogbox", loss="huber", f_scale=2.0)
     assert abs(p3["pan"] - truth["pan"]) < 0.05
