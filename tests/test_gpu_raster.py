@@ -212,3 +212,64 @@ def test_dsm_10m_full_frame(L):
     with L.Mesh(s["vert"], None, syn.grid_indices(n, np.int32)) as m:
         m.render_enqueue(pv, s["offsets"])
         assert_vis_equal(m.fetch_visibility(), vis)
+
+
+def _mesh_case(L, vert, ind, p, offsets=None):
+    ref = orast.visibility(vert, ind, p, offsets)
+    with L.Mesh(vert, None, ind) as m:
+        m.render_enqueue(L.params_vector(p), offsets)
+        got = m.fetch_visibility()
+    assert_vis_equal(got, ref)
+    return ref
+
+
+def test_hand_made_meshes(L):
+    """a few large triangles: the 64x64-tile pass, back faces, a shared edge through pixel
+    centres, a triangle through the camera plane, and the float64 fallback for projected
+    coordinates beyond the fixed-point range"""
+    p = dict(x=0.0, y=0.0, z=0.0, fov=60.0, pan=0.0, tilt=0.0, roll=0.0, a1=1, a2=1, k1=0, k2=0, k3=0, k4=0,
+             k5=0, k6=0, p1=0, p2=0, s1=0, s2=0, s3=0, s4=0, w=320, h=200, cx=160, cy=100)
+    # pan = 0 looks along +Y (north) in X, Z(up), Y storage: view z = stored third component
+    quad = np.array([[-20, -8, 60], [20, -8, 60], [20, 8, 60], [-20, 8, 60]], np.float32)
+    ind_ccw = np.array([[0, 1, 2], [0, 2, 3]], np.int64)
+    r1 = _mesh_case(L, quad, ind_ccw, p)
+    r2 = _mesh_case(L, quad, ind_ccw[:, ::-1].copy(), p)
+    assert (r1 != 0).any() != (r2 != 0).any()            # one orientation is culled entirely
+    front = ind_ccw if (r1 != 0).any() else ind_ccw[:, ::-1].copy()
+    vis = r1 if (r1 != 0).any() else r2
+    assert 0.2 < (vis != 0).mean() < 0.9
+    # both triangles of the quad appear and the diagonal has no hole
+    ids = np.unique(0xFFFFFFFF - (vis[vis != 0] & np.uint64(0xFFFFFFFF)).astype(np.int64))
+    assert list(ids) == [0, 1]
+    rows = np.nonzero((vis != 0).any(axis=1))[0]
+    inner = vis[rows[2]:rows[-2], :]
+    for row in inner:
+        cols = np.nonzero(row)[0]
+        assert (np.diff(cols) == 1).all()                # contiguous span: watertight diagonal
+    # a ground plane through the camera plane (near clip) seen from 2 units above
+    g = 500.0
+    ground = np.array([[-g, -2, -g], [g, -2, -g], [g, -2, g], [-g, -2, g]], np.float32)
+    _mesh_case(L, ground, front, p)
+    _mesh_case(L, ground, front[:, ::-1].copy(), p)
+    # a huge triangle whose vertices project millions of pixels away (vz just above 1): float64 fallback
+    far = np.array([[-3e6, -2e6, 1.001], [3e6, -2e6, 1.001], [0, 5e6, 2.0]], np.float32)
+    for tri in ([[0, 1, 2]], [[0, 2, 1]]):
+        _mesh_case(L, far, np.array(tri, np.int64), p)
+    # occlusion: a near small quad in front of a far big one, drawn in both orders
+    both = np.vstack([quad, quad * np.float32(0.25) + np.float32([0, 0, -30])]).astype(np.float32)
+    i2 = np.vstack([front, front + 4])
+    a = _mesh_case(L, both, i2, p)
+    b = _mesh_case(L, both, i2[::-1].copy(), p)
+    centre = a[100, 160]
+    assert (centre >> np.uint64(32)) == (b[100, 160] >> np.uint64(32))     # same depth wins regardless of order
+
+
+def test_frame_size_changes_and_tiny_frames(L, scene):
+    from alproj_amd import project as prj
+    with prj.Mesh(scene["vert"], scene["col"], scene["ind"]) as m:
+        for w, h in ((640, 427), (33, 17), (1, 1), (640, 427)):
+            p = dict(pose(scene, "base"), w=w, h=h, cx=w / 2, cy=h / 2)
+            got = prj.persp_proj(m, None, None, p, scene["offsets"])
+            ref = orast.render(scene["vert"], scene["col"], scene["ind"], p, scene["offsets"])
+            assert got.shape == (h, w, 3)
+            np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-6)
