@@ -116,10 +116,10 @@ def timed(ctl, L, fn, steps, warmup):
         fn()
     L.event_record(1)
     ctl.device_sync(L)
+    t1 = time.perf_counter()           # this rank's K steps are complete on its GPU
     ctl.barrier()
-    t1 = time.perf_counter()
     dev_ms = L.event_elapsed_ms(0, 1)
-    return ctl.max(t1 - t0), dev_ms
+    return ctl.max(t1 - t0), dev_ms    # MAX over ranks
 
 
 def cpu_baseline(orc, truth, xyz_sample, obs_sample):
