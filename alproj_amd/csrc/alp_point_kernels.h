@@ -234,32 +234,56 @@ template <> struct PopCfg<double> : PopCfgT<double, 2, 128, 1> {};
 // (+1, +1+a1, +1, +1+a2) + 13 (tangential/prism terms with shared 2p1xy and 2p2r2, ratios) +
 // 4 (residuals, squared distance) + 4 (Huber as 0.5 c (2r - c), c = min(r, f), fused into the
 // accumulation) = 43 full-rate + 4 quarter-rate (1/Z, two denominators, sqrt).
-template <typename T, int LOSS, int V, bool MASKED>
-__device__ __forceinline__ T group_loss_sum(const T *r, const T (&qx)[V], const T (&qy)[V], const T (&qz)[V],
-                                            const T (&uoc)[V], const T (&voc)[V], const bool (&ok)[V],
-                                            T f_scale, T half_f2) {
+// normalised, centred image coordinates of V points for the pose in rows 0..11 of r
+template <typename T, int V>
+struct NormCoords {
+    T x1[V], y1[V], xx[V], yy[V], r2[V];
+};
+
+template <typename T, int V>
+__device__ __forceinline__ void norm_coords(const T *r, const T (&qx)[V], const T (&qy)[V], const T (&qz)[V],
+                                            NormCoords<T, V> &o) {
     using N = Num<T>;
-    T zc[V], x1[V], y1[V], r2[V], xx[V], yy[V], d2[V], dist[V];
+    T zc[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {     // rigid transform + K + mirror + centring, folded (rows 0..11)
         zc[j] = N::fma(r[8], qx[j], N::fma(r[9], qy[j], N::fma(r[10], qz[j], r[11])));
-        x1[j] = N::fma(r[0], qx[j], N::fma(r[1], qy[j], N::fma(r[2], qz[j], r[3])));
-        y1[j] = N::fma(r[4], qx[j], N::fma(r[5], qy[j], N::fma(r[6], qz[j], r[7])));
+        o.x1[j] = N::fma(r[0], qx[j], N::fma(r[1], qy[j], N::fma(r[2], qz[j], r[3])));
+        o.y1[j] = N::fma(r[4], qx[j], N::fma(r[5], qy[j], N::fma(r[6], qz[j], r[7])));
     }
 #pragma unroll
     for (int j = 0; j < V; ++j) zc[j] = N::rcp(zc[j]);
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-        x1[j] *= zc[j];
-        y1[j] *= zc[j];
-        xx[j] = x1[j] * x1[j];
-        yy[j] = y1[j] * y1[j];
-        r2[j] = xx[j] + yy[j];
+        o.x1[j] *= zc[j];
+        o.y1[j] *= zc[j];
+        o.xx[j] = o.x1[j] * o.x1[j];
+        o.yy[j] = o.y1[j] * o.y1[j];
+        o.r2[j] = o.xx[j] + o.yy[j];
         if constexpr (sizeof(T) == 8) {            // Q2: the reference squares sqrt(x^2+y^2)
-            const T rr = N::sqrt(r2[j]);
-            r2[j] = rr * rr;
+            const T rr = N::sqrt(o.r2[j]);
+            o.r2[j] = rr * rr;
         }
     }
+}
+
+// SHARED_POSE: every candidate of the call has the same rows 0..11 (only distortion
+// coefficients are optimised, the reference's second phase, example.py:75-78): the
+// normalised coordinates `pre` were computed once per point outside the candidate loop.
+template <typename T, int LOSS, int V, bool MASKED, bool SHARED_POSE>
+__device__ __forceinline__ T group_loss_sum(const T *r, const T (&qx)[V], const T (&qy)[V], const T (&qz)[V],
+                                            const NormCoords<T, V> &pre, const T (&uoc)[V], const T (&voc)[V],
+                                            const bool (&ok)[V], T f_scale, T half_f2) {
+    using N = Num<T>;
+    NormCoords<T, V> own;
+    if constexpr (!SHARED_POSE) norm_coords<T, V>(r, qx, qy, qz, own);
+    const NormCoords<T, V> &nc = SHARED_POSE ? pre : own;
+    const T (&x1)[V] = nc.x1;
+    const T (&y1)[V] = nc.y1;
+    const T (&xx)[V] = nc.xx;
+    const T (&yy)[V] = nc.yy;
+    const T (&r2)[V] = nc.r2;
+    T d2[V], dist[V];
     T nx[V], ny[V], dx[V], dy[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
@@ -316,7 +340,7 @@ __device__ __forceinline__ T group_loss_sum(const T *r, const T (&qx)[V], const 
     return acc;
 }
 
-template <typename T, int LOSS, int V, bool MASKED>
+template <typename T, int LOSS, int V, bool MASKED, bool SHARED_POSE>
 __device__ __forceinline__ void pop_group(const T *__restrict__ x, const T *__restrict__ y,
                                           const T *__restrict__ z, const T *__restrict__ uo,
                                           const T *__restrict__ vo, int64_t base, int64_t end,
@@ -336,6 +360,8 @@ __device__ __forceinline__ void pop_group(const T *__restrict__ x, const T *__re
         uoc[j] = uo[i] - c0;
         voc[j] = vo[i] - c1;
     }
+    NormCoords<T, V> pre;
+    if constexpr (SHARED_POSE) norm_coords<T, V>(s_c[0].v, qx, qy, qz, pre);
     for (int c = 0; c < tc; ++c) {
         T r[32];
         const typename Num<T>::vec *rv = reinterpret_cast<const typename Num<T>::vec *>(s_c[c].v);
@@ -345,13 +371,13 @@ __device__ __forceinline__ void pop_group(const T *__restrict__ x, const T *__re
 #pragma unroll
             for (int e = 0; e < Num<T>::VEC; ++e) r[k * Num<T>::VEC + e] = vget<T>(t, e);
         }
-        T acc = group_loss_sum<T, LOSS, V, MASKED>(r, qx, qy, qz, uoc, voc, ok, f_scale, half_f2);
+        T acc = group_loss_sum<T, LOSS, V, MASKED, SHARED_POSE>(r, qx, qy, qz, pre, uoc, voc, ok, f_scale, half_f2);
         acc = wave_sum_to_lane63(acc);
         if (lane == 63) s_sum_wave[c] += (double)acc;
     }
 }
 
-template <typename T, int LOSS, typename Cfg = PopCfg<T>>
+template <typename T, int LOSS, typename Cfg = PopCfg<T>, bool SHARED_POSE = false>
 __global__ __launch_bounds__(256, Cfg::MINW) void popeval_kernel(
     const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ z, const T *__restrict__ uo,
     const T *__restrict__ vo, int64_t n, const PoseRec<T> *__restrict__ cands, int P, T f_scale,
@@ -384,9 +410,9 @@ __global__ __launch_bounds__(256, Cfg::MINW) void popeval_kernel(
         __syncthreads();
         int64_t base = beg;
         for (; base + 256 * V <= end; base += 256 * V)
-            pop_group<T, LOSS, V, false>(x, y, z, uo, vo, base, end, s_c, s_sum[wave], tc, f_scale, half_f2);
+            pop_group<T, LOSS, V, false, SHARED_POSE>(x, y, z, uo, vo, base, end, s_c, s_sum[wave], tc, f_scale, half_f2);
         for (; base < end; base += 256)
-            pop_group<T, LOSS, 1, true>(x, y, z, uo, vo, base, end, s_c, s_sum[wave], tc, f_scale, half_f2);
+            pop_group<T, LOSS, 1, true, SHARED_POSE>(x, y, z, uo, vo, base, end, s_c, s_sum[wave], tc, f_scale, half_f2);
         __syncthreads();
         if (tid < tc)
             partials[(int64_t)blockIdx.x * P + c0 + tid] =

@@ -153,16 +153,25 @@ int enqueue_popeval(alp_points *p, const double *cand, int64_t P, int loss_kind,
             return fail(ALP_EINVAL, "alp_eval_population: candidates %lld and 0 differ in w or h", (long long)i);
     for (int64_t i = 0; i < P; ++i) fold_pose_t<T>(cand + i * ALP_NPARAM, p->origin, &h[i]);
     ALP_HIP(hipMemcpyAsync(p->cand_dev, h, (size_t)P * sizeof(PoseRec<T>), hipMemcpyHostToDevice, ctx().stream));
-    if (loss_kind == ALP_LOSS_HUBER)
-        hipLaunchKernelGGL((popeval_kernel<T, ALP_LOSS_HUBER>), dim3(nblk), dim3(256), 0, ctx().stream,
-                           (const T *)p->x, (const T *)p->y, (const T *)p->z, (const T *)p->uo,
-                           (const T *)p->vo, p->n, (const PoseRec<T> *)p->cand_dev, (int)P, (T)f_scale,
-                           p->partials);
-    else
-        hipLaunchKernelGGL((popeval_kernel<T, ALP_LOSS_MEAN_DIST>), dim3(nblk), dim3(256), 0, ctx().stream,
-                           (const T *)p->x, (const T *)p->y, (const T *)p->z, (const T *)p->uo,
-                           (const T *)p->vo, p->n, (const PoseRec<T> *)p->cand_dev, (int)P, (T)f_scale,
-                           p->partials);
+    // distortion-only populations (the reference's second phase, example.py:75-78) share the
+    // folded 3x4 matrix: its 12 words are identical in every record, and the kernel then
+    // computes the normalised coordinates once per point instead of once per candidate
+    bool shared_pose = P > 1;
+    for (int64_t i = 1; i < P && shared_pose; ++i)
+        shared_pose = memcmp(h[i].v, h[0].v, 12 * sizeof(T)) == 0;
+#define ALP_LAUNCH_POPEVAL(LOSS, SHARED)                                                                  \
+    hipLaunchKernelGGL((popeval_kernel<T, LOSS, PopCfg<T>, SHARED>), dim3(nblk), dim3(256), 0, ctx().stream, \
+                       (const T *)p->x, (const T *)p->y, (const T *)p->z, (const T *)p->uo,              \
+                       (const T *)p->vo, p->n, (const PoseRec<T> *)p->cand_dev, (int)P, (T)f_scale,      \
+                       p->partials)
+    if (loss_kind == ALP_LOSS_HUBER) {
+        if (shared_pose) ALP_LAUNCH_POPEVAL(ALP_LOSS_HUBER, true);
+        else ALP_LAUNCH_POPEVAL(ALP_LOSS_HUBER, false);
+    } else {
+        if (shared_pose) ALP_LAUNCH_POPEVAL(ALP_LOSS_MEAN_DIST, true);
+        else ALP_LAUNCH_POPEVAL(ALP_LOSS_MEAN_DIST, false);
+    }
+#undef ALP_LAUNCH_POPEVAL
     ALP_HIP(hipGetLastError());
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((P + 31) / 32)), dim3(256), 0, ctx().stream,
                        p->partials, nblk, (int)P, (double)p->n, p->sums_dev);

@@ -238,6 +238,31 @@ def test_population_nan_semantics(L):
     assert np.isnan(losses[0]) and np.isfinite(losses[1]) and amin == 1
 
 
+@pytest.mark.parametrize("prec,rtol", [("f64", 1e-12), ("f32", 2e-6)])
+def test_population_shared_pose_path(L, prec, rtol):
+    """distortion-only populations (every candidate shares the 3x4 pose matrix) take a kernel
+    variant that hoists the transform out of the candidate loop: same losses as the general
+    variant, which is forced by appending one candidate with another pan"""
+    from alproj_amd import synthetic as syn
+    truth = syn.truth_params(316)
+    xyz = syn.gcp_points(3000, truth, seed=8)
+    rng = np.random.default_rng(8)
+    uv = orc.project_points(xyz, truth) + rng.normal(0, 1.0, (3000, 2))
+    cand = np.tile(L.params_vector(truth), (130, 1))
+    cand[:, 7:21] += rng.uniform(-0.01, 0.01, (130, 14))          # a1, a2, k1..s4 only
+    other = cand[:1].copy()
+    other[0, 4] += 0.5                                             # pan
+    with L.Points(xyz, [truth["x"], truth["y"], truth["z"]], prec) as pts:
+        pts.set_observed(uv)
+        for kind, fs in ((L.LOSS_HUBER, 10.0), (L.LOSS_MEAN_DIST, 0.0)):
+            shared, amin_s = pts.eval_population(cand, kind, fs)
+            general, amin_g = pts.eval_population(np.vstack([cand, other]), kind, fs)
+            np.testing.assert_allclose(shared, general[:130], rtol=rtol)
+            ref = np.array([orc.loss_of(xyz, uv, orc.vector_to_params(c), kind, fs) for c in cand[:5]])
+            np.testing.assert_allclose(shared[:5], ref, rtol=1e-9 if prec == "f64" else 1e-5)
+            assert amin_s == int(np.argmin(shared))
+
+
 def test_population_needs_observed(L):
     from alproj_amd import synthetic as syn
     p = syn.base_params(316)

@@ -33,6 +33,8 @@ rng = np.random.default_rng(0)
 cols = [L.PARAM_KEYS.index(t) for t in syn.TARGETS_D21]
 cand = np.tile(L.params_vector(base), (P, 1))
 w = np.array([30, 30, 30, 45, 45, 45, 45] + [0.2] * 14)
+if len(sys.argv) > 5 and sys.argv[5] == "distonly":
+    w[:7] = 0          # distortion-only population: every candidate shares the pose
 cand[:, cols] += rng.uniform(-0.1, 0.1, (P, 21)) * w
 best = 1e9
 for r in range(reps):
