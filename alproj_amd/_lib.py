@@ -71,6 +71,8 @@ _SIGNATURES = {
     "alp_render_enqueue": [_c_void_p, _c_dp, _c_dp, _c_double],
     "alp_render_fetch": [_c_void_p, _c_fp],
     "alp_render_fetch_visibility": [_c_void_p, ctypes.POINTER(ctypes.c_uint64)],
+    "alp_render_valid_count": [_c_void_p, ctypes.POINTER(_c_i64)],
+    "alp_render_fetch_valid": [_c_void_p, _c_dp, ctypes.POINTER(ctypes.c_uint32), _c_dp],
     "alp_distort_image": [_c_fp, _c_i64, _c_i64, _c_i64, _c_dp, _c_fp],
 }
 _RESTYPE = {"alp_last_error": ctypes.c_char_p}
@@ -315,6 +317,18 @@ class Mesh:
     def render(self, pvec, offsets=None, min_distance=None):
         self.render_enqueue(pvec, offsets, min_distance)
         return self.fetch()
+
+    def fetch_valid(self, offsets=None):
+        """After a render of the vertices themselves: (idx, xyz) of the pixels that see the
+        surface (first channel > 0), row-major; xyz = channels (0, 2, 1) + offsets, float64."""
+        n = _c_i64()
+        check(self._lib.alp_render_valid_count(self._h, ctypes.byref(n)))
+        idx = np.empty(n.value, dtype=np.uint32)
+        xyz = np.empty((n.value, 3), dtype=np.float64)
+        off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.float64)
+        check(self._lib.alp_render_fetch_valid(self._h, None if off is None else as_dp(off),
+                                               idx.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), as_dp(xyz)))
+        return idx, xyz
 
 
 def distort_image(img, coeffs):

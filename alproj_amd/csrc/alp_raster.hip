@@ -654,6 +654,90 @@ __global__ __launch_bounds__(256) void distort_image_kernel(const float *__restr
     }
 }
 
+// ------------------------------------------------------------------ reverse_proj post-processing
+// src/alproj/project.py:361-373 on the device: keep the pixels whose first rendered channel
+// (offset-relative x) is > 0 (quirk Q13), in row-major pixel order, and return their linear
+// index and x, y, z = channels 0, 2, 1 (+ offsets, added in float64 like the reference does).
+// Pass 1 counts per chunk of COMPACT_CHUNK pixels, a one-workgroup scan turns the counts into
+// offsets, pass 2 writes (order-preserving stream compaction).
+constexpr int COMPACT_CHUNK = 4096;
+
+__global__ __launch_bounds__(256) void valid_count_kernel(const float *__restrict__ img, long long npix,
+                                                          unsigned *__restrict__ counts) {
+    __shared__ unsigned s[4];
+    const long long base = (long long)blockIdx.x * COMPACT_CHUNK;
+    unsigned c = 0;
+    for (int k = threadIdx.x; k < COMPACT_CHUNK; k += 256) {
+        const long long p = base + k;
+        if (p < npix && img[p * 3] > 0.0f) ++c;
+    }
+    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+// exclusive scan of n counts (n up to a few ten thousand) by one workgroup; total -> offsets[n]
+__global__ __launch_bounds__(1024) void scan_counts_kernel(const unsigned *__restrict__ counts, int n,
+                                                           unsigned long long *__restrict__ offsets) {
+    __shared__ unsigned long long s[1024];
+    const int per = (n + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(n, lo + per);
+    unsigned long long sum = 0;
+    for (int i = lo; i < hi; ++i) sum += counts[i];
+    s[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                 // Hillis-Steele inclusive scan
+        unsigned long long t = threadIdx.x >= d ? s[threadIdx.x - d] : 0;
+        __syncthreads();
+        s[threadIdx.x] += t;
+        __syncthreads();
+    }
+    unsigned long long run = threadIdx.x ? s[threadIdx.x - 1] : 0;
+    for (int i = lo; i < hi; ++i) {
+        offsets[i] = run;
+        run += counts[i];
+    }
+    if (threadIdx.x == 1023) offsets[n] = s[1023];
+}
+
+__global__ __launch_bounds__(256) void valid_write_kernel(const float *__restrict__ img, long long npix,
+                                                          const unsigned long long *__restrict__ offsets,
+                                                          double o0, double o1, double o2,
+                                                          unsigned *__restrict__ idx_out,
+                                                          double *__restrict__ xyz_out) {
+    __shared__ unsigned s_wave[4];
+    const long long base = (long long)blockIdx.x * COMPACT_CHUNK;
+    unsigned long long out = offsets[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k0 = 0; k0 < COMPACT_CHUNK; k0 += 256) {   // consecutive pixels per pass keep the order
+        const long long p = base + k0 + threadIdx.x;
+        float c0 = 0, c1 = 0, c2 = 0;
+        bool valid = false;
+        if (p < npix) {
+            c0 = img[p * 3];
+            valid = c0 > 0.0f;
+            if (valid) { c1 = img[p * 3 + 1]; c2 = img[p * 3 + 2]; }
+        }
+        const unsigned long long m = __ballot(valid);
+        const unsigned before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave] = __popcll(m);
+        __syncthreads();
+        unsigned wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += s_wave[w];
+        const unsigned total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (valid) {
+            const unsigned long long o = out + wbase + before;
+            idx_out[o] = (unsigned)p;
+            xyz_out[o * 3 + 0] = (double)c0 + o0;        // x  (channel 0 + offsets[0])
+            xyz_out[o * 3 + 1] = (double)c2 + o2;        // y  (channel 2 + offsets[2])
+            xyz_out[o * 3 + 2] = (double)c1 + o1;        // z  (channel 1 + offsets[1])
+        }
+        out += total;
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void narrow_indices_kernel(const long long *__restrict__ src, long long count,
                                                              long long dst_off, int *__restrict__ dst) {
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -679,6 +763,11 @@ struct alp_mesh {
     unsigned *qcount_dev = nullptr;
     unsigned *qcount_host = nullptr;   // pinned
     bool rendered = false;
+    // reverse_proj compaction scratch
+    unsigned *compact_counts = nullptr;
+    unsigned long long *compact_offsets = nullptr;
+    int compact_cap = 0;
+    int64_t valid_total = -1;
 };
 
 namespace {
@@ -838,7 +927,7 @@ int alp_mesh_destroy(alp_mesh_t *m) {
     if (!m) return ALP_OK;
     if (ctx().ready) hipStreamSynchronize(ctx().stream);
     for (void *p : {(void *)m->vert, (void *)m->value, (void *)m->ind, (void *)m->vis, (void *)m->image,
-                    (void *)m->queue, (void *)m->qcount_dev})
+                    (void *)m->queue, (void *)m->qcount_dev, (void *)m->compact_counts, (void *)m->compact_offsets})
         if (p) hipFree(p);
     if (m->qcount_host) hipHostFree(m->qcount_host);
     delete m;
@@ -872,6 +961,62 @@ int alp_render_fetch_visibility(alp_mesh_t *m, uint64_t *out) {
     if (!m->rendered) return fail(ALP_ESTATE, "alp_render_fetch_visibility: nothing rendered yet");
     ALP_HIP(hipMemcpyAsync(out, m->vis, (size_t)m->w * m->h * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx().stream));
     ALP_HIP(hipStreamSynchronize(ctx().stream));
+    return ALP_OK;
+}
+
+int alp_render_valid_count(alp_mesh_t *m, int64_t *count) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(m && count, "NULL argument");
+    if (!m->rendered) return fail(ALP_ESTATE, "alp_render_valid_count: nothing rendered yet");
+    const long long npix = (long long)m->w * m->h;
+    const int chunks = (int)((npix + COMPACT_CHUNK - 1) / COMPACT_CHUNK);
+    if (chunks > m->compact_cap) {
+        if (m->compact_counts) hipFree(m->compact_counts);
+        if (m->compact_offsets) hipFree(m->compact_offsets);
+        m->compact_counts = nullptr;
+        m->compact_offsets = nullptr;
+        m->compact_cap = 0;
+        ALP_HIP(hipMalloc((void **)&m->compact_counts, (size_t)chunks * sizeof(unsigned)));
+        ALP_HIP(hipMalloc((void **)&m->compact_offsets, (size_t)(chunks + 1) * sizeof(unsigned long long)));
+        m->compact_cap = chunks;
+    }
+    hipStream_t st = ctx().stream;
+    hipLaunchKernelGGL(valid_count_kernel, dim3(chunks), dim3(256), 0, st, m->image, npix, m->compact_counts);
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, st, m->compact_counts, chunks, m->compact_offsets);
+    ALP_HIP(hipGetLastError());
+    unsigned long long total = 0;
+    ALP_HIP(hipMemcpyAsync(&total, m->compact_offsets + chunks, sizeof(total), hipMemcpyDeviceToHost, st));
+    ALP_HIP(hipStreamSynchronize(st));
+    m->valid_total = (int64_t)total;
+    *count = m->valid_total;
+    return ALP_OK;
+}
+
+int alp_render_fetch_valid(alp_mesh_t *m, const double *offsets, uint32_t *idx_out, double *xyz_out) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(m, "mesh handle is NULL");
+    if (m->valid_total < 0) return fail(ALP_ESTATE, "alp_render_fetch_valid: call alp_render_valid_count first");
+    const int64_t M = m->valid_total;
+    m->valid_total = -1;
+    if (M == 0) return ALP_OK;
+    ALP_REQUIRE(idx_out && xyz_out, "output is NULL");
+    const long long npix = (long long)m->w * m->h;
+    const int chunks = (int)((npix + COMPACT_CHUNK - 1) / COMPACT_CHUNK);
+    char *dev = nullptr;
+    const size_t xyz_bytes = (size_t)M * 3 * sizeof(double), idx_bytes = (size_t)M * sizeof(unsigned);
+    ALP_HIP(hipMalloc((void **)&dev, xyz_bytes + idx_bytes));
+    double *xyz_dev = (double *)dev;
+    unsigned *idx_dev = (unsigned *)(dev + xyz_bytes);
+    hipStream_t st = ctx().stream;
+    const double o0 = offsets ? offsets[0] : 0.0, o1 = offsets ? offsets[1] : 0.0, o2 = offsets ? offsets[2] : 0.0;
+    hipLaunchKernelGGL(valid_write_kernel, dim3(chunks), dim3(256), 0, st, m->image, npix, m->compact_offsets, o0, o1,
+                       o2, idx_dev, xyz_dev);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(xyz_out, xyz_dev, xyz_bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(idx_out, idx_dev, idx_bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(dev);
+    if (e != hipSuccess) return fail(ALP_EHIP, "alp_render_fetch_valid: %s", hipGetErrorString(e));
     return ALP_OK;
 }
 

@@ -11,7 +11,7 @@ here                          reference                               device ent
 ``distort``                   project.py:111-143                      alp_distort_image
 ``persp_proj``                project.py:145-294                      alp_mesh_create + alp_render
 ``sim_image``                 project.py:296-325                      (persp_proj + uint8/BGR)
-``reverse_proj``              project.py:327-374                      (persp_proj + DataFrame)
+``reverse_proj``              project.py:327-374                      alp_render + alp_render_fetch_valid
 ============================  ======================================  =====================
 
 ``to_geotiff`` (project.py:376-503: rasterio I/O and scipy focal statistics) is outside the
@@ -115,18 +115,24 @@ def reverse_proj(array, vert, ind, params, offsets=None, chnames=["B", "G", "R"]
     if array.shape[2] != len(chnames):
         raise ValueError("The array has {} channels but chnames has length of {}. Please set chnames correctly."
                          .format(array.shape[2], len(chnames)))
-    coord = persp_proj(vert, vert, ind, params, offsets, grid_shape=grid_shape)
-    coord = coord[:, :, [0, 2, 1]]                         # channel: x, z, y -> x, y, z
-    uv = np.meshgrid(np.arange(0, array.shape[1]), np.arange(0, array.shape[0]))
-    uv = np.stack(uv, axis=2)
-    concat = np.concatenate([uv, coord, array], 2).reshape(-1, 5 + array.shape[2])
-    columns = ["u", "v", "x", "y", "z"]
-    columns.extend(chnames)
-    df = pd.DataFrame(concat, columns=columns)
-    df[["u", "v"]] = df[["u", "v"]].astype("int16")
-    df = df[df["x"] > 0]
-    if offsets is not None:
-        df["x"] += offsets[0]
-        df["y"] += offsets[2]
-        df["z"] += offsets[1]
-    return df
+    pvec = _params_checked(params)
+    h, w = int(params["h"]), int(params["w"])
+    if array.shape[0] != h or array.shape[1] != w:
+        raise ValueError("all the input array dimensions except for the concatenation axis must match exactly "
+                         f"(array is {array.shape[:2]}, the camera image {(h, w)})")
+    # the render, the x > 0 selection (:369), the x,z,y -> x,y,z reorder (:361) and the offsets
+    # (:370-373) happen on the device; only the surviving pixels travel back
+    if isinstance(vert, _lib.Mesh):
+        vert.render_enqueue(pvec, offsets, None)
+        idx, xyz = vert.fetch_valid(offsets)
+    else:
+        with _lib.Mesh(np.asarray(vert), None, ind, grid_shape) as mesh:
+            mesh.render_enqueue(pvec, offsets, None)
+            idx, xyz = mesh.fetch_valid(offsets)
+    data = {"u": (idx % w).astype("int16"), "v": (idx // w).astype("int16"),
+            "x": xyz[:, 0], "y": xyz[:, 1], "z": xyz[:, 2]}
+    flat = np.asarray(array).reshape(-1, array.shape[2])
+    for k, name in enumerate(chnames):
+        data[name] = flat[idx, k].astype(np.float64)
+    # the reference filters a RangeIndex-ed frame, so the labels are the linear pixel indices
+    return pd.DataFrame(data, index=pd.Index(idx.astype(np.int64)))

@@ -195,6 +195,15 @@ int alp_render_fetch(alp_mesh_t *mesh, float *out);
  * (0xFFFFFFFF - index of the winning triangle).  For inspection and parity tests. */
 int alp_render_fetch_visibility(alp_mesh_t *mesh, uint64_t *out);
 
+/* Post-processing of reverse_proj(), src/alproj/project.py:361-373, for a render whose
+ * values are the vertices themselves (value == NULL): the pixels whose first channel (offset-
+ * relative x) is > 0 (:369), in row-major order.  alp_render_valid_count returns their number
+ * M; alp_render_fetch_valid then writes idx_out[M] (linear pixel index v * w + u) and
+ * xyz_out[M][3] = (x, y, z) = channels (0, 2, 1) (:361) plus offsets[0], offsets[2],
+ * offsets[1] (:370-373; NULL = no offsets), float64. */
+int alp_render_valid_count(alp_mesh_t *mesh, int64_t *count);
+int alp_render_fetch_valid(alp_mesh_t *mesh, const double *offsets, uint32_t *idx_out, double *xyz_out);
+
 /* Image-space distortion remap alone: replaces distort(), src/alproj/project.py:111-143.
  * img/out: h x w x c float32 host images; coeffs: a1,a2,k1..k6,p1,p2,s1..s4. */
 int alp_distort_image(const float *img, int64_t h, int64_t w, int64_t c,

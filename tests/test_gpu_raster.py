@@ -134,6 +134,15 @@ def test_reverse_proj_and_sim_image(L, scene):
     np.testing.assert_allclose(df["y"].to_numpy(), coord[seen][:, 2] + off[2], rtol=1e-9)
     np.testing.assert_allclose(df["z"].to_numpy(), coord[seen][:, 1] + off[1], rtol=1e-9)
     np.testing.assert_array_equal(df["B"].to_numpy(), sim[seen][:, 0])
+    assert all(df[c].dtype == np.float64 for c in ("x", "y", "z", "B", "G", "R"))
+    np.testing.assert_array_equal(df.index.to_numpy(), v * 640 + u)          # labels of the filtered frame
+    with pytest.raises(ValueError):
+        prj.reverse_proj(sim[:100], scene["vert"], scene["ind"], p, off)          # frame size mismatch
+    # no offsets: coordinates stay offset-relative
+    from alproj_amd import synthetic as syn
+    df0 = prj.reverse_proj(sim, scene["vert"], scene["ind"], syn.local_params(p, off))
+    assert len(df0) == len(df) and (df0["x"] > 0).all()
+    np.testing.assert_allclose(df0["x"].to_numpy() + off[0], df["x"].to_numpy(), rtol=1e-12)
     with pytest.raises(ValueError):
         prj.reverse_proj(sim, scene["vert"], scene["ind"], p, off, chnames=["a", "b"])
 
