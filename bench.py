@@ -147,6 +147,13 @@ def main():
                   file=sys.stderr)
         sys.exit(2)
 
+    if ctl.local_rank == 0:                    # harness convenience: (re)build a missing/stale library
+        try:
+            from alproj_amd import _build
+            _build.build()
+        except Exception as e:                 # the product still fails loudly below if it is absent
+            print(f"bench.py: build skipped: {e}", file=sys.stderr)
+    ctl.barrier()
     from alproj_amd import _lib as L
     from alproj_amd import dist as adist
     from alproj_amd import synthetic as syn
