@@ -289,7 +289,10 @@ def main():
         out["raster"] = {"frame": f"{W}x{H}", "vertices": n_total, "triangles": n_tri,
                          "call": "persp_proj(vert, vert, ind, params, offsets) as used by reverse_proj"}
         for name, ind in variants:
+            if ind is not None:     # time the index-array kernel itself (a full regular grid would be recognised)
+                os.environ["ALP_NO_GRID_DETECT"] = "1"
             mesh = L.Mesh(surf["vert"], None, ind, grid=None if ind is not None else (n_side, n_side))
+            os.environ.pop("ALP_NO_GRID_DETECT", None)
             wall_r, dev_r = timed(ctl, L, lambda: mesh.render_enqueue(pv_cam, surf["offsets"]), k_r, 2)
             img = mesh.fetch()
             # algorithmic bytes per frame: vertices 12 B (value == vert), indices 12 B per
@@ -305,6 +308,30 @@ def main():
             }
             mesh.close()
             del img
+
+    # ---------------------------------------------------------------- GCP-scale optimiser (1 GPU)
+    # the reference's own problem size: 1127 GCPs, pop 50, D = 9, 300 generations, Huber f = 10
+    # (docs/usage.md:335, example.py:51-54); BASELINE.md measured 61.7 ms/generation for the
+    # reference's inner loop (without the sampler) in the survey container
+    if ctl.world == 1 and not args.no_cma:
+        import pandas as pd
+        from alproj_amd import optimize as aopt
+        tp = syn.truth_params(316)
+        gx = syn.gcp_points(1127, tp, seed=3)
+        with L.Points(gx, [tp["x"], tp["y"], tp["z"]], "f64") as gp:
+            gp.project(L.params_vector(tp))
+            gu, gv = gp.fetch()
+        guv = np.stack([gu, gv], 1) + np.random.default_rng(3).normal(0, 1.0, (1127, 2))
+        init = dict(tp, pan=tp["pan"] + 2, tilt=tp["tilt"] - 1.5, fov=tp["fov"] + 3, x=tp["x"] + 4)
+        o = aopt.CMAOptimizer(pd.DataFrame(gx, columns=["x", "y", "z"]), pd.DataFrame(guv, columns=["u", "v"]), init)
+        o.set_target(syn.TARGETS_D9)
+        t0 = time.perf_counter()
+        _, err = o.optimize(generation=300, sigma=1.0, population_size=50, f_scale=10.0, seed=7, progress=False)
+        dt = time.perf_counter() - t0
+        out["cma_gcp_scale"] = {"gcps": 1127, "population": 50, "dims": 9, "generations": 300,
+                                "ms_per_generation": dt / 300 * 1e3, "generations_per_s": 300 / dt,
+                                "final_mean_distance_px": err,
+                                "reference_ms_per_generation_survey_container": 61.7}
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1)
     if ctl.world == 1 and not args.no_cpu_baseline:

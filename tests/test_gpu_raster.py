@@ -60,8 +60,13 @@ def assert_vis_equal(got, ref):
                            f"{got[bad][0]:#x} vs {ref[bad][0]:#x}")
 
 
+@pytest.mark.parametrize("detect", [False, True], ids=["index_kernel", "grid_detected"])
 @pytest.mark.parametrize("name", list(POSES))
-def test_visibility_bit_exact(L, scene, name):
+def test_visibility_bit_exact(L, scene, name, detect, monkeypatch):
+    """the scene's index array is the full regular grid: with detection (default) the mesh is
+    rendered by the LDS-tiled grid kernel, without it by the per-triangle index kernel"""
+    if not detect:
+        monkeypatch.setenv("ALP_NO_GRID_DETECT", "1")
     p = pose(scene, name)
     ref = orast.visibility(scene["vert"], scene["ind"], p, scene["offsets"])
     with L.Mesh(scene["vert"], None, scene["ind"]) as m:
@@ -218,9 +223,20 @@ def test_dsm_10m_full_frame(L):
         vis = m.fetch_visibility()
     assert_vis_equal(vis, ref)
     assert (ref != 0).mean() > 0.5
-    with L.Mesh(s["vert"], None, syn.grid_indices(n, np.int32)) as m:
+    ind32 = syn.grid_indices(n, np.int32)
+    # the full regular grid is recognised at mesh creation and rendered by the grid kernel ...
+    with L.Mesh(s["vert"], None, ind32) as m:
         m.render_enqueue(pv, s["offsets"])
         assert_vis_equal(m.fetch_visibility(), vis)
+    # ... unless told not to: the per-triangle index kernel gives the same frame
+    import os
+    os.environ["ALP_NO_GRID_DETECT"] = "1"
+    try:
+        with L.Mesh(s["vert"], None, ind32) as m:
+            m.render_enqueue(pv, s["offsets"])
+            assert_vis_equal(m.fetch_visibility(), vis)
+    finally:
+        del os.environ["ALP_NO_GRID_DETECT"]
 
 
 def _mesh_case(L, vert, ind, p, offsets=None):
