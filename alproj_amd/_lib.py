@@ -73,6 +73,8 @@ _SIGNATURES = {
     "alp_render_fetch_visibility": [_c_void_p, ctypes.POINTER(ctypes.c_uint64)],
     "alp_render_valid_count": [_c_void_p, ctypes.POINTER(_c_i64)],
     "alp_render_fetch_valid": [_c_void_p, _c_dp, ctypes.POINTER(ctypes.c_uint32), _c_dp],
+    "alp_rasterize_points": [_c_dp, _c_dp, _c_dp, _c_i64, _c_i64, _c_double, _c_double, _c_double, _c_i64, _c_i64,
+                             _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_uint8)],
     "alp_distort_image": [_c_fp, _c_i64, _c_i64, _c_i64, _c_dp, _c_fp],
 }
 _RESTYPE = {"alp_last_error": ctypes.c_char_p}

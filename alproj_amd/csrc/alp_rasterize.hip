@@ -1,0 +1,214 @@
+// libalproj_hip.so -- compute part of to_geotiff(), src/alproj/project.py:376-503 (SURVEY.md
+// 8(f) row f2): reverse-projected points -> regular raster.
+//
+//   project.py:435-436  col = int((x - x_min) / res) clipped to [0, width-1],
+//                       row = int((y_max - y) / res) clipped to [0, height-1]
+//   project.py:450-459  per band: groupby (row, col), aggregate (mean / max / min; NaN values are
+//                       skipped like pandas does), store into a float32 raster, NaN elsewhere
+//   project.py:462-479  ceil(max_dist / res) sweeps: every NaN cell takes the NaN-aware
+//                       aggregate of its 3x3 neighbourhood of the PREVIOUS sweep (NaN outside
+//                       the raster); the reference does it with scipy.ndimage.generic_filter
+//                       and a Python lambda per pixel
+//   project.py:483-485  NaN -> nodata, clip to [0, 255], truncate to uint8
+// The GeoTIFF file itself (rasterio) stays on the host side of the ABI.
+//
+// Kernels: scatter (float64 atomics per band: sum+count, or ordered-integer max/min),
+// finalize (float32 raster), focal sweep (ping-pong), uint8 conversion.  The 3x3 mean adds its
+// window in numpy's order (pairwise block of 8, then the ninth) so that the float64 sum -- and
+// with it the float32 value and the truncated byte -- match the reference.
+#include "alp_internal.h"
+
+namespace alp {
+
+enum { AGG_MEAN = 0, AGG_MAX = 1, AGG_MIN = 2 };
+
+// order-preserving map double -> uint64 (so that integer atomicMax/Min order like the doubles)
+__device__ __forceinline__ unsigned long long d2ord(double d) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(d);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ord2d(unsigned long long o) {
+    const unsigned long long u = (o >> 63) ? (o & 0x7fffffffffffffffull) : ~o;
+    return __longlong_as_double((long long)u);
+}
+
+template <int AGG>
+__global__ __launch_bounds__(256) void rz_scatter_kernel(const double *__restrict__ x, const double *__restrict__ y,
+                                                         const double *__restrict__ values, long long n, int nb,
+                                                         double x_min, double y_max, double res, int width,
+                                                         int height, double *__restrict__ acc,
+                                                         unsigned *__restrict__ cnt) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long hw = (long long)width * height;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        long long col = (long long)((x[i] - x_min) / res);
+        long long row = (long long)((y_max - y[i]) / res);
+        col = col < 0 ? 0 : (col > width - 1 ? width - 1 : col);
+        row = row < 0 ? 0 : (row > height - 1 ? height - 1 : row);
+        const long long cell = row * width + col;
+        for (int b = 0; b < nb; ++b) {
+            const double val = values[i * nb + b];
+            if (val != val) continue;                          // pandas skips NaN
+            if constexpr (AGG == AGG_MEAN) {
+                atomicAdd(&acc[b * hw + cell], val);
+            } else if constexpr (AGG == AGG_MAX) {
+                atomicMax(reinterpret_cast<unsigned long long *>(&acc[b * hw + cell]), d2ord(val));
+            } else {
+                atomicMin(reinterpret_cast<unsigned long long *>(&acc[b * hw + cell]), d2ord(val));
+            }
+            atomicAdd(&cnt[b * hw + cell], 1u);
+        }
+    }
+}
+
+template <int AGG>
+__global__ __launch_bounds__(256) void rz_finalize_kernel(const double *__restrict__ acc, const unsigned *__restrict__ cnt,
+                                                          long long total, float *__restrict__ raster) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const unsigned c = cnt[i];
+        float r = __int_as_float(0x7fc00000);                 // NaN
+        if (c) {
+            if constexpr (AGG == AGG_MEAN) r = (float)(acc[i] / (double)c);
+            else r = (float)ord2d(reinterpret_cast<const unsigned long long *>(acc)[i]);
+        }
+        raster[i] = r;
+    }
+}
+
+// one sweep of the NaN-only 3x3 focal fill
+template <int AGG>
+__global__ __launch_bounds__(256) void rz_focal_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                       int nb, int width, int height) {
+    const long long hw = (long long)width * height;
+    const long long total = hw * nb;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const float centre = src[i];
+        if (centre == centre) { dst[i] = centre; continue; }
+        const long long p = i % hw;
+        const int row = (int)(p / width), col = (int)(p - (long long)row * width);
+        const float *band = src + (i - p);
+        double w[9];
+        int k = 0, have = 0;
+#pragma unroll
+        for (int dr = -1; dr <= 1; ++dr)
+#pragma unroll
+            for (int dc = -1; dc <= 1; ++dc, ++k) {
+                const int rr = row + dr, cc = col + dc;
+                float val = __int_as_float(0x7fc00000);
+                if (rr >= 0 && rr < height && cc >= 0 && cc < width) val = band[(long long)rr * width + cc];
+                const bool ok = val == val;
+                have += ok;
+                if constexpr (AGG == AGG_MEAN) w[k] = ok ? (double)val : 0.0;           // nansum: NaN -> 0
+                else if constexpr (AGG == AGG_MAX) w[k] = ok ? (double)val : -INFINITY;
+                else w[k] = ok ? (double)val : INFINITY;
+            }
+        float out = __int_as_float(0x7fc00000);
+        if (have) {
+            if constexpr (AGG == AGG_MEAN) {
+                // numpy's pairwise sum of 9 contiguous doubles: block of 8, then the rest
+                const double s = (((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]))) + w[8];
+                out = (float)(s / (double)have);
+            } else {
+                double m = w[0];
+#pragma unroll
+                for (int j = 1; j < 9; ++j) m = (AGG == AGG_MAX) ? fmax(m, w[j]) : fmin(m, w[j]);
+                out = (float)m;
+            }
+        }
+        dst[i] = out;
+    }
+}
+
+__global__ __launch_bounds__(256) void rz_to_u8_kernel(const float *__restrict__ raster, long long total, int nodata,
+                                                       unsigned char *__restrict__ out) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const float v = raster[i];
+        unsigned char o;
+        if (v != v) o = (unsigned char)nodata;
+        else o = (unsigned char)(v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v));      // clip, then truncate
+        out[i] = o;
+    }
+}
+
+template <int AGG>
+static int run_rasterize(const double *dx, const double *dy, const double *dv, long long n, int nb, double x_min,
+                         double y_max, double res, int width, int height, int sweeps, int nodata, double *acc,
+                         unsigned *cnt, float *ra, float *rb, unsigned char *out_dev) {
+    hipStream_t st = ctx().stream;
+    const long long total = (long long)width * height * nb;
+    const int cu = ctx().cu_count;
+    auto grid = [&](long long items) {
+        const long long want = (items + 255) / 256;
+        return (unsigned)(want < 1 ? 1 : (want < (long long)cu * 8 ? want : (long long)cu * 8));
+    };
+    if constexpr (AGG == AGG_MEAN) {
+        ALP_HIP(hipMemsetAsync(acc, 0, (size_t)total * sizeof(double), st));
+    } else {
+        // identity of max over the ordered keys is 0, of min all ones
+        ALP_HIP(hipMemsetAsync(acc, AGG == AGG_MAX ? 0x00 : 0xff, (size_t)total * sizeof(double), st));
+    }
+    ALP_HIP(hipMemsetAsync(cnt, 0, (size_t)total * sizeof(unsigned), st));
+    hipLaunchKernelGGL((rz_scatter_kernel<AGG>), dim3(grid(n)), dim3(256), 0, st, dx, dy, dv, n, nb, x_min, y_max, res,
+                       width, height, acc, cnt);
+    hipLaunchKernelGGL((rz_finalize_kernel<AGG>), dim3(grid(total)), dim3(256), 0, st, acc, cnt, total, ra);
+    float *cur = ra, *nxt = rb;
+    for (int s = 0; s < sweeps; ++s) {
+        hipLaunchKernelGGL((rz_focal_kernel<AGG>), dim3(grid(total)), dim3(256), 0, st, cur, nxt, nb, width, height);
+        float *t = cur; cur = nxt; nxt = t;
+    }
+    hipLaunchKernelGGL(rz_to_u8_kernel, dim3(grid(total)), dim3(256), 0, st, cur, total, nodata, out_dev);
+    ALP_HIP(hipGetLastError());
+    return ALP_OK;
+}
+
+}  // namespace alp
+
+using namespace alp;
+
+extern "C" int alp_rasterize_points(const double *x, const double *y, const double *values, int64_t n, int64_t nb,
+                                    double x_min, double y_max, double resolution, int64_t width, int64_t height,
+                                    int agg, int sweeps, int nodata, uint8_t *out) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(x && y && values && out, "NULL argument");
+    ALP_REQUIRE(n >= 1 && nb >= 1 && nb <= 64, "n or band count out of range");
+    ALP_REQUIRE(width >= 1 && height >= 1 && width * height <= ((int64_t)1 << 31), "raster size out of range");
+    ALP_REQUIRE(resolution > 0, "resolution must be positive");
+    ALP_REQUIRE(agg == ALP_AGG_MEAN || agg == ALP_AGG_MAX || agg == ALP_AGG_MIN, "agg must be ALP_AGG_MEAN, _MAX or _MIN");
+    ALP_REQUIRE(sweeps >= 0 && sweeps <= 4096, "sweeps out of range");
+    const size_t total = (size_t)width * height * nb;
+    const size_t pts_bytes = (size_t)n * sizeof(double);
+    char *dev = nullptr;
+    // x | y | values | acc (f64) | cnt (u32) | raster a | raster b | out (u8)
+    const size_t bytes = pts_bytes * (2 + nb) + total * (8 + 4 + 4 + 4 + 1) + 64;
+    ALP_HIP(hipMalloc((void **)&dev, bytes));
+    double *dx = (double *)dev, *dy = dx + n, *dv = dy + n;
+    double *acc = dv + (size_t)n * nb;
+    unsigned *cnt = (unsigned *)(acc + total);
+    float *ra = (float *)(cnt + total), *rb = ra + total;
+    unsigned char *out_dev = (unsigned char *)(rb + total);
+    hipStream_t st = ctx().stream;
+    hipError_t e = hipMemcpyAsync(dx, x, pts_bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(dy, y, pts_bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(dv, values, pts_bytes * nb, hipMemcpyHostToDevice, st);
+    int rc = ALP_OK;
+    if (e == hipSuccess) {
+        if (agg == ALP_AGG_MEAN)
+            rc = run_rasterize<AGG_MEAN>(dx, dy, dv, n, (int)nb, x_min, y_max, resolution, (int)width, (int)height, sweeps,
+                                         nodata, acc, cnt, ra, rb, out_dev);
+        else if (agg == ALP_AGG_MAX)
+            rc = run_rasterize<AGG_MAX>(dx, dy, dv, n, (int)nb, x_min, y_max, resolution, (int)width, (int)height, sweeps,
+                                        nodata, acc, cnt, ra, rb, out_dev);
+        else
+            rc = run_rasterize<AGG_MIN>(dx, dy, dv, n, (int)nb, x_min, y_max, resolution, (int)width, (int)height, sweeps,
+                                        nodata, acc, cnt, ra, rb, out_dev);
+    }
+    if (e == hipSuccess && rc == ALP_OK) e = hipMemcpyAsync(out, out_dev, total, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(dev);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(ALP_EHIP, "alp_rasterize_points: %s", hipGetErrorString(e));
+    return ALP_OK;
+}

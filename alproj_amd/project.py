@@ -12,10 +12,8 @@ here                          reference                               device ent
 ``persp_proj``                project.py:145-294                      alp_mesh_create + alp_render
 ``sim_image``                 project.py:296-325                      (persp_proj + uint8/BGR)
 ``reverse_proj``              project.py:327-374                      alp_render + alp_render_fetch_valid
+``rasterize``, ``to_geotiff`` project.py:376-503                      alp_rasterize_points (file: rasterio)
 ============================  ======================================  =====================
-
-``to_geotiff`` (project.py:376-503: rasterio I/O and scipy focal statistics) is outside the
-hot path and not provided.
 
 Extensions (keyword-only, defaults keep the reference behaviour): ``ind=None`` together with
 ``grid_shape=(rows, cols)`` renders the regular-grid mesh of ``get_colored_surface`` without
@@ -32,7 +30,7 @@ import pandas as pd
 from . import _lib
 
 __all__ = ["projection_mat", "modelview_mat", "distort", "persp_proj", "sim_image",
-           "reverse_proj", "Mesh"]
+           "reverse_proj", "rasterize", "to_geotiff", "Mesh"]
 
 Mesh = _lib.Mesh
 
@@ -136,3 +134,56 @@ def reverse_proj(array, vert, ind, params, offsets=None, chnames=["B", "G", "R"]
         data[name] = flat[idx, k].astype(np.float64)
     # the reference filters a RangeIndex-ed frame, so the labels are the linear pixel indices
     return pd.DataFrame(data, index=pd.Index(idx.astype(np.int64)))
+
+
+_AGG = {"mean": 0, "max": 1, "min": 2}
+
+
+def rasterize(df, resolution=1.0, bands=["R", "G", "B"], interpolate=True, max_dist=1.0, agg_func="mean",
+              nodata=255):
+    """The compute part of the reference's ``to_geotiff`` (project.py:414-485) on the device:
+    ``reverse_proj`` output -> ``(raster, bounds)`` with ``raster`` a (bands, height, width)
+    uint8 array and ``bounds = (x_min, y_min, x_max, y_max, width, height)``.
+
+    Same arguments and error messages as ``to_geotiff``.  ``agg_func="median"`` is accepted by
+    the reference but not implemented here (NotImplementedError).
+    """
+    for band in bands:
+        if band not in df.columns:
+            raise ValueError(f"Band '{band}' not found in DataFrame columns: {list(df.columns)}")
+    x = np.ascontiguousarray(df["x"].to_numpy(dtype=np.float64))
+    y = np.ascontiguousarray(df["y"].to_numpy(dtype=np.float64))
+    x_min, x_max, y_min, y_max = x.min(), x.max(), y.min(), y.max()
+    width = int(np.ceil((x_max - x_min) / resolution))
+    height = int(np.ceil((y_max - y_min) / resolution))
+    if width <= 0 or height <= 0:
+        raise ValueError(f"Invalid raster dimensions: width={width}, height={height}")
+    if agg_func not in ("mean", "median", "max", "min"):
+        raise ValueError(f"agg_func must be one of {['mean', 'median', 'max', 'min']}")
+    if agg_func == "median":
+        raise NotImplementedError("agg_func='median' is not implemented on the device yet")
+    values = np.ascontiguousarray(df[list(bands)].to_numpy(dtype=np.float64))
+    sweeps = int(np.ceil(max_dist / resolution)) if (interpolate and max_dist > 0) else 0
+    out = np.empty((len(bands), height, width), dtype=np.uint8)
+    _lib.check(_lib.lib().alp_rasterize_points(
+        _lib.as_dp(x), _lib.as_dp(y), _lib.as_dp(values), len(x), len(bands), float(x_min), float(y_max),
+        float(resolution), width, height, _AGG[agg_func], sweeps, int(nodata),
+        out.ctypes.data_as(_lib.ctypes.POINTER(_lib.ctypes.c_uint8))))
+    return out, (x_min, y_min, x_max, y_max, width, height)
+
+
+def to_geotiff(df, output_path, resolution=1.0, crs="EPSG:6690", bands=["R", "G", "B"], interpolate=True,
+               max_dist=1.0, agg_func="mean", nodata=255):
+    """Convert ``reverse_proj`` output to a GeoTIFF (reference project.py:376-503).  The raster
+    is computed on the device (``rasterize``); writing the file needs ``rasterio`` like the
+    reference does (ImportError otherwise -- use ``rasterize`` to get the arrays)."""
+    raster, (x_min, y_min, x_max, y_max, width, height) = rasterize(
+        df, resolution, bands, interpolate, max_dist, agg_func, nodata)
+    import rasterio
+    from rasterio.transform import from_bounds
+    transform = from_bounds(x_min, y_min, x_max, y_max, width, height)
+    with rasterio.open(output_path, "w", driver="GTiff", height=height, width=width, count=len(bands),
+                       dtype=np.uint8, crs=crs, transform=transform, nodata=nodata) as dst:
+        for band_idx in range(len(bands)):
+            dst.write(raster[band_idx], band_idx + 1)
+    print(f"GeoTIFF saved to {output_path} ({width}x{height} pixels, {len(bands)} bands, nodata={nodata})")

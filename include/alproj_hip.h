@@ -204,6 +204,19 @@ int alp_render_fetch_visibility(alp_mesh_t *mesh, uint64_t *out);
 int alp_render_valid_count(alp_mesh_t *mesh, int64_t *count);
 int alp_render_fetch_valid(alp_mesh_t *mesh, const double *offsets, uint32_t *idx_out, double *xyz_out);
 
+/* Compute part of to_geotiff(), src/alproj/project.py:376-503 (the GeoTIFF file itself is
+ * written by the caller): n points (x, y, values[n][nb]) -> uint8 raster out[nb][height][width].
+ * Pixel of a point: col = int((x - x_min) / resolution), row = int((y_max - y) / resolution),
+ * both clipped (:435-436); per band and pixel the aggregate `agg` of the points that fall in it,
+ * NaN values skipped (:450-459); then `sweeps` passes in which every empty pixel takes the
+ * NaN-aware aggregate of its 3x3 neighbourhood (:462-479; sweeps = ceil(max_dist / resolution),
+ * 0 = no interpolation); empty pixels -> nodata, others clipped to [0, 255] and truncated
+ * (:483-485).  The median of the reference's agg_func list is not implemented. */
+enum alp_agg { ALP_AGG_MEAN = 0, ALP_AGG_MAX = 1, ALP_AGG_MIN = 2 };
+int alp_rasterize_points(const double *x, const double *y, const double *values, int64_t n, int64_t nb,
+                         double x_min, double y_max, double resolution, int64_t width, int64_t height,
+                         int agg, int sweeps, int nodata, uint8_t *out);
+
 /* Image-space distortion remap alone: replaces distort(), src/alproj/project.py:111-143.
  * img/out: h x w x c float32 host images; coeffs: a1,a2,k1..k6,p1,p2,s1..s4. */
 int alp_distort_image(const float *img, int64_t h, int64_t w, int64_t c,

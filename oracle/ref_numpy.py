@@ -319,3 +319,57 @@ def conditioning(xyz, params):
     r2 = x * x + y * y
     den = params["k4"] * r2 + params["k5"] * r2 ** 2 + params["k6"] * r2 ** 3
     return float(depth_ratio), float(min(np.min(np.abs(1 + den)), np.min(np.abs(1 + params["a2"] + den))))
+
+
+# --------------------------------------------------------------------------------------
+# compute part of to_geotiff: rasterise + focal fill + uint8
+# --------------------------------------------------------------------------------------
+def rasterize_points(x, y, values, resolution=1.0, interpolate=True, max_dist=1.0, agg_func="mean",
+                     nodata=255):
+    """project.py:420-485 without the file I/O: extent and size (:420-425), pixel indices
+    (:435-436), per-band groupby aggregation into a float32 raster (:450-459), NaN-only 3x3
+    focal fill with the same aggregation, ceil(max_dist / resolution) sweeps (:462-479), uint8
+    conversion with `nodata` in the empty cells (:483-485).
+
+    x, y (n,), values (n, bands) -> (raster uint8 (bands, height, width),
+    (x_min, y_min, x_max, y_max, width, height)).  Pinned by tests/golden/g9_geotiff.npz.
+    """
+    import pandas as pd
+    from scipy.ndimage import generic_filter
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    values = np.asarray(values, dtype=np.float64)
+    x_min, x_max, y_min, y_max = x.min(), x.max(), y.min(), y.max()
+    width = int(np.ceil((x_max - x_min) / resolution))
+    height = int(np.ceil((y_max - y_min) / resolution))
+    if width <= 0 or height <= 0:
+        raise ValueError(f"Invalid raster dimensions: width={width}, height={height}")
+    funcs = {"mean": np.nanmean, "median": np.nanmedian, "max": np.nanmax, "min": np.nanmin}
+    if agg_func not in funcs:
+        raise ValueError(f"agg_func must be one of {list(funcs.keys())}")
+    func = funcs[agg_func]
+    col = ((x - x_min) / resolution).astype(int).clip(0, width - 1)
+    row = ((y_max - y) / resolution).astype(int).clip(0, height - 1)
+    nb = values.shape[1]
+    raster = np.full((nb, height, width), np.nan, dtype=np.float32)
+    frame = pd.DataFrame({"row": row, "col": col})
+    for b in range(nb):
+        frame["v"] = values[:, b]
+        g = frame.groupby(["row", "col"])["v"].agg(agg_func).reset_index()
+        raster[b, g["row"].values, g["col"].values] = g["v"].values
+    if interpolate and max_dist > 0:
+        sweeps = int(np.ceil(max_dist / resolution))
+        for b in range(nb):
+            for _ in range(sweeps):
+                band = raster[b]
+                mask = np.isnan(band)
+                if not mask.any():
+                    break
+                filled = generic_filter(band, lambda w: func(w) if not np.all(np.isnan(w)) else np.nan,
+                                        size=3, mode="constant", cval=np.nan)
+                band[mask] = filled[mask]
+                raster[b] = band
+    nan_mask = np.isnan(raster)
+    out = np.clip(np.nan_to_num(raster, nan=0), 0, 255).astype(np.uint8)
+    out[nan_mask] = nodata
+    return out, (x_min, y_min, x_max, y_max, width, height)

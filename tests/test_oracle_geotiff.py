@@ -1,0 +1,25 @@
+"""The oracle's restatement of to_geotiff's compute part against the rasters the reference
+itself handed to its GeoTIFF writer (tests/golden/gen_golden_geotiff.py).  CPU only."""
+import ast
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import ref_numpy as orc
+
+G = os.path.join(os.path.dirname(__file__), "golden", "g9_geotiff.npz")
+CASES = ["mean_int", "mean_float_res2", "max_nointerp", "min_sparse", "median_small"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_rasterize_matches_reference(name):
+    g = np.load(G, allow_pickle=False)
+    kw = ast.literal_eval(str(g[f"{name}_kw"]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")           # nanmean of all-NaN windows warns in the reference too
+        raster, bounds = orc.rasterize_points(g[f"{name}_x"], g[f"{name}_y"], g[f"{name}_vals"], **kw)
+    np.testing.assert_array_equal(raster, g[f"{name}_raster"])
+    assert (raster.shape[1], raster.shape[2]) == tuple(g[f"{name}_hw"])
+    np.testing.assert_array_equal(np.array(bounds[:4]), g[f"{name}_bounds"])
