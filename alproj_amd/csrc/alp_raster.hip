@@ -15,10 +15,16 @@
 //
 // Pipeline (all on the library stream):
 //   1. clear the 64-bit visibility buffer (one word per pixel: float32 1/vz << 32 | ~triangle id)
-//   2. raster_kernel: one thread per triangle: gather 3 vertices, view transform, near-plane
-//      clip, snap to 1/256 px, exact int64 edge functions; triangles covering at most
-//      SMALL_PIXELS pixel centres are finished in the thread (64-bit atomicMax per covered
-//      pixel), larger ones are split into 64x64-pixel work items appended to a queue
+//   2. coverage, one of
+//      raster_grid_kernel  regular-grid meshes (no index array, or an index array recognised
+//                          as the full grid at mesh creation): one workgroup per tile of 32x8
+//                          cells, vertices transformed/projected/snapped once into LDS, one
+//                          lane per cell = two triangles;
+//      raster_kernel       any index array: one thread per triangle, three gathered vertices;
+//      both end in emit_snapped(): 32-bit bounding-box rejection and back-face test, then an
+//      inline walk of the bounding box with exact integer edge functions (64-bit atomicMax per
+//      covered pixel centre) for triangles under 64 px; larger ones are split into 64x64-pixel
+//      work items appended to a device queue
 //   3. raster_large_kernel: one wave per work item, one lane per pixel column
 //   4. resolve_kernel: one thread per OUTPUT pixel: distortion source map (float64), fetch the
 //      winning triangle, perspective-correct interpolation by ray/triangle intersection in view

@@ -146,7 +146,6 @@ int main(int argc, char **argv) {
     };
     for (int grid : {2048, 16384}) {
         report("copy-shaped stream", grid, timeit([&] { copy32<<<grid, 256>>>(x, y, z, u, v, nvec); }));
-        report("current (project_kernel)", grid, timeit([&] { project_kernel<float><<<grid, 256>>>(x, y, z, u, v, nvec, pose); }));
         report("unroll1 nt", grid, timeit([&] { project_v<1, true><<<grid, 256>>>(x, y, z, u, v, nvec, pose); }));
         report("unroll2", grid, timeit([&] { project_v<2, false><<<grid, 256>>>(x, y, z, u, v, nvec, pose); }));
         report("unroll2 nt", grid, timeit([&] { project_v<2, true><<<grid, 256>>>(x, y, z, u, v, nvec, pose); }));
@@ -163,7 +162,7 @@ int main(int argc, char **argv) {
         RUNC(1, false, false, 128); RUNC(1, false, false, 64); RUNC(2, false, false, 64);
     }
     const int full = (int)((nvec + 255) / 256);
-    report("current, one vec per thread", full, timeit([&] { project_kernel<float><<<full, 256>>>(x, y, z, u, v, nvec, pose); }));
+    report("library project_kernel (one vec/lane, nt)", full, timeit([&] { project_kernel<float><<<full, 256>>>(x, y, z, u, v, nvec, pose); }));
     report("copy, one vec per thread", full, timeit([&] { copy32<<<full, 256>>>(x, y, z, u, v, nvec); }));
     return 0;
 }
