@@ -1,0 +1,89 @@
+"""Parity checks at BASELINE.json's FULL sizes (100 M-vertex DSM; configs 4 and 5) through
+size-independent properties and, where it is affordable, the oracle itself."""
+import numpy as np
+import pytest
+
+from oracle import raster as orast
+from oracle import ref_numpy as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from alproj_amd import _lib
+    _lib.init(0)
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def dsm():
+    from alproj_amd import synthetic as syn
+    n = syn.grid_side(100_000_000)
+    return n, syn.surface(n)
+
+
+def test_render_100m_bit_exact_and_idempotent(L, dsm):
+    """config 4: 100 M vertices / 200 M triangles onto 5616x3744.  The whole visibility buffer
+    equals the scalar C oracle's; a second render of the resident mesh reproduces it; a pose
+    with lens distortion only permutes/zeroes pixels of the undistorted frame."""
+    from alproj_amd import synthetic as syn
+    n, s = dsm
+    p = syn.base_params(n)
+    pv = L.params_vector(p)
+    with L.Mesh(s["vert"], None, None, grid=(n, n)) as m:
+        m.render_enqueue(pv, s["offsets"])
+        vis = m.fetch_visibility()
+        img = m.fetch()
+        m.render_enqueue(pv, s["offsets"])
+        np.testing.assert_array_equal(m.fetch_visibility(), vis)
+        pd_ = dict(p, k1=-0.05, k2=0.01, a1=1.02, a2=0.98, p1=1e-3, p2=-2e-3)
+        m.render_enqueue(L.params_vector(pd_), s["offsets"])
+        np.testing.assert_array_equal(m.fetch_visibility(), vis)        # the remap happens after visibility
+        dist = m.fetch()
+    ref = orast.visibility(s["vert"], None, p, s["offsets"], grid=(n, n))
+    bad = vis != ref
+    assert not bad.any(), f"{bad.sum()} pixels differ"
+    assert 0.5 < (vis != 0).mean() < 0.6
+    # remap = nearest gather of the undistorted frame (project.py:141)
+    mx, my = orc.distort_maps(int(p["w"]), int(p["h"]), [pd_[k] for k in orc.DIST_KEYS])
+    np.testing.assert_array_equal(dist, orc.remap_nearest(img, mx, my))
+
+
+def test_population_100m_shard_additivity(L, dsm):
+    """config 5: pop 2048, D = 21 on the 100 M-vertex DSM.  The mean loss over all vertices
+    equals the vertex-weighted mean of the losses of 8 row shards -- the identity behind the
+    one all-reduce per generation -- and the argmin is unchanged."""
+    from alproj_amd import dist as adist
+    from alproj_amd import synthetic as syn
+    n, s = dsm
+    xyz = syn.vert_to_xyz_local(s["vert"])
+    base = syn.local_params(syn.standoff_params(n), s["offsets"])
+    truth = syn.local_params(syn.perturbed(syn.standoff_params(n)), s["offsets"])
+    origin = [base["x"], base["y"], base["z"]]
+    rng = np.random.default_rng(3)
+    bounds = orc.bounds_to_array(base, syn.TARGETS_D21)
+    X = rng.uniform(0.45, 0.55, (2048, 21))
+    cand = np.tile(L.params_vector(base), (2048, 1))
+    cand[:, [L.PARAM_KEYS.index(t) for t in syn.TARGETS_D21]] = X * (bounds[:, 1] - bounds[:, 0]) + bounds[:, 0]
+    N = len(xyz)
+    with L.Points(xyz, origin, "f32") as pts:
+        pts.project(L.params_vector(truth))
+        u, v = pts.fetch(np.float32)
+        obs = np.stack([u, v], 1) + rng.normal(0, 1, (N, 2)).astype(np.float32)
+        pts.set_observed(obs)
+        whole, amin = pts.eval_population(cand, L.LOSS_HUBER, 10.0)
+        # a strided sample of the projection against the float64 oracle
+        su, sv = pts.fetch_strided(0, 99991, 1000)
+        ref = orc.project_points(xyz[0:99991 * 1000:99991].astype(np.float64), truth)
+        assert np.all(np.abs(np.stack([su, sv], 1) - ref) <= 1e-5 * np.maximum(np.abs(ref), truth["w"]))
+    acc = np.zeros(2048)
+    for r in range(8):
+        lo, hi = adist.shard_rows(n, r, 8)
+        with L.Points(xyz[lo * n:hi * n], origin, "f32") as part:
+            part.set_observed(obs[lo * n:hi * n])
+            l, _ = part.eval_population(cand, L.LOSS_HUBER, 10.0)
+            acc += l * ((hi - lo) * n)
+    np.testing.assert_allclose(acc / N, whole, rtol=2e-6)
+    assert int(np.argmin(acc)) == amin
+    assert np.isfinite(whole).all()
