@@ -164,6 +164,147 @@ static int run_rasterize(const double *dx, const double *dy, const double *dv, l
     return ALP_OK;
 }
 
+// ------------------------------------------------------------------ median
+// groupby median needs the values of every pixel in order: the points of one band are sorted
+// by value, then stably by pixel (two hipCUB radix sorts: a library sort, nothing to hand-tune),
+// and the middle element(s) of each pixel's run are averaged like numpy/pandas do.
+__global__ __launch_bounds__(256) void rz_median_keys_kernel(const double *__restrict__ x, const double *__restrict__ y,
+                                                             const double *__restrict__ values, long long n, int nb,
+                                                             int band, double x_min, double y_max, double res,
+                                                             int width, int height,
+                                                             unsigned long long *__restrict__ vkey,
+                                                             unsigned *__restrict__ idx, unsigned *__restrict__ cell) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        long long col = (long long)((x[i] - x_min) / res);
+        long long row = (long long)((y_max - y[i]) / res);
+        col = col < 0 ? 0 : (col > width - 1 ? width - 1 : col);
+        row = row < 0 ? 0 : (row > height - 1 ? height - 1 : row);
+        const double val = values[i * nb + band];
+        vkey[i] = d2ord(val);
+        idx[i] = (unsigned)i;
+        cell[i] = (val != val) ? 0xFFFFFFFFu : (unsigned)(row * width + col);      // NaN: sorts behind every pixel
+    }
+}
+
+__global__ __launch_bounds__(256) void rz_gather_cell_kernel(const unsigned *__restrict__ idx_sorted,
+                                                             const unsigned *__restrict__ cell, long long n,
+                                                             unsigned *__restrict__ cell_sorted) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        cell_sorted[i] = cell[idx_sorted[i]];
+}
+
+// runs of equal pixel in the (pixel, value)-sorted order -> median into the float32 raster
+__global__ __launch_bounds__(256) void rz_median_runs_kernel(const unsigned *__restrict__ cell_sorted,
+                                                             const unsigned *__restrict__ idx_sorted,
+                                                             const double *__restrict__ values, long long n, int nb,
+                                                             int band, float *__restrict__ raster_band) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const unsigned c = cell_sorted[i];
+        if (c == 0xFFFFFFFFu || (i > 0 && cell_sorted[i - 1] == c)) continue;      // not the head of a run
+        long long j = i + 1;
+        while (j < n && cell_sorted[j] == c) ++j;
+        const long long k = j - i;
+        const double a = values[(long long)idx_sorted[i + (k - 1) / 2] * nb + band];
+        const double b = values[(long long)idx_sorted[i + k / 2] * nb + band];
+        raster_band[c] = (float)((k & 1) ? a : (a + b) / 2);
+    }
+}
+
+__global__ __launch_bounds__(256) void rz_fill_nan_kernel(float *__restrict__ p, long long total) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
+        p[i] = __int_as_float(0x7fc00000);
+}
+
+__global__ __launch_bounds__(256) void rz_focal_median_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                              int nb, int width, int height) {
+    const long long hw = (long long)width * height;
+    const long long total = hw * nb;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const float centre = src[i];
+        if (centre == centre) { dst[i] = centre; continue; }
+        const long long p = i % hw;
+        const int row = (int)(p / width), col = (int)(p - (long long)row * width);
+        const float *band = src + (i - p);
+        float w[9];
+        int have = 0;
+        for (int dr = -1; dr <= 1; ++dr)
+            for (int dc = -1; dc <= 1; ++dc) {
+                const int rr = row + dr, cc = col + dc;
+                if (rr < 0 || rr >= height || cc < 0 || cc >= width) continue;
+                const float val = band[(long long)rr * width + cc];
+                if (val != val) continue;
+                int k = have++;                                   // insertion sort of at most 9 values
+                while (k > 0 && w[k - 1] > val) { w[k] = w[k - 1]; --k; }
+                w[k] = val;
+            }
+        float out = __int_as_float(0x7fc00000);
+        if (have) out = (have & 1) ? w[have / 2] : (float)(((double)w[have / 2 - 1] + (double)w[have / 2]) / 2);
+        dst[i] = out;
+    }
+}
+
+}  // namespace alp
+
+#include <hipcub/hipcub.hpp>
+
+namespace alp {
+
+static int run_rasterize_median(const double *dx, const double *dy, const double *dv, long long n, int nb, double x_min,
+                                double y_max, double res, int width, int height, int sweeps, int nodata, float *ra,
+                                float *rb, unsigned char *out_dev) {
+    hipStream_t st = ctx().stream;
+    const long long hw = (long long)width * height, total = hw * nb;
+    const int cu = ctx().cu_count;
+    auto grid = [&](long long items) {
+        const long long want = (items + 255) / 256;
+        return (unsigned)(want < 1 ? 1 : (want < (long long)cu * 8 ? want : (long long)cu * 8));
+    };
+    // scratch: value keys (2 x u64), point ids (2 x u32), pixel ids (3 x u32), hipCUB temporary storage
+    size_t tmp1 = 0, tmp2 = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, tmp1, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                       (unsigned *)nullptr, (unsigned *)nullptr, (int)n, 0, 64, st);
+    hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, (unsigned *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr,
+                                       (unsigned *)nullptr, (int)n, 0, 32, st);
+    const size_t tmp = tmp1 > tmp2 ? tmp1 : tmp2;
+    char *scratch = nullptr;
+    ALP_HIP(hipMalloc((void **)&scratch, (size_t)n * (16 + 8 + 12) + tmp + 256));
+    unsigned long long *vkey = (unsigned long long *)scratch, *vkey2 = vkey + n;
+    unsigned *idx = (unsigned *)(vkey2 + n), *idx2 = idx + n, *cell = idx2 + n, *cell_s = cell + n, *cell_s2 = cell_s + n;
+    void *cub_tmp = (void *)(((uintptr_t)(cell_s2 + n) + 255) & ~(uintptr_t)255);
+    hipLaunchKernelGGL(rz_fill_nan_kernel, dim3(grid(total)), dim3(256), 0, st, ra, total);
+    hipError_t e = hipSuccess;
+    for (int b = 0; b < nb && e == hipSuccess; ++b) {
+        hipLaunchKernelGGL(rz_median_keys_kernel, dim3(grid(n)), dim3(256), 0, st, dx, dy, dv, n, nb, b, x_min, y_max, res,
+                           width, height, vkey, idx, cell);
+        size_t t = tmp;
+        e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, t, vkey, vkey2, idx, idx2, (int)n, 0, 64, st);   // by value
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(rz_gather_cell_kernel, dim3(grid(n)), dim3(256), 0, st, idx2, cell, n, cell_s);
+        t = tmp;
+        e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, t, cell_s, cell_s2, idx2, idx, (int)n, 0, 32, st);   // stably by pixel
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(rz_median_runs_kernel, dim3(grid(n)), dim3(256), 0, st, cell_s2, idx, dv, n, nb, b, ra + b * hw);
+    }
+    float *cur = ra, *nxt = rb;
+    for (int s = 0; s < sweeps && e == hipSuccess; ++s) {
+        hipLaunchKernelGGL(rz_focal_median_kernel, dim3(grid(total)), dim3(256), 0, st, cur, nxt, nb, width, height);
+        float *t = cur; cur = nxt; nxt = t;
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rz_to_u8_kernel, dim3(grid(total)), dim3(256), 0, st, cur, total, nodata, out_dev);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);          // scratch is freed below
+    hipFree(scratch);
+    if (e != hipSuccess) return fail(ALP_EHIP, "median rasterisation: %s", hipGetErrorString(e));
+    return ALP_OK;
+}
+
 }  // namespace alp
 
 using namespace alp;
@@ -176,7 +317,9 @@ extern "C" int alp_rasterize_points(const double *x, const double *y, const doub
     ALP_REQUIRE(n >= 1 && nb >= 1 && nb <= 64, "n or band count out of range");
     ALP_REQUIRE(width >= 1 && height >= 1 && width * height <= ((int64_t)1 << 31), "raster size out of range");
     ALP_REQUIRE(resolution > 0, "resolution must be positive");
-    ALP_REQUIRE(agg == ALP_AGG_MEAN || agg == ALP_AGG_MAX || agg == ALP_AGG_MIN, "agg must be ALP_AGG_MEAN, _MAX or _MIN");
+    ALP_REQUIRE(agg == ALP_AGG_MEAN || agg == ALP_AGG_MAX || agg == ALP_AGG_MIN || agg == ALP_AGG_MEDIAN,
+                "agg must be ALP_AGG_MEAN, _MAX, _MIN or _MEDIAN");
+    ALP_REQUIRE(n < ((int64_t)1 << 31), "more than 2^31 points");
     ALP_REQUIRE(sweeps >= 0 && sweeps <= 4096, "sweeps out of range");
     const size_t total = (size_t)width * height * nb;
     const size_t pts_bytes = (size_t)n * sizeof(double);
@@ -201,9 +344,12 @@ extern "C" int alp_rasterize_points(const double *x, const double *y, const doub
         else if (agg == ALP_AGG_MAX)
             rc = run_rasterize<AGG_MAX>(dx, dy, dv, n, (int)nb, x_min, y_max, resolution, (int)width, (int)height, sweeps,
                                         nodata, acc, cnt, ra, rb, out_dev);
-        else
+        else if (agg == ALP_AGG_MIN)
             rc = run_rasterize<AGG_MIN>(dx, dy, dv, n, (int)nb, x_min, y_max, resolution, (int)width, (int)height, sweeps,
                                         nodata, acc, cnt, ra, rb, out_dev);
+        else
+            rc = run_rasterize_median(dx, dy, dv, n, (int)nb, x_min, y_max, resolution, (int)width, (int)height, sweeps,
+                                      nodata, ra, rb, out_dev);
     }
     if (e == hipSuccess && rc == ALP_OK) e = hipMemcpyAsync(out, out_dev, total, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);

@@ -136,7 +136,7 @@ def reverse_proj(array, vert, ind, params, offsets=None, chnames=["B", "G", "R"]
     return pd.DataFrame(data, index=pd.Index(idx.astype(np.int64)))
 
 
-_AGG = {"mean": 0, "max": 1, "min": 2}
+_AGG = {"mean": 0, "max": 1, "min": 2, "median": 3}
 
 
 def rasterize(df, resolution=1.0, bands=["R", "G", "B"], interpolate=True, max_dist=1.0, agg_func="mean",
@@ -145,8 +145,7 @@ def rasterize(df, resolution=1.0, bands=["R", "G", "B"], interpolate=True, max_d
     ``reverse_proj`` output -> ``(raster, bounds)`` with ``raster`` a (bands, height, width)
     uint8 array and ``bounds = (x_min, y_min, x_max, y_max, width, height)``.
 
-    Same arguments and error messages as ``to_geotiff``.  ``agg_func="median"`` is accepted by
-    the reference but not implemented here (NotImplementedError).
+    Same arguments and error messages as ``to_geotiff``.
     """
     for band in bands:
         if band not in df.columns:
@@ -158,10 +157,8 @@ def rasterize(df, resolution=1.0, bands=["R", "G", "B"], interpolate=True, max_d
     height = int(np.ceil((y_max - y_min) / resolution))
     if width <= 0 or height <= 0:
         raise ValueError(f"Invalid raster dimensions: width={width}, height={height}")
-    if agg_func not in ("mean", "median", "max", "min"):
+    if agg_func not in _AGG:
         raise ValueError(f"agg_func must be one of {['mean', 'median', 'max', 'min']}")
-    if agg_func == "median":
-        raise NotImplementedError("agg_func='median' is not implemented on the device yet")
     values = np.ascontiguousarray(df[list(bands)].to_numpy(dtype=np.float64))
     sweeps = int(np.ceil(max_dist / resolution)) if (interpolate and max_dist > 0) else 0
     out = np.empty((len(bands), height, width), dtype=np.uint8)

@@ -211,8 +211,8 @@ int alp_render_fetch_valid(alp_mesh_t *mesh, const double *offsets, uint32_t *id
  * NaN values skipped (:450-459); then `sweeps` passes in which every empty pixel takes the
  * NaN-aware aggregate of its 3x3 neighbourhood (:462-479; sweeps = ceil(max_dist / resolution),
  * 0 = no interpolation); empty pixels -> nodata, others clipped to [0, 255] and truncated
- * (:483-485).  The median of the reference's agg_func list is not implemented. */
-enum alp_agg { ALP_AGG_MEAN = 0, ALP_AGG_MAX = 1, ALP_AGG_MIN = 2 };
+ * (:483-485). */
+enum alp_agg { ALP_AGG_MEAN = 0, ALP_AGG_MAX = 1, ALP_AGG_MIN = 2, ALP_AGG_MEDIAN = 3 };
 int alp_rasterize_points(const double *x, const double *y, const double *values, int64_t n, int64_t nb,
                          double x_min, double y_max, double resolution, int64_t width, int64_t height,
                          int agg, int sweeps, int nodata, uint8_t *out);
