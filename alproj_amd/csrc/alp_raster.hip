@@ -37,6 +37,7 @@
 // see DESIGN.md "parity unpinned" -- the choices made are watertight and deterministic.
 #include "alp_internal.h"
 
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -106,6 +107,12 @@ static void make_view(const double *p, const double *offsets, View *v, RemapCoef
 }
 
 // ------------------------------------------------------------------ device helpers
+#ifdef ALP_RASTER_STATS     // development build: fragment / request census printed after every frame
+__device__ unsigned long long g_rstat[16];
+#define RSTAT(k, n) atomicAdd(&g_rstat[k], (unsigned long long)(n))
+#else
+#define RSTAT(k, n) ((void)0)
+#endif
 __device__ __forceinline__ void to_view(const View &v, float px, float py, float pz, float out[3]) {
     const float dx = (px - v.camf[0]) - v.caml[0];
     const float dy = (py - v.camf[1]) - v.caml[1];
@@ -360,56 +367,161 @@ __device__ __forceinline__ void load_view_tri(const View &v, const float *__rest
 #ifndef INLINE_LOG2
 #define INLINE_LOG2 14      // triangles below 2^INLINE_LOG2 / 256 px are finished inside the thread
 #endif
-__device__ __forceinline__ void emit_snapped(const View &v, const int X[3], const int Y[3], const float iw3[3],
-                                             long long t, int sub, unsigned long long *__restrict__ vis,
-                                             WorkItem *__restrict__ queue, unsigned *__restrict__ qcount,
-                                             unsigned qcap) {
-    // cheap rejection before the 64-bit set-up: bounding box without a pixel centre, or
-    // entirely outside the viewport
+#ifndef COOP_MIN_W
+#define COOP_MIN_W 4        // bounding boxes at least this many pixel columns wide go to coop_raster
+#endif
+#ifndef COOP_MIN_PIX
+#define COOP_MIN_PIX 16     // ... if they also hold at least this many pixel centres
+#endif
+
+// A triangle parked by emit_snapped for coop_raster (the whole wave rasterises it together).
+struct Deferred {
+    int X[3], Y[3];
+    float iw[3];
+    unsigned t;
+};
+
+// The inline walk of emit_snapped done by all 64 lanes of the wave on ONE triangle (arguments
+// wave-uniform): lane = one pixel of an 8x8 block (8 consecutive pixels of a row = one 64-byte
+// line of the visibility buffer), the blocks tile the bounding box.  A lane-per-triangle walk
+// sends every fragment as its own memory-side request; here the fragments of a row segment
+// leave in one.  Same integers and the same float32 depth expression as the inline walk.
+__device__ __forceinline__ void coop_raster(const View &v, const int X[3], const int Y[3], const float iw3[3],
+                                            unsigned t, unsigned long long *__restrict__ vis, int lane) {
+    const int minx = min(X[0], min(X[1], X[2])), maxx = max(X[0], max(X[1], X[2]));
+    const int miny = min(Y[0], min(Y[1], Y[2])), maxy = max(Y[0], max(Y[1], Y[2]));
+    const int ci0 = max((minx + SUB / 2 - 1) >> 8, 0), ci1 = min((maxx - SUB / 2) >> 8, v.w - 1);
+    const int cj0 = max((miny + SUB / 2 - 1) >> 8, 0), cj1 = min((maxy - SUB / 2) >> 8, v.h - 1);
+    const int area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (X[2] - X[0]) * (Y[1] - Y[0]);
+    int dx[3], dy[3], bias[3], xa[3], ya[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int a = (k + 1) % 3, b = (k + 2) % 3;
+        dx[k] = X[b] - X[a];
+        dy[k] = Y[b] - Y[a];
+        xa[k] = X[a];
+        ya[k] = Y[a];
+        bias[k] = (dy[k] < 0 || (dy[k] == 0 && dx[k] > 0)) ? 0 : 1;
+    }
+    const float inv_area = 1.0f / (float)area2;
+    const unsigned long long lo = (unsigned long long)(0xFFFFFFFFu - t);
+    const int lx = lane & 7, ly = lane >> 3;
+    for (int by = cj0; by <= cj1; by += 8)
+        for (int bx = ci0 & ~7; bx <= ci1; bx += 8) {
+            const int i = bx + lx, j = by + ly;
+            if (i < ci0 || i > ci1 || j > cj1) continue;
+            const int px = i * SUB + SUB / 2, py = j * SUB + SUB / 2;
+            const int w0 = dx[0] * (py - ya[0]) - dy[0] * (px - xa[0]) - bias[0];
+            const int w1 = dx[1] * (py - ya[1]) - dy[1] * (px - xa[1]) - bias[1];
+            const int w2 = dx[2] * (py - ya[2]) - dy[2] * (px - xa[2]) - bias[2];
+            if ((w0 | w1 | w2) >= 0) {
+                RSTAT(7, 1);
+                const float q = __builtin_fmaf((float)(w2 + bias[2]), iw3[2],
+                                               __builtin_fmaf((float)(w1 + bias[1]), iw3[1],
+                                                              (float)(w0 + bias[0]) * iw3[0])) * inv_area;
+                vis_max(vis, v, i, j, ((unsigned long long)__float_as_uint(q) << 32) | lo);
+            }
+        }
+}
+
+// Wave-converged: rasterise the parked triangles of all lanes, one after the other.
+__device__ __forceinline__ void coop_drain(const View &v, bool parked, const Deferred &d,
+                                           unsigned long long *__restrict__ vis) {
+    unsigned long long mask = __ballot(parked);
+    const int lane = (int)(threadIdx.x & 63);
+    while (mask) {
+        const int src = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        int X[3], Y[3];
+        float iw3[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            X[k] = __builtin_amdgcn_readlane(d.X[k], src);
+            Y[k] = __builtin_amdgcn_readlane(d.Y[k], src);
+            iw3[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d.iw[k]), src));
+        }
+        const unsigned t = (unsigned)__builtin_amdgcn_readlane((int)d.t, src);
+        if (lane == 0) RSTAT(8, 1);
+        coop_raster(v, X, Y, iw3, t, vis, lane);
+    }
+}
+
+enum { EMIT_DONE = 0, EMIT_PARKED = 1, EMIT_GENERAL = 2 };
+
+// One snapped window-space triangle, 32-bit part: bounding-box rejection, then -- for triangles
+// under 64 px -- back-face test and the inline walk (or parking for coop_raster if may_park).
+// Returns EMIT_GENERAL, having done nothing, for a larger triangle.
+__device__ __forceinline__ int emit_small(const View &v, const int X[3], const int Y[3], const float *iwsrc,
+                                          int n0, int n1, int n2, long long t, unsigned long long *__restrict__ vis,
+                                          Deferred *park, bool may_park) {
+    // bounding box without a pixel centre, or entirely outside the viewport
     const int minx = min(X[0], min(X[1], X[2])), maxx = max(X[0], max(X[1], X[2]));
     const int miny = min(Y[0], min(Y[1], Y[2])), maxy = max(Y[0], max(Y[1], Y[2]));
     const int i0 = (minx + SUB / 2 - 1) >> 8, i1 = (maxx - SUB / 2) >> 8;       // SUB == 256
     const int j0 = (miny + SUB / 2 - 1) >> 8, j1 = (maxy - SUB / 2) >> 8;
-    if (i0 > i1 || j0 > j1 || i1 < 0 || j1 < 0 || i0 > v.w - 1 || j0 > v.h - 1) return;
-    if (maxx - minx < (1 << INLINE_LOG2) && maxy - miny < (1 << INLINE_LOG2)) {
-        // triangle smaller than 64 px: every product of the set-up fits 32 bits when taken
-        // relative to the first pixel centre -- the same integers as the 64-bit path
-        const int area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (X[2] - X[0]) * (Y[1] - Y[0]);
-        if (area2 <= 0) return;
-        const int ci0 = max(i0, 0), ci1 = min(i1, v.w - 1), cj0 = max(j0, 0), cj1 = min(j1, v.h - 1);
-        const int px0 = ci0 * SUB + SUB / 2, py0 = cj0 * SUB + SUB / 2;
-        // the tie rule is folded into the stepped value: w = e - (edge owns its boundary ? 0 : 1),
-        // so "inside" is simply w0, w1, w2 >= 0 = sign bit of (w0 | w1 | w2)
-        int dx[3], dy[3], row[3], bias[3];
+    if (i0 > i1 || j0 > j1 || i1 < 0 || j1 < 0 || i0 > v.w - 1 || j0 > v.h - 1) return EMIT_DONE;
+    if (!(maxx - minx < (1 << INLINE_LOG2) && maxy - miny < (1 << INLINE_LOG2))) return EMIT_GENERAL;
+    // triangle smaller than 64 px: every product of the set-up fits 32 bits when taken
+    // relative to the first pixel centre -- the same integers as the 64-bit path
+    const int area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (X[2] - X[0]) * (Y[1] - Y[0]);
+    if (area2 <= 0) return EMIT_DONE;
+    const int ci0 = max(i0, 0), ci1 = min(i1, v.w - 1), cj0 = max(j0, 0), cj1 = min(j1, v.h - 1);
+    const float iw3[3] = {iwsrc[n0], iwsrc[n1], iwsrc[n2]};     // only now: most triangles never get here
+    if (may_park && ci1 - ci0 + 1 >= COOP_MIN_W && (ci1 - ci0 + 1) * (cj1 - cj0 + 1) >= COOP_MIN_PIX) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const int a = (k + 1) % 3, b = (k + 2) % 3;
-            dx[k] = X[b] - X[a];
-            dy[k] = Y[b] - Y[a];
-            bias[k] = (dy[k] < 0 || (dy[k] == 0 && dx[k] > 0)) ? 0 : 1;
-            row[k] = dx[k] * (py0 - Y[a]) - dy[k] * (px0 - X[a]) - bias[k];
+            park->X[k] = X[k];
+            park->Y[k] = Y[k];
+            park->iw[k] = iw3[k];
         }
-        const float inv_area = 1.0f / (float)area2;
-        const unsigned long long lo = (unsigned long long)(0xFFFFFFFFu - (unsigned)t);
-        for (int j = cj0; j <= cj1; ++j) {
-            int w0 = row[0], w1 = row[1], w2 = row[2];
-            for (int i = ci0; i <= ci1; ++i) {
-                if ((w0 | w1 | w2) >= 0) {
-                    const float q = __builtin_fmaf((float)(w2 + bias[2]), iw3[2],
-                                                   __builtin_fmaf((float)(w1 + bias[1]), iw3[1],
-                                                                  (float)(w0 + bias[0]) * iw3[0])) * inv_area;
-                    vis_max(vis, v, i, j, ((unsigned long long)__float_as_uint(q) << 32) | lo);
-                }
-                w0 -= dy[0] * SUB;
-                w1 -= dy[1] * SUB;
-                w2 -= dy[2] * SUB;
-            }
-            row[0] += dx[0] * SUB;
-            row[1] += dx[1] * SUB;
-            row[2] += dx[2] * SUB;
-        }
-        return;
+        park->t = (unsigned)t;
+        return EMIT_PARKED;
     }
+    const int px0 = ci0 * SUB + SUB / 2, py0 = cj0 * SUB + SUB / 2;
+    // the tie rule is folded into the stepped value: w = e - (edge owns its boundary ? 0 : 1),
+    // so "inside" is simply w0, w1, w2 >= 0 = sign bit of (w0 | w1 | w2)
+    int dx[3], dy[3], row[3], bias[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int a = (k + 1) % 3, b = (k + 2) % 3;
+        dx[k] = X[b] - X[a];
+        dy[k] = Y[b] - Y[a];
+        bias[k] = (dy[k] < 0 || (dy[k] == 0 && dx[k] > 0)) ? 0 : 1;
+        row[k] = dx[k] * (py0 - Y[a]) - dy[k] * (px0 - X[a]) - bias[k];
+    }
+    const float inv_area = 1.0f / (float)area2;
+    const unsigned long long lo = (unsigned long long)(0xFFFFFFFFu - (unsigned)t);
+    RSTAT(2, 1);
+    for (int j = cj0; j <= cj1; ++j) {
+        int w0 = row[0], w1 = row[1], w2 = row[2];
+        for (int i = ci0; i <= ci1; ++i) {
+            if ((w0 | w1 | w2) >= 0) {
+                RSTAT((ci1 - ci0) == 0 ? 3 : (ci1 - ci0) < 3 ? 4 : (ci1 - ci0) < 7 ? 5 : 6, 1);
+                const float q = __builtin_fmaf((float)(w2 + bias[2]), iw3[2],
+                                               __builtin_fmaf((float)(w1 + bias[1]), iw3[1],
+                                                              (float)(w0 + bias[0]) * iw3[0])) * inv_area;
+                vis_max(vis, v, i, j, ((unsigned long long)__float_as_uint(q) << 32) | lo);
+            }
+            w0 -= dy[0] * SUB;
+            w1 -= dy[1] * SUB;
+            w2 -= dy[2] * SUB;
+        }
+        row[0] += dx[0] * SUB;
+        row[1] += dx[1] * SUB;
+        row[2] += dx[2] * SUB;
+    }
+    return EMIT_DONE;
+}
+
+// One snapped window-space triangle of any size (all vertices in front of the near plane, inside
+// the fixed-point range): emit_small, else the 64-bit set-up and either the 64-bit inline walk
+// (<= SMALL_PIXELS centres) or 64x64-pixel work items for raster_large_kernel.  `sub` = index in
+// the clip fan.
+__device__ __forceinline__ void emit_snapped(const View &v, const int X[3], const int Y[3], const float iw3[3],
+                                             long long t, int sub, unsigned long long *__restrict__ vis,
+                                             WorkItem *__restrict__ queue, unsigned *__restrict__ qcount,
+                                             unsigned qcap) {
+    if (emit_small(v, X, Y, iw3, 0, 1, 2, t, vis, nullptr, false) != EMIT_GENERAL) return;
     const TriSetup s = setup_snapped(v, X, Y, iw3);
     if (!s.valid) return;
     const int bw = s.i1 - s.i0 + 1, bh = s.j1 - s.j0 + 1;
@@ -425,6 +537,28 @@ __device__ __forceinline__ void emit_snapped(const View &v, const int X[3], cons
     }
 }
 
+// The general path for one triangle given by its view-space vertices: near-plane clip, then
+// emit_snapped per fan triangle (or a whole-triangle work item beyond the fixed-point range).
+__device__ __forceinline__ void emit_general(const View &v, const float q[3][3], long long t,
+                                             unsigned long long *__restrict__ vis, WorkItem *__restrict__ queue,
+                                             unsigned *__restrict__ qcount, unsigned qcap) {
+    float xw[4], yw[4], iw[4];
+    bool big;
+    const int ntri = clip_project(v, q, xw, yw, iw, big);
+    if (ntri <= 0) return;
+    if (big) {                       // rare: hand the whole triangle to the large pass
+        const unsigned slot = atomicAdd(qcount, 1u);
+        if (slot < qcap) queue[slot] = WorkItem{(unsigned)t, 0xFFFF, 0, 0, 0};
+        return;
+    }
+    for (int f = 0; f < ntri; ++f) {
+        const int X[3] = {snap(xw[0]), snap(xw[f + 1]), snap(xw[f + 2])};
+        const int Y[3] = {snap(yw[0]), snap(yw[f + 1]), snap(yw[f + 2])};
+        const float i3[3] = {iw[0], iw[f + 1], iw[f + 2]};
+        emit_snapped(v, X, Y, i3, t, f, vis, queue, qcount, qcap);
+    }
+}
+
 // ------------------------------------------------------------------ kernel 2: per-triangle raster
 template <bool IMPLICIT>
 __global__ __launch_bounds__(256) void raster_kernel(const float *__restrict__ vert, const int *__restrict__ ind,
@@ -436,21 +570,28 @@ __global__ __launch_bounds__(256) void raster_kernel(const float *__restrict__ v
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n_tri; t += stride) {
         float q[3][3];
         load_view_tri<IMPLICIT>(v, vert, ind, gw, t, q);
-        float xw[4], yw[4], iw[4];
-        bool big;
-        const int ntri = clip_project(v, q, xw, yw, iw, big);
-        if (ntri <= 0) continue;
-        if (big) {                       // rare: hand the whole triangle to the large pass
-            const unsigned slot = atomicAdd(qcount, 1u);
-            if (slot < qcap) queue[slot] = WorkItem{(unsigned)t, 0xFFFF, 0, 0, 0};
-            continue;
-        }
-        for (int f = 0; f < ntri; ++f) {
-            const int X[3] = {snap(xw[0]), snap(xw[f + 1]), snap(xw[f + 2])};
-            const int Y[3] = {snap(yw[0]), snap(yw[f + 1]), snap(yw[f + 2])};
-            const float i3[3] = {iw[0], iw[f + 1], iw[f + 2]};
-            emit_snapped(v, X, Y, i3, t, f, vis, queue, qcount, qcap);
-        }
+        emit_general(v, q, t, vis, queue, qcount, qcap);
+    }
+}
+
+// The triangles raster_grid_kernel set aside (near-plane crossings, 64 px and more): one thread
+// per entry of the general queue, the same path as raster_kernel.  The entry count is read on
+// the device, so no host round trip separates the passes.
+template <bool IMPLICIT>
+__global__ __launch_bounds__(256) void raster_general_kernel(const float *__restrict__ vert,
+                                                             const int *__restrict__ ind, long long gw, View v,
+                                                             unsigned long long *__restrict__ vis,
+                                                             const unsigned *__restrict__ gqueue,
+                                                             const unsigned *__restrict__ gcount, unsigned gcap,
+                                                             WorkItem *__restrict__ queue,
+                                                             unsigned *__restrict__ qcount, unsigned qcap) {
+    const unsigned n = min(*gcount, gcap);
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned it = blockIdx.x * blockDim.x + threadIdx.x; it < n; it += stride) {
+        const long long t = gqueue[it];
+        float q[3][3];
+        load_view_tri<IMPLICIT>(v, vert, ind, gw, t, q);
+        emit_general(v, q, t, vis, queue, qcount, qcap);
     }
 }
 
@@ -463,75 +604,82 @@ __global__ __launch_bounds__(256) void raster_kernel(const float *__restrict__ v
 // the same clip_project path as raster_kernel.  Same arithmetic, same results.
 constexpr int GT_W = 32, GT_H = 8, GT_VW = GT_W + 1, GT_VH = GT_H + 1, GT_NV = GT_VW * GT_VH;
 
-__global__ __launch_bounds__(256) void raster_grid_kernel(const float *__restrict__ vert, int gh, int gw, View v,
-                                                          unsigned long long *__restrict__ vis,
-                                                          WorkItem *__restrict__ queue, unsigned *__restrict__ qcount,
-                                                          unsigned qcap) {
-    __shared__ float s_q[3][GT_NV];       // view-space coordinates
-    __shared__ int s_X[GT_NV], s_Y[GT_NV];
+#ifndef GRID_WAVES_PER_EU
+#define GRID_WAVES_PER_EU 8
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRID_WAVES_PER_EU)))
+void raster_grid_kernel(const float *__restrict__ vert, int gh, int gw, View v, unsigned long long *__restrict__ vis,
+                        unsigned *__restrict__ gqueue, unsigned *__restrict__ gcount, unsigned gcap,
+                        int lanes_along_rows) {
+    // s_xy[].x of a vertex without window coordinates: behind the near plane / outside the fixed-point range
+    constexpr int BEHIND = INT_MIN, RANGE = INT_MIN + 1;
+    __shared__ int2 s_xy[GT_NV];          // snapped window coordinates
     __shared__ float s_iw[GT_NV];
-    __shared__ unsigned char s_flag[GT_NV];   // 1 = in front of the near plane and inside the fixed-point range
     const int tiles_x = (gw - 1 + GT_W - 1) / GT_W;
     const int tile_r = blockIdx.x / tiles_x, tile_c = blockIdx.x - tile_r * tiles_x;
     const int r0 = tile_r * GT_H, c0 = tile_c * GT_W;
     for (int idx = threadIdx.x; idx < GT_NV; idx += 256) {
         const int lr = idx / GT_VW, lc = idx - lr * GT_VW;
         const int r = r0 + lr, c = c0 + lc;
-        unsigned char flag = 0;
+        int2 xy = make_int2(BEHIND, 0);
         if (r < gh && c < gw) {
             const float *p = vert + 3 * ((long long)r * gw + c);
             float q[3];
             to_view(v, p[0], p[1], p[2], q);
-            s_q[0][idx] = q[0]; s_q[1][idx] = q[1]; s_q[2][idx] = q[2];
             if (q[2] >= 1.0f) {
                 float xw, yw, iw;
                 to_window(v, q, xw, yw, iw);
+                xy.x = RANGE;
                 if (fabsf(xw) < COORD_LIMIT && fabsf(yw) < COORD_LIMIT) {
-                    s_X[idx] = snap(xw);
-                    s_Y[idx] = snap(yw);
+                    xy = make_int2(snap(xw), snap(yw));
                     s_iw[idx] = iw;
-                    flag = 1;
                 }
             }
         }
-        s_flag[idx] = flag;
+        s_xy[idx] = xy;
     }
     __syncthreads();
-    const int lr = threadIdx.x / GT_W, lc = threadIdx.x - lr * GT_W;
+    // Phase 2: one wave = 8 x 8 cells; consecutive lanes take cells along the grid axis that runs
+    // ACROSS the view, so that their fragments fall on neighbouring pixels of one row and the
+    // atomics of one instruction share 64-byte lines (the memory side serves one request per
+    // instruction and line).
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    const int lr = lanes_along_rows ? (lane & 7) : (lane >> 3);
+    const int lc = wave * 8 + (lanes_along_rows ? (lane >> 3) : (lane & 7));
     const int r = r0 + lr, c = c0 + lc;
-    if (r >= gh - 1 || c >= gw - 1) return;
     const int ia = lr * GT_VW + lc, ib = ia + GT_VW, ic = ib + 1, id = ia + 1;
     const long long cell = (long long)r * (gw - 1) + c;
+    const int2 P[4] = {s_xy[ia], s_xy[ib], s_xy[ic], s_xy[id]};
+    bool work = r < gh - 1 && c < gw - 1;
+    if (work && P[0].x > RANGE && P[1].x > RANGE && P[2].x > RANGE && P[3].x > RANGE) {
+        // the cell's bounding box holds no pixel centre of the viewport: neither can its triangles
+        const int minx = min(min(P[0].x, P[1].x), min(P[2].x, P[3].x)), maxx = max(max(P[0].x, P[1].x), max(P[2].x, P[3].x));
+        const int miny = min(min(P[0].y, P[1].y), min(P[2].y, P[3].y)), maxy = max(max(P[0].y, P[1].y), max(P[2].y, P[3].y));
+        const int i0 = (minx + SUB / 2 - 1) >> 8, i1 = (maxx - SUB / 2) >> 8;
+        const int j0 = (miny + SUB / 2 - 1) >> 8, j1 = (maxy - SUB / 2) >> 8;
+        if (i0 > i1 || j0 > j1 || i1 < 0 || j1 < 0 || i0 > v.w - 1 || j0 > v.h - 1) work = false;
+    }
     // triangles of the cell (surface.py:194-201): (a, b, c) and (a, c, d)
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        const int k0 = ia, k1 = half ? ic : ib, k2 = half ? id : ic;
+        const int k1 = half ? ic : ib, k2 = half ? id : ic;
+        const int2 A = P[0], B = half ? P[2] : P[1], C = half ? P[3] : P[2];
         const long long t = 2 * cell + half;
-        if (s_flag[k0] & s_flag[k1] & s_flag[k2]) {
-            const int X[3] = {s_X[k0], s_X[k1], s_X[k2]}, Y[3] = {s_Y[k0], s_Y[k1], s_Y[k2]};
-            const float iw3[3] = {s_iw[k0], s_iw[k1], s_iw[k2]};
-            emit_snapped(v, X, Y, iw3, t, 0, vis, queue, qcount, qcap);
-        } else {
-            // near-plane crossing, behind the camera or out of range: the general path
-            const float q[3][3] = {{s_q[0][k0], s_q[1][k0], s_q[2][k0]},
-                                   {s_q[0][k1], s_q[1][k1], s_q[2][k1]},
-                                   {s_q[0][k2], s_q[1][k2], s_q[2][k2]}};
-            float xw[4], yw[4], iw[4];
-            bool big;
-            const int ntri = clip_project(v, q, xw, yw, iw, big);
-            if (ntri <= 0) continue;
-            if (big) {
-                const unsigned slot = atomicAdd(qcount, 1u);
-                if (slot < qcap) queue[slot] = WorkItem{(unsigned)t, 0xFFFF, 0, 0, 0};
-                continue;
+        Deferred park;
+        int code = EMIT_DONE;
+        if (work) {
+            if (A.x > RANGE && B.x > RANGE && C.x > RANGE) {
+                const int X[3] = {A.x, B.x, C.x}, Y[3] = {A.y, B.y, C.y};
+                code = emit_small(v, X, Y, s_iw, ia, k1, k2, t, vis, &park, true);
+            } else if (!(A.x == BEHIND && B.x == BEHIND && C.x == BEHIND)) {
+                code = EMIT_GENERAL;      // near-plane crossing or out of range (all three behind: nothing to draw)
             }
-            for (int f = 0; f < ntri; ++f) {
-                const int X[3] = {snap(xw[0]), snap(xw[f + 1]), snap(xw[f + 2])};
-                const int Y[3] = {snap(yw[0]), snap(yw[f + 1]), snap(yw[f + 2])};
-                const float i3[3] = {iw[0], iw[f + 1], iw[f + 2]};
-                emit_snapped(v, X, Y, i3, t, f, vis, queue, qcount, qcap);
+            if (code == EMIT_GENERAL) {   // rare: raster_general_kernel redoes this triangle from its vertices
+                const unsigned slot = atomicAdd(gcount, 1u);
+                if (slot < gcap) gqueue[slot] = (unsigned)t;
             }
         }
+        coop_drain(v, code == EMIT_PARKED, park, vis);      // every lane of the wave arrives here
     }
 }
 
@@ -541,7 +689,9 @@ template <bool IMPLICIT>
 __global__ __launch_bounds__(256) void raster_large_kernel(const float *__restrict__ vert,
                                                            const int *__restrict__ ind, long long gw, View v,
                                                            unsigned long long *__restrict__ vis,
-                                                           const WorkItem *__restrict__ queue, unsigned count) {
+                                                           const WorkItem *__restrict__ queue,
+                                                           const unsigned *__restrict__ qcount, unsigned qcap) {
+    const unsigned count = min(*qcount, qcap);
     const int lane = threadIdx.x & 63;
     const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -779,8 +929,14 @@ struct alp_mesh {
     float *image = nullptr;
     WorkItem *queue = nullptr;
     unsigned qcap = 0;
-    unsigned *qcount_dev = nullptr;
-    unsigned *qcount_host = nullptr;   // pinned
+    unsigned *gqueue = nullptr;        // general queue: triangle ids set aside by raster_grid_kernel
+    unsigned gcap = 0;
+    unsigned *qcount_dev = nullptr;    // [0] work items, [1] general-queue entries
+    unsigned *qcount_host = nullptr;   // pinned copy of the two counters of the last frame
+    bool unchecked = false;            // last frame enqueued, its queue counters not yet checked (finish_frame)
+    View last_v;
+    RemapCoef last_rc;
+    double last_min_distance = 0;
     bool rendered = false;
     // reverse_proj compaction scratch
     unsigned *compact_counts = nullptr;
@@ -823,42 +979,47 @@ int ensure_queue(alp_mesh *m, unsigned cap) {
     return ALP_OK;
 }
 
+int ensure_gqueue(alp_mesh *m, unsigned cap) {
+    if (m->gqueue && m->gcap >= cap) return ALP_OK;
+    if (m->gqueue) hipFree(m->gqueue);
+    m->gqueue = nullptr;
+    ALP_HIP(hipMalloc((void **)&m->gqueue, (size_t)cap * sizeof(unsigned)));
+    m->gcap = cap;
+    return ALP_OK;
+}
+
+// Enqueue one whole frame on the library stream, no host round trip: clear, raster passes (the
+// queue lengths stay on the device), resolve.  The two queue counters are copied to pinned host
+// memory at the end; finish_frame() checks them before anything reads the frame.
 template <bool IMPLICIT>
 int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_distance) {
     hipStream_t st = ctx().stream;
     const int cu = ctx().cu_count;
     ALP_HIP(hipMemsetAsync(m->vis, 0, (size_t)v.w * v.h * sizeof(unsigned long long), st));
     if (m->n_tri > 0) {
-        const long long want = (m->n_tri + 255) / 256;
-        const int grid = (int)(want < (long long)cu * 16 ? want : (long long)cu * 16);
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            ALP_HIP(hipMemsetAsync(m->qcount_dev, 0, sizeof(unsigned), st));
-            if constexpr (IMPLICIT) {
-                const long long tiles = ((m->grid_w - 1 + GT_W - 1) / GT_W) * ((m->grid_h - 1 + GT_H - 1) / GT_H);
-                hipLaunchKernelGGL(raster_grid_kernel, dim3((unsigned)tiles), dim3(256), 0, st, m->vert,
-                                   (int)m->grid_h, (int)m->grid_w, v, m->vis, m->queue, m->qcount_dev, m->qcap);
-            } else {
-                hipLaunchKernelGGL((raster_kernel<IMPLICIT>), dim3(grid), dim3(256), 0, st, m->vert, m->ind,
-                                   (long long)m->n_tri, (long long)m->grid_w, v, m->vis, m->queue, m->qcount_dev,
-                                   m->qcap);
-            }
+        ALP_HIP(hipMemsetAsync(m->qcount_dev, 0, 2 * sizeof(unsigned), st));
+        if constexpr (IMPLICIT) {
+            const long long tiles = ((m->grid_w - 1 + GT_W - 1) / GT_W) * ((m->grid_h - 1 + GT_H - 1) / GT_H);
+            // vertices are X, Z, Y: columns step X (R[0][0] on screen x), rows step Y (R[0][2])
+            int along_rows = std::fabs(v.R[0][2]) > std::fabs(v.R[0][0]);
+            if (const char *e = getenv("ALP_GRID_LANES")) along_rows = e[0] == 'r';   // development override
+            hipLaunchKernelGGL(raster_grid_kernel, dim3((unsigned)tiles), dim3(256), 0, st, m->vert, (int)m->grid_h,
+                               (int)m->grid_w, v, m->vis, m->gqueue, m->qcount_dev + 1, m->gcap, along_rows);
             ALP_HIP(hipGetLastError());
-            ALP_HIP(hipMemcpyAsync(m->qcount_host, m->qcount_dev, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-            ALP_HIP(hipStreamSynchronize(st));
-            if (*m->qcount_host <= m->qcap) break;
-            // the queue was too small: the small triangles are already in (max is idempotent);
-            // grow it and redo the pass so that every large work item is recorded
-            if (int e = ensure_queue(m, *m->qcount_host + 1024)) return e;
+            hipLaunchKernelGGL((raster_general_kernel<IMPLICIT>), dim3(cu * 2), dim3(256), 0, st, m->vert, m->ind,
+                               (long long)m->grid_w, v, m->vis, m->gqueue, m->qcount_dev + 1, m->gcap, m->queue,
+                               m->qcount_dev, m->qcap);
+        } else {
+            const long long want = (m->n_tri + 255) / 256;
+            const int grid = (int)(want < (long long)cu * 16 ? want : (long long)cu * 16);
+            hipLaunchKernelGGL((raster_kernel<IMPLICIT>), dim3(grid), dim3(256), 0, st, m->vert, m->ind,
+                               (long long)m->n_tri, (long long)m->grid_w, v, m->vis, m->queue, m->qcount_dev, m->qcap);
         }
-        const unsigned count = *m->qcount_host;
-        if (count > 0) {
-            const unsigned waves = count;
-            const unsigned blocks = (waves + 3) / 4;
-            const unsigned g = blocks < (unsigned)cu * 8 ? blocks : (unsigned)cu * 8;
-            hipLaunchKernelGGL((raster_large_kernel<IMPLICIT>), dim3(g), dim3(256), 0, st, m->vert, m->ind,
-                               (long long)m->grid_w, v, m->vis, m->queue, count);
-            ALP_HIP(hipGetLastError());
-        }
+        ALP_HIP(hipGetLastError());
+        hipLaunchKernelGGL((raster_large_kernel<IMPLICIT>), dim3(cu * 8), dim3(256), 0, st, m->vert, m->ind,
+                           (long long)m->grid_w, v, m->vis, m->queue, m->qcount_dev, m->qcap);
+        ALP_HIP(hipGetLastError());
+        ALP_HIP(hipMemcpyAsync(m->qcount_host, m->qcount_dev, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     }
     const long long npix = (long long)v.w * v.h;
     const long long want = (npix + 255) / 256;
@@ -866,7 +1027,41 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
     hipLaunchKernelGGL((resolve_kernel<IMPLICIT>), dim3(grid), dim3(256), 0, st, m->vert, m->value, m->ind,
                        (long long)m->grid_w, v, rc, min_distance, m->vis, m->image);
     ALP_HIP(hipGetLastError());
+    m->last_v = v;
+    m->last_rc = rc;
+    m->last_min_distance = min_distance;
+    m->unchecked = m->n_tri > 0;
+#ifdef ALP_RASTER_STATS
+    {
+        unsigned long long hs[16], zero[16] = {0};
+        ALP_HIP(hipStreamSynchronize(st));
+        ALP_HIP(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_rstat), sizeof(hs)));
+        ALP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rstat), zero, sizeof(zero)));
+        fprintf(stderr, "[raster stats] inline tris %llu | inline fragments by bbox width: 1px %llu, 2-3 %llu, 4-7 %llu, "
+                        ">=8 %llu | coop tris %llu fragments %llu\n", hs[2], hs[3], hs[4], hs[5], hs[6], hs[8], hs[7]);
+    }
+#endif
     m->rendered = true;
+    return ALP_OK;
+}
+
+// Before anything reads the last frame: wait for it and make sure neither queue overflowed.  A
+// queue that was too small is grown and the frame rendered again (max is idempotent, but the
+// dropped entries were never drawn).
+int finish_frame(alp_mesh *m) {
+    while (m->unchecked) {
+        ALP_HIP(hipStreamSynchronize(ctx().stream));
+        m->unchecked = false;
+        const unsigned items = m->qcount_host[0], general = m->qcount_host[1];
+        if (items <= m->qcap && general <= m->gcap) break;
+        if (items > m->qcap)
+            if (int e = ensure_queue(m, items + items / 4 + 1024)) return e;
+        if (general > m->gcap)
+            if (int e = ensure_gqueue(m, general + general / 4 + 1024)) return e;
+        if (int e = m->implicit ? render_impl<true>(m, m->last_v, m->last_rc, m->last_min_distance)
+                                : render_impl<false>(m, m->last_v, m->last_rc, m->last_min_distance))
+            return e;
+    }
     return ALP_OK;
 }
 
@@ -934,10 +1129,11 @@ int alp_mesh_create(const float *vert, const float *value, int64_t n_vert, const
             if (rc) return bail(rc);
         }
     }
-    if (hipMalloc((void **)&m->qcount_dev, sizeof(unsigned)) != hipSuccess ||
-        hipHostMalloc((void **)&m->qcount_host, sizeof(unsigned), hipHostMallocDefault) != hipSuccess)
+    if (hipMalloc((void **)&m->qcount_dev, 2 * sizeof(unsigned)) != hipSuccess ||
+        hipHostMalloc((void **)&m->qcount_host, 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess)
         return bail(fail(ALP_EHIP, "hipMalloc queue counter"));
     if ((rc = ensure_queue(m, 1u << 20))) return bail(rc);
+    if ((rc = ensure_gqueue(m, 1u << 20))) return bail(rc);
     // The index array the reference builds (surface.py:194-201) is the full regular grid unless
     // nodata triangles were filtered out: recognise it, drop the 12 B/triangle array and use the
     // LDS-tiled grid kernel (same triangle ids, same result, no index traffic).
@@ -975,7 +1171,7 @@ int alp_mesh_destroy(alp_mesh_t *m) {
     if (!m) return ALP_OK;
     if (ctx().ready) hipStreamSynchronize(ctx().stream);
     for (void *p : {(void *)m->vert, (void *)m->value, (void *)m->ind, (void *)m->vis, (void *)m->image,
-                    (void *)m->queue, (void *)m->qcount_dev, (void *)m->compact_counts, (void *)m->compact_offsets})
+                    (void *)m->queue, (void *)m->gqueue, (void *)m->qcount_dev, (void *)m->compact_counts, (void *)m->compact_offsets})
         if (p) hipFree(p);
     if (m->qcount_host) hipHostFree(m->qcount_host);
     delete m;
@@ -998,6 +1194,7 @@ int alp_render_fetch(alp_mesh_t *m, float *out) {
     if (int rc = require_init()) return rc;
     ALP_REQUIRE(m && out, "NULL argument");
     if (!m->rendered) return fail(ALP_ESTATE, "alp_render_fetch: nothing rendered yet");
+    if (int e = finish_frame(m)) return e;
     ALP_HIP(hipMemcpyAsync(out, m->image, (size_t)m->w * m->h * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx().stream));
     ALP_HIP(hipStreamSynchronize(ctx().stream));
     return ALP_OK;
@@ -1007,6 +1204,7 @@ int alp_render_fetch_visibility(alp_mesh_t *m, uint64_t *out) {
     if (int rc = require_init()) return rc;
     ALP_REQUIRE(m && out, "NULL argument");
     if (!m->rendered) return fail(ALP_ESTATE, "alp_render_fetch_visibility: nothing rendered yet");
+    if (int e = finish_frame(m)) return e;
     ALP_HIP(hipMemcpyAsync(out, m->vis, (size_t)m->w * m->h * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx().stream));
     ALP_HIP(hipStreamSynchronize(ctx().stream));
     return ALP_OK;
@@ -1016,6 +1214,7 @@ int alp_render_valid_count(alp_mesh_t *m, int64_t *count) {
     if (int rc = require_init()) return rc;
     ALP_REQUIRE(m && count, "NULL argument");
     if (!m->rendered) return fail(ALP_ESTATE, "alp_render_valid_count: nothing rendered yet");
+    if (int e = finish_frame(m)) return e;
     const long long npix = (long long)m->w * m->h;
     const int chunks = (int)((npix + COMPACT_CHUNK - 1) / COMPACT_CHUNK);
     if (chunks > m->compact_cap) {
