@@ -560,17 +560,49 @@ __device__ __forceinline__ void emit_general(const View &v, const float q[3][3],
 }
 
 // ------------------------------------------------------------------ kernel 2: per-triangle raster
+// One thread per triangle, three gathered vertices.  Like raster_grid_kernel it finishes only the
+// common case itself (all vertices in front and in range, under 64 px) and sets the rest aside
+// for raster_general_kernel.
 template <bool IMPLICIT>
 __global__ __launch_bounds__(256) void raster_kernel(const float *__restrict__ vert, const int *__restrict__ ind,
                                                      long long n_tri, long long gw, View v,
                                                      unsigned long long *__restrict__ vis,
-                                                     WorkItem *__restrict__ queue, unsigned *__restrict__ qcount,
-                                                     unsigned qcap) {
+                                                     unsigned *__restrict__ gqueue, unsigned *__restrict__ gcount,
+                                                     unsigned gcap) {
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n_tri; t += stride) {
-        float q[3][3];
-        load_view_tri<IMPLICIT>(v, vert, ind, gw, t, q);
-        emit_general(v, q, t, vis, queue, qcount, qcap);
+    const long long rounds = (n_tri + stride - 1) / stride;       // every lane makes every round: coop_drain is wave-wide
+    for (long long k = 0; k < rounds; ++k) {
+        const long long t = k * stride + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        Deferred park;
+        int code = EMIT_DONE;
+        if (t < n_tri) {
+            float q[3][3];
+            load_view_tri<IMPLICIT>(v, vert, ind, gw, t, q);
+            const bool in0 = q[0][2] >= 1.0f, in1 = q[1][2] >= 1.0f, in2 = q[2][2] >= 1.0f;
+            if (in0 && in1 && in2) {
+                float xw[3], yw[3], iw[3];
+                bool ok = true;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    to_window(v, q[c], xw[c], yw[c], iw[c]);
+                    ok = ok && fabsf(xw[c]) < COORD_LIMIT && fabsf(yw[c]) < COORD_LIMIT;
+                }
+                if (ok) {
+                    const int X[3] = {snap(xw[0]), snap(xw[1]), snap(xw[2])};
+                    const int Y[3] = {snap(yw[0]), snap(yw[1]), snap(yw[2])};
+                    code = emit_small(v, X, Y, iw, 0, 1, 2, t, vis, &park, true);
+                } else {
+                    code = EMIT_GENERAL;
+                }
+            } else if (in0 || in1 || in2) {
+                code = EMIT_GENERAL;
+            }
+            if (code == EMIT_GENERAL) {
+                const unsigned slot = atomicAdd(gcount, 1u);
+                if (slot < gcap) gqueue[slot] = (unsigned)t;
+            }
+        }
+        coop_drain(v, code == EMIT_PARKED, park, vis);
     }
 }
 
@@ -1005,16 +1037,17 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
             if (const char *e = getenv("ALP_GRID_LANES")) along_rows = e[0] == 'r';   // development override
             hipLaunchKernelGGL(raster_grid_kernel, dim3((unsigned)tiles), dim3(256), 0, st, m->vert, (int)m->grid_h,
                                (int)m->grid_w, v, m->vis, m->gqueue, m->qcount_dev + 1, m->gcap, along_rows);
-            ALP_HIP(hipGetLastError());
-            hipLaunchKernelGGL((raster_general_kernel<IMPLICIT>), dim3(cu * 2), dim3(256), 0, st, m->vert, m->ind,
-                               (long long)m->grid_w, v, m->vis, m->gqueue, m->qcount_dev + 1, m->gcap, m->queue,
-                               m->qcount_dev, m->qcap);
         } else {
             const long long want = (m->n_tri + 255) / 256;
             const int grid = (int)(want < (long long)cu * 16 ? want : (long long)cu * 16);
             hipLaunchKernelGGL((raster_kernel<IMPLICIT>), dim3(grid), dim3(256), 0, st, m->vert, m->ind,
-                               (long long)m->n_tri, (long long)m->grid_w, v, m->vis, m->queue, m->qcount_dev, m->qcap);
+                               (long long)m->n_tri, (long long)m->grid_w, v, m->vis, m->gqueue, m->qcount_dev + 1,
+                               m->gcap);
         }
+        ALP_HIP(hipGetLastError());
+        hipLaunchKernelGGL((raster_general_kernel<IMPLICIT>), dim3(cu * 2), dim3(256), 0, st, m->vert, m->ind,
+                           (long long)m->grid_w, v, m->vis, m->gqueue, m->qcount_dev + 1, m->gcap, m->queue,
+                           m->qcount_dev, m->qcap);
         ALP_HIP(hipGetLastError());
         hipLaunchKernelGGL((raster_large_kernel<IMPLICIT>), dim3(cu * 8), dim3(256), 0, st, m->vert, m->ind,
                            (long long)m->grid_w, v, m->vis, m->queue, m->qcount_dev, m->qcap);
