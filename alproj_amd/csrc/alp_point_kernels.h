@@ -222,7 +222,16 @@ template <typename T> struct PopCfg;
 //   V=4 TC=128 8 wg/CU 736          | V=8 TC=128 6 wg/CU 744 | V=16 TC=256 2 wg/CU 549
 // The bare arithmetic of group_losses (no LDS, no reduction; tools/eval_rate.hip) runs at
 // 780-880 Gevals/s: ~50 VALU instructions of which 4 are quarter-rate v_rcp/v_sqrt.
-template <> struct PopCfg<float> : PopCfgT<float, 4, 128, 2> {};
+// Reading the records with scalar loads straight from global memory (s_load_dwordx16, SGPR
+// operands, no LDS tile) measured 709-718 against 732 Gevals/s for the LDS tile, V=8 on top of
+// it 679.
+#ifndef POP_V
+#define POP_V 4
+#endif
+#ifndef POP_MINW
+#define POP_MINW 2
+#endif
+template <> struct PopCfg<float> : PopCfgT<float, POP_V, 128, POP_MINW> {};
 template <> struct PopCfg<double> : PopCfgT<double, 2, 128, 1> {};
 
 // Sum of the losses of V points against one pose record r (wave-uniform).  uoc/voc are the
@@ -409,10 +418,11 @@ __global__ __launch_bounds__(256, Cfg::MINW) void popeval_kernel(
         }
         __syncthreads();
         int64_t base = beg;
+        const PoseRec<T> *recs = s_c;
         for (; base + 256 * V <= end; base += 256 * V)
-            pop_group<T, LOSS, V, false, SHARED_POSE>(x, y, z, uo, vo, base, end, s_c, s_sum[wave], tc, f_scale, half_f2);
+            pop_group<T, LOSS, V, false, SHARED_POSE>(x, y, z, uo, vo, base, end, recs, s_sum[wave], tc, f_scale, half_f2);
         for (; base < end; base += 256)
-            pop_group<T, LOSS, 1, true, SHARED_POSE>(x, y, z, uo, vo, base, end, s_c, s_sum[wave], tc, f_scale, half_f2);
+            pop_group<T, LOSS, 1, true, SHARED_POSE>(x, y, z, uo, vo, base, end, recs, s_sum[wave], tc, f_scale, half_f2);
         __syncthreads();
         if (tid < tc)
             partials[(int64_t)blockIdx.x * P + c0 + tid] =
