@@ -73,6 +73,8 @@ _SIGNATURES = {
     "alp_render_fetch_visibility": [_c_void_p, ctypes.POINTER(ctypes.c_uint64)],
     "alp_render_valid_count": [_c_void_p, ctypes.POINTER(_c_i64)],
     "alp_render_fetch_valid": [_c_void_p, _c_dp, ctypes.POINTER(ctypes.c_uint32), _c_dp],
+    "alp_render_gather": [_c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), _c_i64, _c_dp,
+                          _c_dp],
     "alp_rasterize_points": [_c_dp, _c_dp, _c_dp, _c_i64, _c_i64, _c_double, _c_double, _c_double, _c_i64, _c_i64,
                              _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_uint8)],
     "alp_distort_image": [_c_fp, _c_i64, _c_i64, _c_i64, _c_dp, _c_fp],
@@ -331,6 +333,20 @@ class Mesh:
         check(self._lib.alp_render_fetch_valid(self._h, None if off is None else as_dp(off),
                                                idx.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), as_dp(xyz)))
         return idx, xyz
+
+    def gather(self, u, v, offsets=None):
+        """After a render of the vertices themselves: (n, 3) float64 x, y, z seen by the pixels
+        (u[i], v[i]); NaN outside the image or where no surface is seen."""
+        u = np.ascontiguousarray(u, dtype=np.int32)
+        v = np.ascontiguousarray(v, dtype=np.int32)
+        if u.shape != v.shape or u.ndim != 1:
+            raise ValueError("u and v must be 1-D arrays of the same length")
+        xyz = np.empty((len(u), 3), dtype=np.float64)
+        off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.float64)
+        ip = ctypes.POINTER(ctypes.c_int32)
+        check(self._lib.alp_render_gather(self._h, u.ctypes.data_as(ip), v.ctypes.data_as(ip), len(u),
+                                          None if off is None else as_dp(off), as_dp(xyz)))
+        return xyz
 
 
 def distort_image(img, coeffs):

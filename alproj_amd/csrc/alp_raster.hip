@@ -851,6 +851,31 @@ __global__ __launch_bounds__(256) void distort_image_kernel(const float *__restr
 // offsets, pass 2 writes (order-preserving stream compaction).
 constexpr int COMPACT_CHUNK = 4096;
 
+// set_gcp (src/alproj/gcp.py:644-648) against the resident coordinate image instead of a merge
+// with the reverse_proj table: pixel (u[i], v[i]) -> x, y, z = channels (0, 2, 1) + offsets,
+// NaN where the pixel is outside the image or does not see the surface (x <= 0, project.py:369)
+__global__ __launch_bounds__(256) void gather_pixels_kernel(const float *__restrict__ image, int w, int h,
+                                                            const int *__restrict__ u, const int *__restrict__ v,
+                                                            long long n, double o0, double o1, double o2,
+                                                            double *__restrict__ xyz) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double nan = __builtin_nan("");
+    double x = nan, y = nan, z = nan;
+    const int uu = u[i], vv = v[i];
+    if (uu >= 0 && uu < w && vv >= 0 && vv < h) {
+        const float *px = image + 3 * ((long long)vv * w + uu);
+        if (px[0] > 0.0f) {
+            x = (double)px[0] + o0;
+            y = (double)px[2] + o2;
+            z = (double)px[1] + o1;
+        }
+    }
+    xyz[3 * i + 0] = x;
+    xyz[3 * i + 1] = y;
+    xyz[3 * i + 2] = z;
+}
+
 __global__ __launch_bounds__(256) void valid_count_kernel(const float *__restrict__ img, long long npix,
                                                           unsigned *__restrict__ counts) {
     __shared__ unsigned s[4];
@@ -1240,6 +1265,36 @@ int alp_render_fetch_visibility(alp_mesh_t *m, uint64_t *out) {
     if (int e = finish_frame(m)) return e;
     ALP_HIP(hipMemcpyAsync(out, m->vis, (size_t)m->w * m->h * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx().stream));
     ALP_HIP(hipStreamSynchronize(ctx().stream));
+    return ALP_OK;
+}
+
+int alp_render_gather(alp_mesh_t *m, const int32_t *u, const int32_t *v, int64_t n, const double *offsets,
+                      double *xyz_out) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(m, "mesh handle is NULL");
+    ALP_REQUIRE(n >= 0, "n is negative");
+    if (!m->rendered) return fail(ALP_ESTATE, "alp_render_gather: nothing rendered yet");
+    if (int e = finish_frame(m)) return e;
+    if (n == 0) return ALP_OK;
+    ALP_REQUIRE(u && v && xyz_out, "NULL argument");
+    char *dev = nullptr;
+    const size_t uv_bytes = (size_t)n * sizeof(int32_t), xyz_bytes = (size_t)n * 3 * sizeof(double);
+    ALP_HIP(hipMalloc((void **)&dev, xyz_bytes + 2 * uv_bytes));
+    double *xyz_dev = (double *)dev;
+    int32_t *u_dev = (int32_t *)(dev + xyz_bytes), *v_dev = u_dev + n;
+    hipStream_t st = ctx().stream;
+    const double o0 = offsets ? offsets[0] : 0.0, o1 = offsets ? offsets[1] : 0.0, o2 = offsets ? offsets[2] : 0.0;
+    hipError_t e = hipMemcpyAsync(u_dev, u, uv_bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(v_dev, v, uv_bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(gather_pixels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m->image, m->w,
+                           m->h, u_dev, v_dev, n, o0, o1, o2, xyz_dev);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(xyz_out, xyz_dev, xyz_bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(dev);
+    if (e != hipSuccess) return fail(ALP_EHIP, "alp_render_gather: %s", hipGetErrorString(e));
     return ALP_OK;
 }
 

@@ -12,6 +12,7 @@ here                          reference                               device ent
 ``persp_proj``                project.py:145-294                      alp_mesh_create + alp_render
 ``sim_image``                 project.py:296-325                      (persp_proj + uint8/BGR)
 ``reverse_proj``              project.py:327-374                      alp_render + alp_render_fetch_valid
+``reverse_proj_device``       project.py:360 (result kept in HBM)     alp_render_enqueue, alp_render_gather
 ``rasterize``, ``to_geotiff`` project.py:376-503                      alp_rasterize_points (file: rasterio)
 ============================  ======================================  =====================
 
@@ -30,7 +31,7 @@ import pandas as pd
 from . import _lib
 
 __all__ = ["projection_mat", "modelview_mat", "distort", "persp_proj", "sim_image",
-           "reverse_proj", "rasterize", "to_geotiff", "Mesh"]
+           "reverse_proj", "reverse_proj_device", "ReverseProjection", "rasterize", "to_geotiff", "Mesh"]
 
 Mesh = _lib.Mesh
 
@@ -106,6 +107,70 @@ def sim_image(vert, color, ind, params, offsets=None, min_distance=None, *, grid
     return np.ascontiguousarray(raw[:, :, ::-1])          # cv2.COLOR_RGB2BGR
 
 
+class ReverseProjection:
+    """The coordinate image of ``reverse_proj`` kept on the device (SURVEY section 8(f), rows f2 and
+    f4): ``to_frame`` builds the reference's DataFrame, ``lookup`` answers ``set_gcp`` for a few
+    thousand pixels without ever materialising the ~10 M-row table."""
+
+    def __init__(self, mesh, offsets, w, h, owns_mesh):
+        self.mesh, self.offsets, self.w, self.h, self._owns = mesh, offsets, int(w), int(h), owns_mesh
+
+    def lookup(self, u, v):
+        """(n, 3) float64 x, y, z seen at the pixels (u, v) of the simulated image; NaN where the
+        pixel is outside the image, not integral, or does not see the surface."""
+        u = np.asarray(u, dtype=np.float64)
+        v = np.asarray(v, dtype=np.float64)
+        whole = (u == np.round(u)) & (v == np.round(v)) & (np.abs(u) < 2**31) & (np.abs(v) < 2**31)
+        ui = np.where(whole, u, -1).astype(np.int32)
+        vi = np.where(whole, v, -1).astype(np.int32)
+        return self.mesh.gather(ui, vi, self.offsets)
+
+    def to_frame(self, array, chnames=["B", "G", "R"]):
+        """The DataFrame of the reference's ``reverse_proj`` (project.py:361-374)."""
+        array = np.asarray(array)
+        if array.shape[2] != len(chnames):
+            raise ValueError("The array has {} channels but chnames has length of {}. Please set chnames correctly."
+                             .format(array.shape[2], len(chnames)))
+        if array.shape[0] != self.h or array.shape[1] != self.w:
+            raise ValueError("all the input array dimensions except for the concatenation axis must match exactly "
+                             f"(array is {array.shape[:2]}, the camera image {(self.h, self.w)})")
+        # the x > 0 selection (:369), the x,z,y -> x,y,z reorder (:361) and the offsets (:370-373)
+        # happen on the device; only the surviving pixels travel back
+        idx, xyz = self.mesh.fetch_valid(self.offsets)
+        w = self.w
+        data = {"u": (idx % w).astype("int16"), "v": (idx // w).astype("int16"),
+                "x": xyz[:, 0], "y": xyz[:, 1], "z": xyz[:, 2]}
+        flat = array.reshape(-1, array.shape[2])
+        for k, name in enumerate(chnames):
+            data[name] = flat[idx, k].astype(np.float64)
+        # the reference filters a RangeIndex-ed frame, so the labels are the linear pixel indices
+        return pd.DataFrame(data, index=pd.Index(idx.astype(np.int64)))
+
+    def close(self):
+        if self._owns and self.mesh is not None:
+            self.mesh.close()
+        self.mesh = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def reverse_proj_device(vert, ind, params, offsets=None, *, grid_shape=None):
+    """The render half of ``reverse_proj`` (project.py:360): coordinates of the surface seen by
+    every pixel, left on the device as a ``ReverseProjection``."""
+    pvec = _params_checked(params)
+    h, w = int(params["h"]), int(params["w"])
+    if isinstance(vert, _lib.Mesh):
+        mesh, owns = vert, False
+    else:
+        mesh, owns = _lib.Mesh(np.asarray(vert), None, ind, grid_shape), True
+    mesh.render_enqueue(pvec, offsets, None)
+    return ReverseProjection(mesh, offsets, w, h, owns)
+
+
 def reverse_proj(array, vert, ind, params, offsets=None, chnames=["B", "G", "R"], *, grid_shape=None):
     """Reverse projection (geo-rectification) of an (h, w, channels) array onto the surface
     (reference project.py:327-374): a DataFrame with u, v, x, y, z and the channels, one row
@@ -113,27 +178,12 @@ def reverse_proj(array, vert, ind, params, offsets=None, chnames=["B", "G", "R"]
     if array.shape[2] != len(chnames):
         raise ValueError("The array has {} channels but chnames has length of {}. Please set chnames correctly."
                          .format(array.shape[2], len(chnames)))
-    pvec = _params_checked(params)
     h, w = int(params["h"]), int(params["w"])
     if array.shape[0] != h or array.shape[1] != w:
         raise ValueError("all the input array dimensions except for the concatenation axis must match exactly "
                          f"(array is {array.shape[:2]}, the camera image {(h, w)})")
-    # the render, the x > 0 selection (:369), the x,z,y -> x,y,z reorder (:361) and the offsets
-    # (:370-373) happen on the device; only the surviving pixels travel back
-    if isinstance(vert, _lib.Mesh):
-        vert.render_enqueue(pvec, offsets, None)
-        idx, xyz = vert.fetch_valid(offsets)
-    else:
-        with _lib.Mesh(np.asarray(vert), None, ind, grid_shape) as mesh:
-            mesh.render_enqueue(pvec, offsets, None)
-            idx, xyz = mesh.fetch_valid(offsets)
-    data = {"u": (idx % w).astype("int16"), "v": (idx // w).astype("int16"),
-            "x": xyz[:, 0], "y": xyz[:, 1], "z": xyz[:, 2]}
-    flat = np.asarray(array).reshape(-1, array.shape[2])
-    for k, name in enumerate(chnames):
-        data[name] = flat[idx, k].astype(np.float64)
-    # the reference filters a RangeIndex-ed frame, so the labels are the linear pixel indices
-    return pd.DataFrame(data, index=pd.Index(idx.astype(np.int64)))
+    with reverse_proj_device(vert, ind, params, offsets, grid_shape=grid_shape) as rp:
+        return rp.to_frame(array, chnames)
 
 
 _AGG = {"mean": 0, "max": 1, "min": 2, "median": 3}

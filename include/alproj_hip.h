@@ -204,6 +204,13 @@ int alp_render_fetch_visibility(alp_mesh_t *mesh, uint64_t *out);
 int alp_render_valid_count(alp_mesh_t *mesh, int64_t *count);
 int alp_render_fetch_valid(alp_mesh_t *mesh, const double *offsets, uint32_t *idx_out, double *xyz_out);
 
+/* set_gcp(), src/alproj/gcp.py:644-648, without the reverse_proj table: for n pixels (u[i], v[i])
+ * of the last render (values = the vertices themselves) write xyz_out[i] = (x, y, z) as
+ * alp_render_fetch_valid defines them, or NaN where the pixel lies outside the image or does
+ * not see the surface (the rows the reference's left join + dropna removes). */
+int alp_render_gather(alp_mesh_t *mesh, const int32_t *u, const int32_t *v, int64_t n,
+                      const double *offsets, double *xyz_out);
+
 /* Compute part of to_geotiff(), src/alproj/project.py:376-503 (the GeoTIFF file itself is
  * written by the caller): n points (x, y, values[n][nb]) -> uint8 raster out[nb][height][width].
  * Pixel of a point: col = int((x - x_min) / resolution), row = int((y_max - y) / resolution),

@@ -152,6 +152,40 @@ def test_reverse_proj_and_sim_image(L, scene):
         prj.reverse_proj(sim, scene["vert"], scene["ind"], p, off, chnames=["a", "b"])
 
 
+def test_set_gcp_on_the_device_equals_the_table_join(L, scene):
+    """set_gcp against the resident coordinate image (alp_render_gather) gives
+    the rows, labels and values of the reference's merge with the reverse_proj table"""
+    import pandas as pd
+    from alproj_amd import project as prj
+    from alproj_amd.gcp import filter_gcp_distance, set_gcp
+    p = pose(scene, "base")
+    off = scene["offsets"]
+    rng = np.random.default_rng(5)
+    n = 2000
+    match = pd.DataFrame({"u_org": rng.integers(0, 5616, n), "v_org": rng.integers(0, 3744, n),
+                          "u_sim": rng.integers(-3, 643, n), "v_sim": rng.integers(-3, 430, n)})
+    dummy = np.zeros((427, 640, 1), np.uint8)
+    with prj.reverse_proj_device(scene["vert"], scene["ind"], p, off) as rp:
+        got = set_gcp(match, rp)
+        frame = rp.to_frame(dummy, ["c"])
+        gotf = set_gcp(match.astype(np.float64), rp)
+        half = match.astype(np.float64)
+        half["u_sim"] += 0.5                      # not a pixel: no row survives
+        assert len(set_gcp(half, rp)) == 0
+        assert len(set_gcp(match.iloc[:0], rp)) == 0
+    exp = set_gcp(match, frame)
+    assert 0 < len(exp) < n
+    assert list(got.columns) == ["u", "v", "x", "y", "z"]
+    np.testing.assert_array_equal(got.index.to_numpy(), exp.index.to_numpy())
+    np.testing.assert_array_equal(got.to_numpy(dtype=np.float64), exp.to_numpy(dtype=np.float64))
+    np.testing.assert_array_equal(gotf.to_numpy(dtype=np.float64), exp.to_numpy(dtype=np.float64))
+    dall = np.sqrt((got["x"] - p["x"]) ** 2 + (got["y"] - p["y"]) ** 2 + (got["z"] - p["z"]) ** 2)
+    cut = float(np.median(dall))
+    near = filter_gcp_distance(got, p, max_distance=cut)
+    assert len(near) == int((dall <= cut).sum()) and 0 < len(near) < len(got)
+    assert list(near.index) == list(range(len(near)))
+
+
 def test_reverse_proj_hits_the_surface(L, scene):
     """geometry check independent of the oracle: a pixel's reverse-projected world point must
     project back onto that pixel through the GL camera model"""
