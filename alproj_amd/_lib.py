@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ALPROJ_HIP_LIB", os.path.join(_HERE, "libalproj_hip.so"))   # override: dev ablation builds
 
-ALP_F32, ALP_F64, ALP_I32, ALP_I64 = 0, 1, 2, 3
+ALP_F32, ALP_F64, ALP_I32, ALP_I64, ALP_U8, ALP_U16 = 0, 1, 2, 3, 4, 5
 LOSS_MEAN_DIST, LOSS_HUBER = 0, 1
 NPARAM = 25
 UNIQUE_ID_BYTES = 128
@@ -71,6 +71,10 @@ _SIGNATURES = {
     "alp_render_enqueue": [_c_void_p, _c_dp, _c_dp, _c_double],
     "alp_render_fetch": [_c_void_p, _c_fp],
     "alp_render_fetch_visibility": [_c_void_p, ctypes.POINTER(ctypes.c_uint64)],
+    "alp_mesh_set_valid": [_c_void_p, ctypes.POINTER(ctypes.c_uint8)],
+    "alp_mesh_from_rasters": [_c_void_p, _c_int, _c_i64, _c_i64, _c_dp, ctypes.c_double, _c_void_p, _c_int,
+                              ctypes.c_double, ctypes.POINTER(ctypes.c_uint8), _c_dp, ctypes.POINTER(_c_void_p)],
+    "alp_mesh_fetch": [_c_void_p, _c_fp, _c_fp, ctypes.POINTER(ctypes.c_uint8)],
     "alp_render_valid_count": [_c_void_p, ctypes.POINTER(_c_i64)],
     "alp_render_fetch_valid": [_c_void_p, _c_dp, ctypes.POINTER(ctypes.c_uint32), _c_dp],
     "alp_render_gather": [_c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), _c_i64, _c_dp,
@@ -287,6 +291,63 @@ class Mesh:
                                 n_tri, gh, gw, ctypes.byref(h)))
         self._h, self._lib = h, l
         self.shape = None
+        self.n_vert = vert.shape[0]
+
+    @classmethod
+    def from_rasters(cls, dsm, transform, z_max, aerial, color_div, nodata=None):
+        """Implicit-grid mesh built on the device from a filled DSM (rows, cols), the affine
+        coefficients (a, b, c, d, e, f), three aerial bands (3, rows, cols; uint8 / uint16 /
+        float32) and the DSM nodata mask (alp_mesh_from_rasters).  Returns (mesh, offsets)."""
+        l = lib()
+        dsm = np.ascontiguousarray(dsm)
+        if dsm.dtype not in (np.float32, np.float64):
+            dsm = dsm.astype(np.float64)
+        if dsm.ndim != 2:
+            raise ValueError("dsm must have shape (rows, cols)")
+        aerial = np.ascontiguousarray(aerial)
+        if aerial.dtype not in (np.uint8, np.uint16, np.float32):
+            aerial = aerial.astype(np.float32)
+        if aerial.shape != (3,) + dsm.shape:
+            raise ValueError("aerial must have shape (3, rows, cols)")
+        codes = {np.dtype(np.float32): ALP_F32, np.dtype(np.float64): ALP_F64, np.dtype(np.uint8): ALP_U8,
+                 np.dtype(np.uint16): ALP_U16}
+        t = np.ascontiguousarray(transform, dtype=np.float64)
+        if t.shape != (6,):
+            raise ValueError("transform must have the six affine coefficients a, b, c, d, e, f")
+        nod = None
+        if nodata is not None:
+            nod = np.ascontiguousarray(nodata, dtype=np.uint8)
+            if nod.shape != dsm.shape:
+                raise ValueError("nodata must have the shape of dsm")
+        off = np.empty(3, dtype=np.float64)
+        h = _c_void_p()
+        check(l.alp_mesh_from_rasters(dsm.ctypes.data_as(_c_void_p), codes[dsm.dtype], dsm.shape[0], dsm.shape[1],
+                                      as_dp(t), float(z_max), aerial.ctypes.data_as(_c_void_p), codes[aerial.dtype],
+                                      float(color_div),
+                                      None if nod is None else nod.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                                      as_dp(off), ctypes.byref(h)))
+        self = cls.__new__(cls)
+        self._h, self._lib, self.shape, self.n_vert = h, l, None, dsm.size
+        return self, off
+
+    def set_valid(self, valid):
+        """Per-vertex mask (falsy = nodata: its triangles are not drawn); None removes it."""
+        if valid is None:
+            check(self._lib.alp_mesh_set_valid(self._h, None))
+            return
+        valid = np.ascontiguousarray(np.asarray(valid).ravel() != 0, dtype=np.uint8)
+        if valid.shape[0] != self.n_vert:
+            raise ValueError("valid must have one entry per vertex")
+        check(self._lib.alp_mesh_set_valid(self._h, valid.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))))
+
+    def fetch_arrays(self):
+        """(vert, value, valid) of the resident mesh as numpy arrays (inspection / tests)."""
+        vert = np.empty((self.n_vert, 3), dtype=np.float32)
+        value = np.empty((self.n_vert, 3), dtype=np.float32)
+        valid = np.empty(self.n_vert, dtype=np.uint8)
+        check(self._lib.alp_mesh_fetch(self._h, as_fp(vert), as_fp(value),
+                                       valid.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))))
+        return vert, value, valid.astype(bool)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

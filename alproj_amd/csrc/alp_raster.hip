@@ -565,6 +565,7 @@ __device__ __forceinline__ void emit_general(const View &v, const float q[3][3],
 // for raster_general_kernel.
 template <bool IMPLICIT>
 __global__ __launch_bounds__(256) void raster_kernel(const float *__restrict__ vert, const int *__restrict__ ind,
+                                                     const unsigned char *__restrict__ valid,
                                                      long long n_tri, long long gw, View v,
                                                      unsigned long long *__restrict__ vis,
                                                      unsigned *__restrict__ gqueue, unsigned *__restrict__ gcount,
@@ -575,7 +576,12 @@ __global__ __launch_bounds__(256) void raster_kernel(const float *__restrict__ v
         const long long t = k * stride + (long long)blockIdx.x * blockDim.x + threadIdx.x;
         Deferred park;
         int code = EMIT_DONE;
-        if (t < n_tri) {
+        bool draw = t < n_tri;
+        if (draw && valid) {
+            const Idx3 id = tri_vertices<IMPLICIT>(ind, gw, t);
+            draw = valid[id.a] && valid[id.b] && valid[id.c];
+        }
+        if (draw) {
             float q[3][3];
             load_view_tri<IMPLICIT>(v, vert, ind, gw, t, q);
             const bool in0 = q[0][2] >= 1.0f, in1 = q[1][2] >= 1.0f, in2 = q[2][2] >= 1.0f;
@@ -640,11 +646,12 @@ constexpr int GT_W = 32, GT_H = 8, GT_VW = GT_W + 1, GT_VH = GT_H + 1, GT_NV = G
 #define GRID_WAVES_PER_EU 8
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRID_WAVES_PER_EU)))
-void raster_grid_kernel(const float *__restrict__ vert, int gh, int gw, View v, unsigned long long *__restrict__ vis,
-                        unsigned *__restrict__ gqueue, unsigned *__restrict__ gcount, unsigned gcap,
-                        int lanes_along_rows) {
-    // s_xy[].x of a vertex without window coordinates: behind the near plane / outside the fixed-point range
-    constexpr int BEHIND = INT_MIN, RANGE = INT_MIN + 1;
+void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__restrict__ valid, int gh, int gw, View v,
+                        unsigned long long *__restrict__ vis, unsigned *__restrict__ gqueue,
+                        unsigned *__restrict__ gcount, unsigned gcap, int lanes_along_rows) {
+    // s_xy[].x of a vertex without window coordinates: behind the near plane / outside the
+    // fixed-point range / masked out (nodata: its triangles do not exist, surface.py:203-205)
+    constexpr int BEHIND = INT_MIN, RANGE = INT_MIN + 1, NODATA = INT_MIN + 2;
     __shared__ int2 s_xy[GT_NV];          // snapped window coordinates
     __shared__ float s_iw[GT_NV];
     const int tiles_x = (gw - 1 + GT_W - 1) / GT_W;
@@ -654,7 +661,9 @@ void raster_grid_kernel(const float *__restrict__ vert, int gh, int gw, View v, 
         const int lr = idx / GT_VW, lc = idx - lr * GT_VW;
         const int r = r0 + lr, c = c0 + lc;
         int2 xy = make_int2(BEHIND, 0);
-        if (r < gh && c < gw) {
+        if (r < gh && c < gw && valid && !valid[(long long)r * gw + c]) {
+            xy.x = NODATA;
+        } else if (r < gh && c < gw) {
             const float *p = vert + 3 * ((long long)r * gw + c);
             float q[3];
             to_view(v, p[0], p[1], p[2], q);
@@ -683,7 +692,7 @@ void raster_grid_kernel(const float *__restrict__ vert, int gh, int gw, View v, 
     const long long cell = (long long)r * (gw - 1) + c;
     const int2 P[4] = {s_xy[ia], s_xy[ib], s_xy[ic], s_xy[id]};
     bool work = r < gh - 1 && c < gw - 1;
-    if (work && P[0].x > RANGE && P[1].x > RANGE && P[2].x > RANGE && P[3].x > RANGE) {
+    if (work && P[0].x > NODATA && P[1].x > NODATA && P[2].x > NODATA && P[3].x > NODATA) {
         // the cell's bounding box holds no pixel centre of the viewport: neither can its triangles
         const int minx = min(min(P[0].x, P[1].x), min(P[2].x, P[3].x)), maxx = max(max(P[0].x, P[1].x), max(P[2].x, P[3].x));
         const int miny = min(min(P[0].y, P[1].y), min(P[2].y, P[3].y)), maxy = max(max(P[0].y, P[1].y), max(P[2].y, P[3].y));
@@ -700,10 +709,11 @@ void raster_grid_kernel(const float *__restrict__ vert, int gh, int gw, View v, 
         Deferred park;
         int code = EMIT_DONE;
         if (work) {
-            if (A.x > RANGE && B.x > RANGE && C.x > RANGE) {
+            if (A.x > NODATA && B.x > NODATA && C.x > NODATA) {
                 const int X[3] = {A.x, B.x, C.x}, Y[3] = {A.y, B.y, C.y};
                 code = emit_small(v, X, Y, s_iw, ia, k1, k2, t, vis, &park, true);
-            } else if (!(A.x == BEHIND && B.x == BEHIND && C.x == BEHIND)) {
+            } else if (A.x != NODATA && B.x != NODATA && C.x != NODATA &&
+                       !(A.x == BEHIND && B.x == BEHIND && C.x == BEHIND)) {
                 code = EMIT_GENERAL;      // near-plane crossing or out of range (all three behind: nothing to draw)
             }
             if (code == EMIT_GENERAL) {   // rare: raster_general_kernel redoes this triangle from its vertices
@@ -971,6 +981,65 @@ __global__ __launch_bounds__(256) void narrow_indices_kernel(const long long *__
         dst[dst_off + i] = (int)src[i];
 }
 
+// ------------------------------------------------------------------ mesh construction from rasters
+// get_colored_surface after its raster I/O (src/alproj/surface.py:173-212) on the device: the
+// DSM and the aerial bands go up once (4 + 3..12 B per vertex instead of 24 B of float32 vert +
+// col and 48 B of int64 indices), vertices / colours / the nodata mask are built in HBM and the
+// index array is never formed (implicit grid + per-vertex mask).
+template <typename Z>
+__device__ __forceinline__ double surface_z(const Z *dsm, long long i, double z_max) {
+    double z = (double)dsm[i];
+    if (z < 0) z = 0;                        // surface.py:175
+    if (z > z_max) z = z_max;                // surface.py:176
+    return z;
+}
+
+// min over the clamped elevations (>= 0, so the float64 bit patterns order like the values)
+template <typename Z>
+__global__ __launch_bounds__(256) void surface_zmin_kernel(const Z *__restrict__ dsm, long long n, double z_max,
+                                                           unsigned long long *__restrict__ out) {
+    double m = __builtin_inf();
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double z = surface_z(dsm, i, z_max);
+        m = z < m ? z : m;                   // a NaN elevation never becomes the minimum (numpy would return NaN)
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const double o = __shfl_xor(m, d);
+        m = o < m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMin(out, (unsigned long long)__double_as_longlong(m));
+}
+
+template <typename Z, typename A>
+__global__ __launch_bounds__(256) void surface_build_kernel(const Z *__restrict__ dsm, const A *__restrict__ aerial,
+                                                            const unsigned char *__restrict__ nodata,
+                                                            long long rows, long long cols, double t0, double t2,
+                                                            double t4, double t5, double z_max, double color_div,
+                                                            double ox, double oz, double oy,
+                                                            float *__restrict__ vert, float *__restrict__ value,
+                                                            unsigned char *__restrict__ valid) {
+    const long long n = rows * cols;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long r = i / cols, c = i - r * cols;
+    // surface.py:179-180, 189, 211-212: float64 coordinates minus the float64 offsets, then the
+    // float32 cast of persp_proj (project.py:213); this unit is compiled without fp contraction
+    const double x = (double)c * t0 + t2, y = (double)r * t4 + t5, z = surface_z(dsm, i, z_max);
+    vert[3 * i + 0] = (float)(x - ox);
+    vert[3 * i + 1] = (float)(z - oz);
+    vert[3 * i + 2] = (float)(y - oy);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {            // _normalize_aerial, surface.py:44-66
+        double a = (double)aerial[b * n + i];
+        if (color_div > 0) a /= color_div;
+        a = a < 0 ? 0 : a;                   // np.clip keeps a NaN
+        a = a > 1 ? 1 : a;
+        value[3 * i + b] = (float)a;
+    }
+    valid[i] = nodata ? (nodata[i] ? 0 : 1) : 1;
+}
+
 }  // namespace alp
 
 using namespace alp;
@@ -980,6 +1049,7 @@ struct alp_mesh {
     bool implicit = false;
     float *vert = nullptr, *value = nullptr;
     int *ind = nullptr;
+    unsigned char *valid = nullptr;    // optional, per vertex: 0 = nodata, its triangles are not drawn
     // per-render state (sized on first use)
     int w = 0, h = 0;
     unsigned long long *vis = nullptr;
@@ -1060,12 +1130,13 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
             // vertices are X, Z, Y: columns step X (R[0][0] on screen x), rows step Y (R[0][2])
             int along_rows = std::fabs(v.R[0][2]) > std::fabs(v.R[0][0]);
             if (const char *e = getenv("ALP_GRID_LANES")) along_rows = e[0] == 'r';   // development override
-            hipLaunchKernelGGL(raster_grid_kernel, dim3((unsigned)tiles), dim3(256), 0, st, m->vert, (int)m->grid_h,
-                               (int)m->grid_w, v, m->vis, m->gqueue, m->qcount_dev + 1, m->gcap, along_rows);
+            hipLaunchKernelGGL(raster_grid_kernel, dim3((unsigned)tiles), dim3(256), 0, st, m->vert, m->valid,
+                               (int)m->grid_h, (int)m->grid_w, v, m->vis, m->gqueue, m->qcount_dev + 1, m->gcap,
+                               along_rows);
         } else {
             const long long want = (m->n_tri + 255) / 256;
             const int grid = (int)(want < (long long)cu * 16 ? want : (long long)cu * 16);
-            hipLaunchKernelGGL((raster_kernel<IMPLICIT>), dim3(grid), dim3(256), 0, st, m->vert, m->ind,
+            hipLaunchKernelGGL((raster_kernel<IMPLICIT>), dim3(grid), dim3(256), 0, st, m->vert, m->ind, m->valid,
                                (long long)m->n_tri, (long long)m->grid_w, v, m->vis, m->gqueue, m->qcount_dev + 1,
                                m->gcap);
         }
@@ -1228,7 +1299,7 @@ int alp_mesh_create(const float *vert, const float *value, int64_t n_vert, const
 int alp_mesh_destroy(alp_mesh_t *m) {
     if (!m) return ALP_OK;
     if (ctx().ready) hipStreamSynchronize(ctx().stream);
-    for (void *p : {(void *)m->vert, (void *)m->value, (void *)m->ind, (void *)m->vis, (void *)m->image,
+    for (void *p : {(void *)m->vert, (void *)m->value, (void *)m->ind, (void *)m->valid, (void *)m->vis, (void *)m->image,
                     (void *)m->queue, (void *)m->gqueue, (void *)m->qcount_dev, (void *)m->compact_counts, (void *)m->compact_offsets})
         if (p) hipFree(p);
     if (m->qcount_host) hipHostFree(m->qcount_host);
@@ -1384,6 +1455,137 @@ int alp_distort_image(const float *img, int64_t h, int64_t w, int64_t c, const d
     if (e == hipSuccess) e = hipStreamSynchronize(ctx().stream);
     hipFree(dev);
     if (e != hipSuccess) return fail(ALP_EHIP, "alp_distort_image: %s", hipGetErrorString(e));
+    return ALP_OK;
+}
+
+int alp_mesh_set_valid(alp_mesh_t *m, const uint8_t *valid) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(m, "mesh handle is NULL");
+    if (!valid) {
+        if (m->valid) hipFree(m->valid);
+        m->valid = nullptr;
+        return ALP_OK;
+    }
+    if (!m->valid) ALP_HIP(hipMalloc((void **)&m->valid, (size_t)m->n_vert));
+    return upload_chunked(m->valid, valid, (size_t)m->n_vert);
+}
+
+int alp_mesh_from_rasters(const void *dsm, int dsm_dtype, int64_t rows, int64_t cols, const double transform[6],
+                          double z_max, const void *aerial, int aerial_dtype, double color_div,
+                          const uint8_t *nodata, double offsets_out[3], alp_mesh_t **out) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    ALP_REQUIRE(dsm && aerial && transform && offsets_out, "NULL argument");
+    ALP_REQUIRE(dsm_dtype == ALP_F32 || dsm_dtype == ALP_F64, "dsm_dtype must be ALP_F32 or ALP_F64");
+    ALP_REQUIRE(aerial_dtype == ALP_F32 || aerial_dtype == ALP_U8 || aerial_dtype == ALP_U16,
+                "aerial_dtype must be ALP_U8, ALP_U16 or ALP_F32");
+    ALP_REQUIRE(rows >= 2 && cols >= 2, "the raster needs at least 2 x 2 cells");
+    ALP_REQUIRE(rows * cols < ((int64_t)1 << 31), "more than 2^31 vertices");
+    ALP_REQUIRE(z_max >= 0, "z_max is negative");
+    const int64_t n = rows * cols;
+    alp_mesh *m = new alp_mesh();
+    m->n_vert = n;
+    m->grid_h = rows;
+    m->grid_w = cols;
+    m->n_tri = 2 * (rows - 1) * (cols - 1);
+    m->implicit = true;
+    int rc = ALP_OK;
+    void *dsm_dev = nullptr, *aer_dev = nullptr;
+    unsigned char *nod_dev = nullptr;
+    unsigned long long *zmin_dev = nullptr;
+    auto bail = [&](int code) {
+        for (void *p : {dsm_dev, aer_dev, (void *)nod_dev, (void *)zmin_dev})
+            if (p) hipFree(p);
+        alp_mesh_destroy(m);
+        return code;
+    };
+    const size_t zsize = dsm_dtype == ALP_F32 ? 4 : 8;
+    const size_t asize = aerial_dtype == ALP_U8 ? 1 : aerial_dtype == ALP_U16 ? 2 : 4;
+    if (hipMalloc(&dsm_dev, (size_t)n * zsize) != hipSuccess || hipMalloc(&aer_dev, (size_t)n * 3 * asize) != hipSuccess ||
+        hipMalloc((void **)&zmin_dev, 8) != hipSuccess || hipMalloc((void **)&m->vert, (size_t)n * 12) != hipSuccess ||
+        hipMalloc((void **)&m->value, (size_t)n * 12) != hipSuccess || hipMalloc((void **)&m->valid, (size_t)n) != hipSuccess ||
+        (nodata && hipMalloc((void **)&nod_dev, (size_t)n) != hipSuccess))
+        return bail(fail(ALP_EHIP, "alp_mesh_from_rasters: hipMalloc"));
+    if ((rc = upload_chunked(dsm_dev, dsm, (size_t)n * zsize))) return bail(rc);
+    if ((rc = upload_chunked(aer_dev, aerial, (size_t)n * 3 * asize))) return bail(rc);
+    if (nodata && (rc = upload_chunked(nod_dev, nodata, (size_t)n))) return bail(rc);
+    hipStream_t st = ctx().stream;
+    // offsets = vert.min(axis=0) (surface.py:211): x and y from the two coordinate vectors on the
+    // host (same float64 mul + add), z by a device reduction
+    double ox = __builtin_inf(), oy = __builtin_inf();
+    for (int64_t c = 0; c < cols; ++c) {
+        const double x = (double)c * transform[0] + transform[2];
+        ox = x < ox ? x : ox;
+    }
+    for (int64_t r = 0; r < rows; ++r) {
+        const double y = (double)r * transform[4] + transform[5];
+        oy = y < oy ? y : oy;
+    }
+    const unsigned long long inf_bits = 0x7FF0000000000000ull;
+    hipError_t e = hipMemcpyAsync(zmin_dev, &inf_bits, 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        const dim3 grid((unsigned)(ctx().cu_count * 8));
+        if (dsm_dtype == ALP_F32)
+            hipLaunchKernelGGL(surface_zmin_kernel<float>, grid, dim3(256), 0, st, (const float *)dsm_dev, (long long)n, z_max, zmin_dev);
+        else
+            hipLaunchKernelGGL(surface_zmin_kernel<double>, grid, dim3(256), 0, st, (const double *)dsm_dev, (long long)n, z_max, zmin_dev);
+        e = hipGetLastError();
+    }
+    double oz = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&oz, zmin_dev, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return bail(fail(ALP_EHIP, "alp_mesh_from_rasters: %s", hipGetErrorString(e)));
+    const dim3 grid((unsigned)((n + 255) / 256));
+#define ALP_BUILD(Z, A)                                                                                              \
+    hipLaunchKernelGGL((surface_build_kernel<Z, A>), grid, dim3(256), 0, st, (const Z *)dsm_dev, (const A *)aer_dev, \
+                       (const unsigned char *)nod_dev, (long long)rows, (long long)cols, transform[0], transform[2], \
+                       transform[4], transform[5], z_max, color_div, ox, oz, oy, m->vert, m->value, m->valid)
+    if (dsm_dtype == ALP_F32) {
+        if (aerial_dtype == ALP_U8) ALP_BUILD(float, unsigned char);
+        else if (aerial_dtype == ALP_U16) ALP_BUILD(float, unsigned short);
+        else ALP_BUILD(float, float);
+    } else {
+        if (aerial_dtype == ALP_U8) ALP_BUILD(double, unsigned char);
+        else if (aerial_dtype == ALP_U16) ALP_BUILD(double, unsigned short);
+        else ALP_BUILD(double, float);
+    }
+#undef ALP_BUILD
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return bail(fail(ALP_EHIP, "alp_mesh_from_rasters: %s", hipGetErrorString(e)));
+    if (!nodata) {                           // nothing masked: plain grid
+        hipFree(m->valid);
+        m->valid = nullptr;
+    }
+    for (void *p : {dsm_dev, aer_dev, (void *)nod_dev, (void *)zmin_dev})
+        if (p) hipFree(p);
+    dsm_dev = aer_dev = nullptr;
+    nod_dev = nullptr;
+    zmin_dev = nullptr;
+    if (hipMalloc((void **)&m->qcount_dev, 2 * sizeof(unsigned)) != hipSuccess ||
+        hipHostMalloc((void **)&m->qcount_host, 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess)
+        return bail(fail(ALP_EHIP, "hipMalloc queue counter"));
+    if ((rc = ensure_queue(m, 1u << 20))) return bail(rc);
+    if ((rc = ensure_gqueue(m, 1u << 20))) return bail(rc);
+    offsets_out[0] = ox;                     // X, Z, Y like `vert` (surface.py:189)
+    offsets_out[1] = oz;
+    offsets_out[2] = oy;
+    *out = m;
+    return ALP_OK;
+}
+
+int alp_mesh_fetch(alp_mesh_t *m, float *vert, float *value, uint8_t *valid) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(m, "mesh handle is NULL");
+    hipStream_t st = ctx().stream;
+    if (vert) ALP_HIP(hipMemcpyAsync(vert, m->vert, (size_t)m->n_vert * 12, hipMemcpyDeviceToHost, st));
+    if (value) ALP_HIP(hipMemcpyAsync(value, m->value ? m->value : m->vert, (size_t)m->n_vert * 12, hipMemcpyDeviceToHost, st));
+    if (valid) {
+        if (m->valid) ALP_HIP(hipMemcpyAsync(valid, m->valid, (size_t)m->n_vert, hipMemcpyDeviceToHost, st));
+        else memset(valid, 1, (size_t)m->n_vert);
+    }
+    ALP_HIP(hipStreamSynchronize(st));
     return ALP_OK;
 }
 

@@ -51,7 +51,9 @@ enum alp_dtype {
     ALP_F32 = 0,
     ALP_F64 = 1,
     ALP_I32 = 2,
-    ALP_I64 = 3
+    ALP_I64 = 3,
+    ALP_U8 = 4,
+    ALP_U16 = 5
 };
 
 /* Loss kinds of the population evaluation. */
@@ -174,6 +176,32 @@ int alp_mesh_create(const float *vert, const float *value, int64_t n_vert,
                     const void *ind, int ind_dtype, int64_t n_tri,
                     int64_t grid_h, int64_t grid_w, alp_mesh_t **out);
 int alp_mesh_destroy(alp_mesh_t *mesh);
+
+/* Per-vertex nodata mask (n_vert bytes, 0 = nodata; NULL removes the mask): triangles touching
+ * a masked vertex are not drawn -- what get_colored_surface does by filtering its index array,
+ * src/alproj/surface.py:203-205.  Triangle ids stay those of the unfiltered mesh. */
+int alp_mesh_set_valid(alp_mesh_t *mesh, const uint8_t *valid);
+
+/* Mesh construction of get_colored_surface() after its raster I/O, src/alproj/surface.py:173-212,
+ * on the device: implicit-grid mesh with colours and nodata mask from
+ *   dsm      rows x cols elevations (ALP_F32 or ALP_F64), nodata already filled (:171);
+ *            clamped to [0, z_max] (:175-176, z_max = the `dsm_max_height` of :169)
+ *   transform  the six affine coefficients a, b, c, d, e, f of the merged rasters:
+ *            x = col * a + c, y = row * e + f (:179-180)
+ *   aerial   3 x rows x cols band-planar colours (ALP_U8, ALP_U16 or ALP_F32), divided by
+ *            color_div (0 = leave as they are) and clipped to [0, 1] (_normalize_aerial, :26-66;
+ *            the caller picks the divisor from the source dtype / color_max)
+ *   nodata   rows x cols bytes, nonzero = DSM nodata (:110-117), or NULL
+ * Vertices are float32 (x, z, y) minus offsets_out = their float64 minimum (:211-212), vertex id
+ * = row * cols + col, triangles (a, a+cols, a+cols+1), (a, a+cols+1, a+1) (:194-201). */
+int alp_mesh_from_rasters(const void *dsm, int dsm_dtype, int64_t rows, int64_t cols,
+                          const double transform[6], double z_max, const void *aerial,
+                          int aerial_dtype, double color_div, const uint8_t *nodata,
+                          double offsets_out[3], alp_mesh_t **out);
+
+/* Copy the resident mesh back (any pointer may be NULL): vert, value n_vert x 3 float32, valid
+ * n_vert bytes.  For inspection and parity tests. */
+int alp_mesh_fetch(alp_mesh_t *mesh, float *vert, float *value, uint8_t *valid);
 
 /* Depth-buffered render + lens-distortion remap: replaces persp_proj(),
  * src/alproj/project.py:145-294 (OpenGL draw :210-290, distort :111-143).

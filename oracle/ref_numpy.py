@@ -373,3 +373,48 @@ def rasterize_points(x, y, values, resolution=1.0, interpolate=True, max_dist=1.
     out = np.clip(np.nan_to_num(raster, nan=0), 0, 255).astype(np.uint8)
     out[nan_mask] = nodata
     return out, (x_min, y_min, x_max, y_max, width, height)
+
+
+# ---------------------------------------------------------------------------------------------
+# surface.get_colored_surface after its raster I/O (src/alproj/surface.py:26-66, 173-212)
+def normalize_aerial(data, source_dtype, color_max=None):
+    """surface.py:44-66 (the warning for float rasters above 255 is not restated)."""
+    data = np.asarray(data).astype(np.float64)
+    source_dtype = np.dtype(source_dtype)
+    if color_max is not None:
+        data = data / color_max
+    elif np.issubdtype(source_dtype, np.unsignedinteger) or np.issubdtype(source_dtype, np.signedinteger):
+        data = data / np.iinfo(source_dtype).max
+    elif np.issubdtype(source_dtype, np.floating):
+        if data.max() > 1.0:
+            data = data / 255.0
+    else:
+        data = data / 255.0
+    return np.clip(data, 0, 1)
+
+
+def colored_surface(aerial2, dsm_filled, transform, nodata_mask, source_dtype, color_max=None, dsm_max_height=None):
+    """(vert - offsets, col, ind, offsets) as surface.py:173-212 builds them from the merged
+    aerial bands, the hole-filled DSM, the affine coefficients and the DSM nodata mask."""
+    aerial2 = np.asarray(aerial2)[:3]
+    nodata_mask = np.asarray(nodata_mask, dtype=bool)
+    dsm2 = np.array(dsm_filled, copy=True)[np.newaxis, :, :]
+    if dsm_max_height is None:
+        dsm_max_height = dsm2[0][~nodata_mask].max() if (~nodata_mask).any() else 0
+    dsm2[dsm2 < 0] = 0                                                      # :175
+    dsm2[dsm2 > dsm_max_height] = dsm_max_height                            # :176
+    x = np.arange(0, dsm2.shape[2]) * transform[0] + transform[2]           # :179
+    y = np.arange(0, dsm2.shape[1]) * transform[4] + transform[5]           # :180
+    xx, yy = np.meshgrid(x, y)
+    w, h = xx.shape[0], xx.shape[1]                                         # :182-183 (rows, cols: quirk Q15)
+    zz = np.squeeze(dsm2)
+    vert = np.transpose(np.vstack((xx, zz, yy)).reshape([3, -1]))           # :189-190
+    col = np.vstack((aerial2[0], aerial2[1], aerial2[2])).reshape([3, -1])  # :191
+    col = np.transpose(normalize_aerial(col, source_dtype, color_max))
+    aii, ajj = np.meshgrid(np.arange(0, w - 1), np.arange(0, h - 1))        # :195-197
+    a = (aii + ajj * h).flatten()
+    ind = np.transpose(np.vstack((a, a + h, a + h + 1, a, a + h + 1, a + 1))).reshape([-1, 3])
+    valid_tri = (~nodata_mask.flatten())[ind].all(axis=1)                   # :203-205
+    ind = ind[valid_tri]
+    offsets = vert.min(axis=0)                                              # :211
+    return vert - offsets, col, ind, offsets

@@ -1,0 +1,94 @@
+"""mesh construction on the device (alp_mesh_from_rasters) against the
+arrays of the reference's own get_colored_surface, and renders of the masked implicit grid
+against the oracle run on the reference's filtered index array."""
+import os
+
+import numpy as np
+import pytest
+
+from alproj_amd import synthetic as syn
+from oracle import raster as orast
+
+pytestmark = pytest.mark.gpu
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "g11_surface.npz"))
+NAMES = [str(n) for n in G["names"]]
+
+
+@pytest.fixture(scope="module")
+def L():
+    from alproj_amd import _lib
+    _lib.init(0)
+    return _lib
+
+
+def camera(vert, offsets, w=320, h=200):
+    """a camera above one corner of the (offset-relative, X Z Y) patch looking across it"""
+    p = dict(syn.BASE_CAMERA)
+    ext = vert.max(axis=0)
+    p.update(x=offsets[0] - 5.0, y=offsets[2] + ext[2] / 2, z=offsets[1] + ext[1] + 15.0, pan=90.0, tilt=-25.0,
+             fov=70.0, w=w, h=h, cx=w / 2, cy=h / 2, k1=-0.03, p1=1e-3)
+    return p
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_device_mesh_equals_reference_arrays(L, name):
+    from alproj_amd import project as prj
+    from alproj_amd.surface import colored_surface_mesh
+    cm = float(G[f"{name}_color_max"])
+    aerial, nodata = G[f"{name}_aerial"], G[f"{name}_nodata"]
+    mesh, off = colored_surface_mesh(aerial, G[f"{name}_filled"], G[f"{name}_transform"], nodata, aerial.dtype,
+                                     color_max=None if np.isnan(cm) else cm,
+                                     dsm_max_height=np.float32(G[f"{name}_zmax"]))
+    with mesh:
+        vert, col, valid = mesh.fetch_arrays()
+        np.testing.assert_array_equal(off, G[f"{name}_offsets"])
+        np.testing.assert_array_equal(vert, G[f"{name}_vert"].astype(np.float32))      # persp_proj's cast, project.py:213
+        np.testing.assert_array_equal(col, G[f"{name}_col"].astype(np.float32))
+        np.testing.assert_array_equal(valid, ~nodata.ravel())
+        # the masked implicit grid renders what the reference's filtered index array renders
+        p = camera(vert, off)
+        got = prj.persp_proj(mesh, None, None, p, off)
+        exp = orast.render(vert, col, G[f"{name}_ind"], p, off)
+        np.testing.assert_array_equal(got, exp)
+        assert (exp.sum(axis=2) > 0).mean() > 0.2
+        # visibility: same winners once the implicit triangle ids are mapped to the filtered positions
+        vis = mesh.fetch_visibility()
+        ovis = orast.visibility(vert, G[f"{name}_ind"], p, off)
+        n = nodata.shape[0]
+        full = syn.grid_indices(n)
+        keep = np.flatnonzero((~nodata.ravel())[full].all(axis=1))
+        np.testing.assert_array_equal(full[keep], G[f"{name}_ind"])
+        hit = ovis != 0
+        np.testing.assert_array_equal(vis != 0, hit)
+        np.testing.assert_array_equal(vis[hit] >> np.uint64(32), ovis[hit] >> np.uint64(32))
+        tri_dev = 0xFFFFFFFF - (vis[hit] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        tri_ref = 0xFFFFFFFF - (ovis[hit] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        np.testing.assert_array_equal(tri_dev, keep[tri_ref])
+
+
+def test_set_valid_on_explicit_and_implicit_meshes(L):
+    from alproj_amd import project as prj
+    n = 64
+    s = syn.surface(n)
+    rng = np.random.default_rng(3)
+    valid = rng.random(n * n) > 0.05
+    ind = syn.grid_indices(n)
+    kept = ind[valid[ind].all(axis=1)]
+    p = syn.base_params(n)
+    p.update(w=320, h=200, cx=160.0, cy=100.0, tilt=-20.0, z=p["z"] + 30)
+    exp = orast.render(s["vert"], None, kept, p, s["offsets"])
+    os.environ["ALP_NO_GRID_DETECT"] = "1"
+    try:
+        with L.Mesh(s["vert"], None, ind) as m:              # explicit index kernel + mask
+            m.set_valid(valid)
+            np.testing.assert_array_equal(prj.persp_proj(m, None, None, p, s["offsets"]), exp)
+            m.set_valid(None)
+            full = prj.persp_proj(m, None, None, p, s["offsets"])
+    finally:
+        del os.environ["ALP_NO_GRID_DETECT"]
+    np.testing.assert_array_equal(full, orast.render(s["vert"], None, ind, p, s["offsets"]))
+    with L.Mesh(s["vert"], None, None, grid=(n, n)) as m:     # implicit grid + mask
+        m.set_valid(valid)
+        np.testing.assert_array_equal(prj.persp_proj(m, None, None, p, s["offsets"]), exp)
+    assert (exp != full).any()

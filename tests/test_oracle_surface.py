@@ -1,0 +1,40 @@
+"""oracle.ref_numpy.colored_surface (restating src/alproj/surface.py:168-212) against the
+arrays the reference's own get_colored_surface produced (tests/golden/gen_golden_surface.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ref_numpy as orc
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "g11_surface.npz"))
+NAMES = [str(n) for n in G["names"]]
+
+
+def case(name):
+    cm = float(G[f"{name}_color_max"])
+    return dict(aerial=G[f"{name}_aerial"], filled=G[f"{name}_filled"], transform=G[f"{name}_transform"],
+                nodata=G[f"{name}_nodata"], zmax=float(G[f"{name}_zmax"]), color_max=None if np.isnan(cm) else cm)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_colored_surface_restatement(name):
+    c = case(name)
+    vert, col, ind, off = orc.colored_surface(c["aerial"], c["filled"], c["transform"], c["nodata"],
+                                              c["aerial"].dtype, c["color_max"], np.float32(c["zmax"]))
+    np.testing.assert_array_equal(off, G[f"{name}_offsets"])
+    np.testing.assert_array_equal(vert, G[f"{name}_vert"])
+    np.testing.assert_array_equal(col, G[f"{name}_col"])
+    np.testing.assert_array_equal(ind, G[f"{name}_ind"])
+    assert col.min() >= 0 and col.max() <= 1
+
+
+def test_color_divisor_rules():
+    from alproj_amd.surface import color_divisor
+    a = np.zeros((3, 2, 2), np.float32)
+    assert color_divisor(a, np.uint8) == 255.0 and color_divisor(a, np.uint16) == 65535.0
+    assert color_divisor(a, np.int16) == 32767.0 and color_divisor(a, np.uint16, color_max=4095) == 4095.0
+    assert color_divisor(a + 0.5, np.float32) == 0.0
+    assert color_divisor(a + 200, np.float32) == 255.0
+    with pytest.warns(UserWarning, match="Float aerial photo has max value"):
+        assert color_divisor(a + 300, np.float32) == 255.0
