@@ -71,6 +71,7 @@ _SIGNATURES = {
     "alp_render_enqueue": [_c_void_p, _c_dp, _c_dp, _c_double],
     "alp_render_fetch": [_c_void_p, _c_fp],
     "alp_render_fetch_visibility": [_c_void_p, ctypes.POINTER(ctypes.c_uint64)],
+    "alp_mesh_set_value_source": [_c_void_p, _c_int],
     "alp_mesh_set_valid": [_c_void_p, ctypes.POINTER(ctypes.c_uint8)],
     "alp_mesh_from_rasters": [_c_void_p, _c_int, _c_i64, _c_i64, _c_dp, ctypes.c_double, _c_void_p, _c_int,
                               ctypes.c_double, ctypes.POINTER(ctypes.c_uint8), _c_dp, ctypes.POINTER(_c_void_p)],
@@ -362,9 +363,13 @@ class Mesh:
     def __exit__(self, *exc):
         self.close()
 
-    def render_enqueue(self, pvec, offsets=None, min_distance=None):
+    def render_enqueue(self, pvec, offsets=None, min_distance=None, coords=False):
+        """``coords=True`` renders the vertices themselves (reverse_proj) instead of the stored
+        per-vertex values."""
         pvec = np.ascontiguousarray(pvec, dtype=np.float64)
         off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.float64)
+        check(self._lib.alp_mesh_set_value_source(self._h, 1 if coords else 0))
+        self.generation = getattr(self, "generation", 0) + 1      # lets holders of an older frame notice
         check(self._lib.alp_render_enqueue(self._h, as_dp(pvec), None if off is None else as_dp(off),
                                            0.0 if min_distance is None else float(min_distance)))
         self.shape = (int(pvec[22]), int(pvec[21]), 3)

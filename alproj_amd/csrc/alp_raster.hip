@@ -1050,6 +1050,7 @@ struct alp_mesh {
     float *vert = nullptr, *value = nullptr;
     int *ind = nullptr;
     unsigned char *valid = nullptr;    // optional, per vertex: 0 = nodata, its triangles are not drawn
+    bool coords_as_value = false;      // render the vertices themselves (reverse_proj) although values are stored
     // per-render state (sized on first use)
     int w = 0, h = 0;
     unsigned long long *vis = nullptr;
@@ -1153,7 +1154,8 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
     const long long npix = (long long)v.w * v.h;
     const long long want = (npix + 255) / 256;
     const int grid = (int)(want < (long long)cu * 16 ? want : (long long)cu * 16);
-    hipLaunchKernelGGL((resolve_kernel<IMPLICIT>), dim3(grid), dim3(256), 0, st, m->vert, m->value, m->ind,
+    hipLaunchKernelGGL((resolve_kernel<IMPLICIT>), dim3(grid), dim3(256), 0, st, m->vert,
+                       m->coords_as_value ? nullptr : m->value, m->ind,
                        (long long)m->grid_w, v, rc, min_distance, m->vis, m->image);
     ALP_HIP(hipGetLastError());
     m->last_v = v;
@@ -1455,6 +1457,14 @@ int alp_distort_image(const float *img, int64_t h, int64_t w, int64_t c, const d
     if (e == hipSuccess) e = hipStreamSynchronize(ctx().stream);
     hipFree(dev);
     if (e != hipSuccess) return fail(ALP_EHIP, "alp_distort_image: %s", hipGetErrorString(e));
+    return ALP_OK;
+}
+
+int alp_mesh_set_value_source(alp_mesh_t *m, int source) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(m, "mesh handle is NULL");
+    ALP_REQUIRE(source == ALP_VALUE_STORED || source == ALP_VALUE_VERTICES, "source must be ALP_VALUE_STORED or ALP_VALUE_VERTICES");
+    m->coords_as_value = source == ALP_VALUE_VERTICES;
     return ALP_OK;
 }
 

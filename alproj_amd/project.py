@@ -112,8 +112,16 @@ class ReverseProjection:
     f4): ``to_frame`` builds the reference's DataFrame, ``lookup`` answers ``set_gcp`` for a few
     thousand pixels without ever materialising the ~10 M-row table."""
 
-    def __init__(self, mesh, offsets, w, h, owns_mesh):
+    def __init__(self, mesh, offsets, w, h, owns_mesh, pvec):
         self.mesh, self.offsets, self.w, self.h, self._owns = mesh, offsets, int(w), int(h), owns_mesh
+        self._pvec, self._generation = pvec, mesh.generation
+
+    def _current(self):
+        """The mesh may have rendered something else since (it holds one frame): render again."""
+        if self.mesh.generation != self._generation:
+            self.mesh.render_enqueue(self._pvec, self.offsets, None, coords=True)
+            self._generation = self.mesh.generation
+        return self.mesh
 
     def lookup(self, u, v):
         """(n, 3) float64 x, y, z seen at the pixels (u, v) of the simulated image; NaN where the
@@ -123,7 +131,7 @@ class ReverseProjection:
         whole = (u == np.round(u)) & (v == np.round(v)) & (np.abs(u) < 2**31) & (np.abs(v) < 2**31)
         ui = np.where(whole, u, -1).astype(np.int32)
         vi = np.where(whole, v, -1).astype(np.int32)
-        return self.mesh.gather(ui, vi, self.offsets)
+        return self._current().gather(ui, vi, self.offsets)
 
     def to_frame(self, array, chnames=["B", "G", "R"]):
         """The DataFrame of the reference's ``reverse_proj`` (project.py:361-374)."""
@@ -136,7 +144,7 @@ class ReverseProjection:
                              f"(array is {array.shape[:2]}, the camera image {(self.h, self.w)})")
         # the x > 0 selection (:369), the x,z,y -> x,y,z reorder (:361) and the offsets (:370-373)
         # happen on the device; only the surviving pixels travel back
-        idx, xyz = self.mesh.fetch_valid(self.offsets)
+        idx, xyz = self._current().fetch_valid(self.offsets)
         w = self.w
         data = {"u": (idx % w).astype("int16"), "v": (idx // w).astype("int16"),
                 "x": xyz[:, 0], "y": xyz[:, 1], "z": xyz[:, 2]}
@@ -167,8 +175,8 @@ def reverse_proj_device(vert, ind, params, offsets=None, *, grid_shape=None):
         mesh, owns = vert, False
     else:
         mesh, owns = _lib.Mesh(np.asarray(vert), None, ind, grid_shape), True
-    mesh.render_enqueue(pvec, offsets, None)
-    return ReverseProjection(mesh, offsets, w, h, owns)
+    mesh.render_enqueue(pvec, offsets, None, coords=True)
+    return ReverseProjection(mesh, offsets, w, h, owns, pvec)
 
 
 def reverse_proj(array, vert, ind, params, offsets=None, chnames=["B", "G", "R"], *, grid_shape=None):

@@ -177,6 +177,12 @@ int alp_mesh_create(const float *vert, const float *value, int64_t n_vert,
                     int64_t grid_h, int64_t grid_w, alp_mesh_t **out);
 int alp_mesh_destroy(alp_mesh_t *mesh);
 
+/* What the following renders interpolate: the stored per-vertex values (sim_image,
+ * src/alproj/project.py:321) or the vertices themselves (reverse_proj, project.py:360) -- one
+ * resident mesh serves both calls of the reference's pipeline (example.py:33-36). */
+enum alp_value_source { ALP_VALUE_STORED = 0, ALP_VALUE_VERTICES = 1 };
+int alp_mesh_set_value_source(alp_mesh_t *mesh, int source);
+
 /* Per-vertex nodata mask (n_vert bytes, 0 = nodata; NULL removes the mask): triangles touching
  * a masked vertex are not drawn -- what get_colored_surface does by filtering its index array,
  * src/alproj/surface.py:203-205.  Triangle ids stay those of the unfiltered mesh. */
