@@ -92,3 +92,56 @@ def test_set_valid_on_explicit_and_implicit_meshes(L):
         m.set_valid(valid)
         np.testing.assert_array_equal(prj.persp_proj(m, None, None, p, s["offsets"]), exp)
     assert (exp != full).any()
+
+
+def _flat(size=10, elevation=100.0, aerial_dtype=np.uint8, rgb=128):
+    """the rasters of the reference's tests/test_surface.py helpers, as arrays"""
+    t = (1.0, 0.0, 500.0, 0.0, -1.0, 500.0 + size)
+    return (np.full((3, size, size), rgb, dtype=aerial_dtype), np.full((size, size), elevation, dtype=np.float32), t,
+            np.zeros((size, size), dtype=bool))
+
+
+def test_reference_surface_behaviours(L):
+    """tests/test_surface.py of the reference: elevation 0 is not nodata, an all-nodata DSM warns
+    and draws nothing, a nodata quadrant loses its triangles, dtypes normalise as documented."""
+    from alproj_amd import project as prj
+    from alproj_amd.surface import colored_surface_mesh
+    cam = dict(syn.BASE_CAMERA)
+    cam.update(x=505.0, y=505.0, z=40.0, pan=0.0, tilt=-89.0, fov=60.0, w=160, h=120, cx=80.0, cy=60.0)
+    aerial, dsm, t, nod = _flat(elevation=0.0)
+    mesh, off = colored_surface_mesh(aerial, dsm, t, nod, aerial.dtype)
+    with mesh:
+        vert, col, valid = mesh.fetch_arrays()
+        assert valid.all() and vert.shape == (100, 3) and np.allclose(col, 128 / 255)
+        np.testing.assert_array_equal(off, [500.0, 0.0, 501.0])
+        full = prj.persp_proj(mesh, None, None, cam, off)
+        assert (full[:, :, 0] > 0).mean() > 0.01
+    aerial, dsm, t, nod = _flat()
+    with pytest.warns(UserWarning, match="All triangles were filtered out"):
+        mesh, off = colored_surface_mesh(aerial, dsm * 0, t, ~nod, aerial.dtype, dsm_max_height=0)
+    with mesh:
+        cam0 = dict(cam, z=40.0)
+        assert not prj.persp_proj(mesh, None, None, cam0, off).any()
+    nod2 = nod.copy()
+    nod2[:5, :5] = True                                     # top-left quadrant (north-west)
+    mesh, off = colored_surface_mesh(aerial, dsm, t, nod2, aerial.dtype)
+    with mesh:
+        _, _, valid = mesh.fetch_arrays()
+        np.testing.assert_array_equal(valid.reshape(10, 10), ~nod2)
+        cam2 = dict(cam, z=140.0)
+        part = prj.persp_proj(mesh, None, None, cam2, off)
+        ref_ind = syn.grid_indices(10)
+        ref_ind = ref_ind[(~nod2.ravel())[ref_ind].all(axis=1)]
+        vert, col, _ = mesh.fetch_arrays()
+        np.testing.assert_array_equal(part, orast.render(vert, col, ref_ind, cam2, off))
+        covered = (part[:, :, 0] > 0).mean()
+        assert 0 < covered < (prj.persp_proj(vert, col, syn.grid_indices(10), cam2, off)[:, :, 0] > 0).mean()
+    # dtypes (TestGetColoredSurfaceDtypes): uint16 full scale, float32 in [0, 1], color_max, int16
+    for dtype, rgb, kw, exp in [(np.uint16, 32768, {}, 32768 / 65535), (np.float32, 0.5, {}, 0.5),
+                                (np.uint16, 2048, {"color_max": 4095}, 2048 / 4095), (np.int16, 16384, {}, 16384 / 32767),
+                                (np.float32, -3.0, {}, 0.0)]:
+        aerial, dsm, t, nod = _flat(aerial_dtype=dtype, rgb=rgb)
+        mesh, off = colored_surface_mesh(aerial, dsm, t, nod, aerial.dtype, **kw)
+        with mesh:
+            _, col, _ = mesh.fetch_arrays()
+            np.testing.assert_array_equal(col, np.float32(exp))

@@ -38,3 +38,27 @@ def test_color_divisor_rules():
     assert color_divisor(a + 200, np.float32) == 255.0
     with pytest.warns(UserWarning, match="Float aerial photo has max value"):
         assert color_divisor(a + 300, np.float32) == 255.0
+
+
+# the behaviours the reference's tests/test_surface.py::TestNormalizeAerial pins, on the restatement
+@pytest.mark.parametrize("data,dtype,kw,exp", [
+    ([[128, 255, 0]], np.uint8, {}, [[128 / 255, 1.0, 0.0]]),
+    ([[32768, 65535, 0]], np.uint16, {}, [[32768 / 65535, 1.0, 0.0]]),
+    ([[0.5, 1.0, 0.0]], np.float32, {}, [[0.5, 1.0, 0.0]]),
+    ([[128.0, 255.0, 0.0]], np.float32, {}, [[128 / 255, 1.0, 0.0]]),
+    ([[300.0, 500.0]], np.float32, {}, [[1.0, 1.0]]),
+    ([[-10.0, 128.0]], np.uint8, {}, [[0.0, 128 / 255]]),
+    ([[500.0, 1000.0]], np.float32, {"color_max": 1000.0}, [[0.5, 1.0]]),
+    ([[16384, 32767, 0]], np.int16, {}, [[16384 / 32767, 1.0, 0.0]]),
+])
+def test_normalize_aerial_rules(data, dtype, kw, exp):
+    from alproj_amd.surface import color_divisor
+    arr = np.array(data, dtype=np.float64)
+    np.testing.assert_allclose(orc.normalize_aerial(arr, np.dtype(dtype), **kw), exp, atol=1e-12)
+    # the divisor the device path is given reproduces the same numbers
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        div = color_divisor(arr, dtype, kw.get("color_max"))
+    got = np.clip(arr / div if div > 0 else arr, 0, 1)
+    np.testing.assert_allclose(got, exp, atol=1e-12)
