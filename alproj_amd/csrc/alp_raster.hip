@@ -1107,6 +1107,16 @@ int ensure_queue(alp_mesh *m, unsigned cap) {
     return ALP_OK;
 }
 
+// both device queues start at 2^20 entries and grow on demand (finish_frame); ALP_QUEUE_CAP
+// lowers the start so that tests can exercise the growth path
+unsigned initial_queue_cap() {
+    if (const char *e = getenv("ALP_QUEUE_CAP")) {
+        const long v = atol(e);
+        if (v >= 1 && v < (1l << 30)) return (unsigned)v;
+    }
+    return 1u << 20;
+}
+
 int ensure_gqueue(alp_mesh *m, unsigned cap) {
     if (m->gqueue && m->gcap >= cap) return ALP_OK;
     if (m->gqueue) hipFree(m->gqueue);
@@ -1263,8 +1273,8 @@ int alp_mesh_create(const float *vert, const float *value, int64_t n_vert, const
     if (hipMalloc((void **)&m->qcount_dev, 2 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void **)&m->qcount_host, 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess)
         return bail(fail(ALP_EHIP, "hipMalloc queue counter"));
-    if ((rc = ensure_queue(m, 1u << 20))) return bail(rc);
-    if ((rc = ensure_gqueue(m, 1u << 20))) return bail(rc);
+    if ((rc = ensure_queue(m, initial_queue_cap()))) return bail(rc);
+    if ((rc = ensure_gqueue(m, initial_queue_cap()))) return bail(rc);
     // The index array the reference builds (surface.py:194-201) is the full regular grid unless
     // nodata triangles were filtered out: recognise it, drop the 12 B/triangle array and use the
     // LDS-tiled grid kernel (same triangle ids, same result, no index traffic).
@@ -1576,8 +1586,8 @@ int alp_mesh_from_rasters(const void *dsm, int dsm_dtype, int64_t rows, int64_t 
     if (hipMalloc((void **)&m->qcount_dev, 2 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void **)&m->qcount_host, 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess)
         return bail(fail(ALP_EHIP, "hipMalloc queue counter"));
-    if ((rc = ensure_queue(m, 1u << 20))) return bail(rc);
-    if ((rc = ensure_gqueue(m, 1u << 20))) return bail(rc);
+    if ((rc = ensure_queue(m, initial_queue_cap()))) return bail(rc);
+    if ((rc = ensure_gqueue(m, initial_queue_cap()))) return bail(rc);
     offsets_out[0] = ox;                     // X, Z, Y like `vert` (surface.py:189)
     offsets_out[1] = oz;
     offsets_out[2] = oy;

@@ -90,6 +90,69 @@ def test_implicit_grid_and_int32_indices(L, scene):
         assert_vis_equal(m.fetch_visibility(), ref)
 
 
+MORE_POSES = {
+    "inside_looking_north": dict(dx=150.0, dy=-100.0, dz=-30.0, pan=0.0, tilt=-5.0),     # lanes along the other grid axis
+    "inside_looking_south_west": dict(dx=200.0, dy=60.0, dz=-35.0, pan=230.0, tilt=-10.0, roll=-15.0),
+    "rolled_90": dict(roll=90.0, tilt=-15.0),
+    "straight_down": dict(dx=150.0, dz=200.0, tilt=-89.5, pan=10.0),
+    "tele": dict(fov=12.0, tilt=-14.0, pan=93.0),                                        # triangles of tens of pixels
+}
+
+
+@pytest.mark.parametrize("name", list(MORE_POSES))
+@pytest.mark.parametrize("size", [(640, 427), (1600, 1067)])
+def test_more_poses_bit_exact(L, scene, name, size):
+    """cameras inside the grid (half of it behind the near plane), other view axes, a large frame
+    (triangles above 64 px -> general queue -> work items), on the implicit grid"""
+    p = dict(scene["params"])
+    d = dict(MORE_POSES[name])
+    p["x"] += d.pop("dx", 0.0)
+    p["y"] += d.pop("dy", 0.0)
+    p["z"] += d.pop("dz", 0.0)
+    p.update(d, w=size[0], h=size[1], cx=size[0] / 2, cy=size[1] / 2)
+    n = scene["n"]
+    ref = orast.visibility(scene["vert"], None, p, scene["offsets"], grid=(n, n))
+    with L.Mesh(scene["vert"], None, None, grid=(n, n)) as m:
+        m.render_enqueue(L.params_vector(p), scene["offsets"])
+        assert_vis_equal(m.fetch_visibility(), ref)
+    assert (ref != 0).mean() > 0.05
+
+
+def test_queue_growth_redoes_the_frame(L, scene, monkeypatch):
+    """both device queues start tiny: the first frame overflows them, finish_frame grows them and
+    renders again, and the result is the same as with ample queues"""
+    p = dict(pose(scene, "low_near_plane"), w=1600, h=1067, cx=800.0, cy=533.5)
+    n = scene["n"]
+    ref = orast.visibility(scene["vert"], None, p, scene["offsets"], grid=(n, n))
+    monkeypatch.setenv("ALP_QUEUE_CAP", "8")
+    for kw in (dict(ind=None, grid=(n, n)), dict(ind=scene["ind"].astype(np.int32), grid=None)):
+        if kw["ind"] is not None:
+            monkeypatch.setenv("ALP_NO_GRID_DETECT", "1")
+        with L.Mesh(scene["vert"], None, kw["ind"], grid=kw["grid"]) as m:
+            for _ in range(2):                     # second frame: queues already large enough
+                m.render_enqueue(L.params_vector(p), scene["offsets"])
+                assert_vis_equal(m.fetch_visibility(), ref)
+
+
+def test_non_square_grid_with_mask(L):
+    from alproj_amd import project as prj
+    from alproj_amd import synthetic as syn
+    s = syn.surface(330)
+    gh, gw = 200, 330
+    vert = s["vert"][:gh * gw]                      # the 200 northern rows of the 330-column grid
+    rng = np.random.default_rng(9)
+    valid = rng.random(gh * gw) > 0.02
+    a = (np.arange(gw - 1)[None, :] + np.arange(gh - 1)[:, None] * gw).ravel()
+    ind = np.stack([a, a + gw, a + gw + 1, a, a + gw + 1, a + 1], axis=1).reshape(-1, 3)
+    p = dict(syn.base_params(330), w=640, h=427, cx=320.0, cy=213.5, pan=60.0, tilt=-10.0)
+    p["y"] += 60.0
+    ref = orast.render(vert, None, ind[valid[ind].all(axis=1)], p, s["offsets"])
+    with L.Mesh(vert, None, None, grid=(gh, gw)) as m:
+        m.set_valid(valid)
+        np.testing.assert_array_equal(prj.persp_proj(m, None, None, p, s["offsets"]), ref)
+    assert (ref[:, :, 0] > 0).mean() > 0.1
+
+
 def test_filtered_triangles(L, scene):
     """nodata triangles removed from the index array (surface.py:203-205) leave holes"""
     rng = np.random.default_rng(3)
