@@ -306,6 +306,35 @@ def test_edge_cases(L, scene):
     assert not np.array_equal(a, b)
 
 
+def test_state_and_argument_errors(L, scene):
+    """the ABI reports misuse instead of reading garbage"""
+    from alproj_amd import project as prj
+    with L.Mesh(scene["vert"], None, scene["ind"]) as m:
+        m.shape = (427, 640, 3)
+        for call in (m.fetch, m.fetch_visibility, m.fetch_valid, lambda: m.gather([1], [1])):
+            with pytest.raises(L.AlprojHipError, match="nothing rendered yet"):
+                call()
+        with pytest.raises(ValueError):
+            m.set_valid(np.ones(5))
+        with pytest.raises(ValueError):
+            m.gather([1, 2], [1])
+        m.render_enqueue(L.params_vector(pose(scene, "base")), scene["offsets"], coords=True)
+        assert m.gather([], []).shape == (0, 3)
+        xyz = m.gather([-1, 640, 3, 320], [5, 5, -2, 400], scene["offsets"])
+        assert np.isnan(xyz[:3]).all() and np.isfinite(xyz[3]).all()
+    with pytest.raises(L.AlprojHipError, match="image size"):
+        prj.persp_proj(scene["vert"], None, scene["ind"], dict(pose(scene, "base"), w=0), scene["offsets"])
+    dsm = np.zeros((4, 4), np.float32)
+    with pytest.raises(ValueError):
+        L.Mesh.from_rasters(dsm, (1, 0, 0, 0, -1, 4), 10.0, np.zeros((3, 4, 5), np.uint8), 255.0)
+    with pytest.raises(ValueError):
+        L.Mesh.from_rasters(dsm, (1, 0, 0, 0, -1), 10.0, np.zeros((3, 4, 4), np.uint8), 255.0)
+    with pytest.raises(L.AlprojHipError, match="z_max is negative"):
+        L.Mesh.from_rasters(dsm, (1, 0, 0, 0, -1, 4), -1.0, np.zeros((3, 4, 4), np.uint8), 255.0)
+    with pytest.raises(L.AlprojHipError, match="at least 2 x 2"):
+        L.Mesh.from_rasters(dsm[:1], (1, 0, 0, 0, -1, 4), 1.0, np.zeros((3, 1, 4), np.uint8), 255.0)
+
+
 def test_dsm_10m_full_frame(L):
     """BASELINE config-4 style render at 10 M vertices / 20 M triangles onto the 5616x3744
     frame: bit-exact visibility against the oracle, implicit grid == explicit int32 indices."""
