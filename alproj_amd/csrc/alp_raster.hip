@@ -785,7 +785,7 @@ __device__ __forceinline__ bool remap_source(const RemapCoef &c, int w, int h, i
 template <bool IMPLICIT>
 __global__ __launch_bounds__(256) void resolve_kernel(const float *__restrict__ vert, const float *__restrict__ value,
                                                       const int *__restrict__ ind, long long gw, View v,
-                                                      RemapCoef rc, double min_distance,
+                                                      RemapCoef rc, int identity_remap, double min_distance,
                                                       const unsigned long long *__restrict__ vis,
                                                       float *__restrict__ out) {
     const long long npix = (long long)v.w * v.h;
@@ -794,7 +794,9 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float *__restrict__ 
         const int y = (int)(p / v.w), x = (int)(p - (long long)y * v.w);
         float o[3] = {0.0f, 0.0f, 0.0f};
         int sx, sy;
-        if (remap_source(rc, v.w, v.h, x, y, sx, sy)) {
+        // no distortion at all (a1 = a2 = 1, everything else 0): the float64 map returns the
+        // pixel itself for every image size (checked exhaustively up to 32768), skip it
+        if (identity_remap ? (sx = x, sy = y, true) : remap_source(rc, v.w, v.h, x, y, sx, sy)) {
             const int j = v.h - 1 - sy;                               // flipud: image row -> GL row
             const unsigned long long key = vis[(size_t)j * v.w + sx];
             if (key) {
@@ -1164,9 +1166,12 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
     const long long npix = (long long)v.w * v.h;
     const long long want = (npix + 255) / 256;
     const int grid = (int)(want < (long long)cu * 16 ? want : (long long)cu * 16);
+    const int identity = rc.a1 == 1 && rc.a2 == 1 && rc.k1 == 0 && rc.k2 == 0 && rc.k3 == 0 && rc.k4 == 0 && rc.k5 == 0 &&
+                         rc.k6 == 0 && rc.p1 == 0 && rc.p2 == 0 && rc.s1 == 0 && rc.s2 == 0 && rc.s3 == 0 && rc.s4 == 0 &&
+                         rc.c0 > 0 && rc.c1 > 0;
     hipLaunchKernelGGL((resolve_kernel<IMPLICIT>), dim3(grid), dim3(256), 0, st, m->vert,
                        m->coords_as_value ? nullptr : m->value, m->ind,
-                       (long long)m->grid_w, v, rc, min_distance, m->vis, m->image);
+                       (long long)m->grid_w, v, rc, identity, min_distance, m->vis, m->image);
     ALP_HIP(hipGetLastError());
     m->last_v = v;
     m->last_rc = rc;

@@ -306,6 +306,19 @@ def test_edge_cases(L, scene):
     assert not np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("w,h", [(1, 1), (2, 1), (1, 3), (2, 2), (7, 5), (64, 1)])
+def test_tiny_frames(L, scene, w, h):
+    """degenerate image sizes: the centre (w-1)/2 is 0 for a one-pixel axis and the distortion map
+    of the reference divides by it (project.py:128-131) -> nothing is drawn; oracle and device agree"""
+    from alproj_amd import project as prj
+    for extra in ({}, dict(k1=-0.05, a1=1.02)):
+        p = dict(pose(scene, "tilt_roll"), w=w, h=h, cx=w / 2, cy=h / 2, **extra)
+        ref = orast.render(scene["vert"], scene["col"], scene["ind"], p, scene["offsets"])
+        got = prj.persp_proj(scene["vert"], scene["col"], scene["ind"], p, scene["offsets"])
+        np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-6)
+        assert (ref.any(axis=2) == got.any(axis=2)).all()
+
+
 def test_state_and_argument_errors(L, scene):
     """the ABI reports misuse instead of reading garbage"""
     from alproj_amd import project as prj
