@@ -174,7 +174,9 @@ def main():
     base = syn.local_params(syn.standoff_params(n_side), surf["offsets"])
     truth = syn.local_params(syn.perturbed(syn.standoff_params(n_side)), surf["offsets"])
     origin = [base["x"], base["y"], base["z"]]
+    t_up = time.perf_counter()
     pts = L.Points(xyz_l, origin, args.precision)
+    t_up = time.perf_counter() - t_up              # host -> device upload of the vertex array (not in `value`)
     t_gen = time.perf_counter() - t_gen
     pv_truth = L.params_vector(truth)
 
@@ -186,6 +188,10 @@ def main():
     bpv = BYTES_PER_VERTEX[args.precision]
     achieved = n_local * bpv / kern_s
 
+    t_fetch = time.perf_counter()
+    uu_all, vv_all = pts.fetch(np.float32)          # device -> host of all projected pixels
+    t_fetch = time.perf_counter() - t_fetch
+    del uu_all, vv_all
     # parity spot check on the bench workload itself (outside the timed region)
     step = max(1, n_local // 4000)
     cnt = (n_local - 1) // step
@@ -221,6 +227,10 @@ def main():
         "parity": {"checked_vertices": int(cnt), "max_err_rel_to_max(|ref|,w)_vs_f64_oracle": parity_max_rel,
                    "tolerance": 1e-5},
         "device": info, "setup_s": t_gen,
+        # SURVEY 8(d) c2 asks for the end-to-end figure beside the kernel figure; it is never `value`
+        "pcie_inclusive": {"upload_s": t_up, "fetch_uv_s": t_fetch,
+                           "gpoints_per_s_one_pass_incl_upload_and_fetch":
+                               n_local / (t_up + ms_per_step / 1e3 + t_fetch) / 1e9},
     }
 
     # ---------------------------------------------------------------- leg 2: CMA-ES generations
