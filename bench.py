@@ -323,6 +323,10 @@ def main():
                              # 12 B written per pixel), which is fused away here
                              "frac_with_survey_remap_bytes": (alg + W * H * 24) / (dev_r / k_r / 1e3) / HBM_PEAK},
             }
+            if ind is None:     # also with the distorted ground-truth pose (remap stage on)
+                pv_dist = L.params_vector(syn.truth_params(n_side))
+                wall_d, dev_d = timed(ctl, L, lambda: mesh.render_enqueue(pv_dist, surf["offsets"]), k_r, 2)
+                out["raster"][name]["distorted_pose_ms_per_frame"] = wall_d / k_r * 1e3
             mesh.close()
             del img
 
