@@ -221,7 +221,7 @@ __device__ __forceinline__ unsigned long long pixel_key(const TriSetup &s, int i
 }
 
 __device__ __forceinline__ void vis_max(unsigned long long *vis, const View &v, int i, int j, unsigned long long key) {
-    unsigned long long *dst = vis + (size_t)j * v.w + i;
+    unsigned long long *dst = vis + (unsigned)(__umul24((unsigned)j, (unsigned)v.w) + (unsigned)i);   // j, w <= 2^15
     // unconditional: a plain-load pre-test ("only if larger") measured SLOWER (3.35 vs 3.02 ms per
     // 100 M-vertex frame) -- the load serialises behind the atomic it was meant to save
     atomicMax(dst, key);
@@ -367,6 +367,11 @@ __device__ __forceinline__ void load_view_tri(const View &v, const float *__rest
 #ifndef INLINE_LOG2
 #define INLINE_LOG2 14      // triangles below 2^INLINE_LOG2 / 256 px are finished inside the thread
 #endif
+// 24-bit multiply (full rate; v_mul_lo_u32 issues at a quarter of it): every product of the
+// 32-bit set-up has factors below 2^15 (triangle extent < 2^14 sub-pixels, pixel centres inside
+// its bounding box)
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+
 #ifndef COOP_MIN_W
 #define COOP_MIN_W 4        // bounding boxes at least this many pixel columns wide go to coop_raster
 #endif
@@ -411,9 +416,9 @@ __device__ __forceinline__ void coop_raster(const View &v, const int X[3], const
             const int i = bx + lx, j = by + ly;
             if (i < ci0 || i > ci1 || j > cj1) continue;
             const int px = i * SUB + SUB / 2, py = j * SUB + SUB / 2;
-            const int w0 = dx[0] * (py - ya[0]) - dy[0] * (px - xa[0]) - bias[0];
-            const int w1 = dx[1] * (py - ya[1]) - dy[1] * (px - xa[1]) - bias[1];
-            const int w2 = dx[2] * (py - ya[2]) - dy[2] * (px - xa[2]) - bias[2];
+            const int w0 = mul24(dx[0], py - ya[0]) - mul24(dy[0], px - xa[0]) - bias[0];
+            const int w1 = mul24(dx[1], py - ya[1]) - mul24(dy[1], px - xa[1]) - bias[1];
+            const int w2 = mul24(dx[2], py - ya[2]) - mul24(dy[2], px - xa[2]) - bias[2];
             if ((w0 | w1 | w2) >= 0) {
                 RSTAT(7, 1);
                 const float q = __builtin_fmaf((float)(w2 + bias[2]), iw3[2],
@@ -452,7 +457,7 @@ enum { EMIT_DONE = 0, EMIT_PARKED = 1, EMIT_GENERAL = 2 };
 // under 64 px -- back-face test and the inline walk (or parking for coop_raster if may_park).
 // Returns EMIT_GENERAL, having done nothing, for a larger triangle.
 __device__ __forceinline__ int emit_small(const View &v, const int X[3], const int Y[3], const float *iwsrc,
-                                          int n0, int n1, int n2, long long t, unsigned long long *__restrict__ vis,
+                                          int n0, int n1, int n2, unsigned t, unsigned long long *__restrict__ vis,
                                           Deferred *park, bool may_park) {
     // bounding box without a pixel centre, or entirely outside the viewport
     const int minx = min(X[0], min(X[1], X[2])), maxx = max(X[0], max(X[1], X[2]));
@@ -463,18 +468,18 @@ __device__ __forceinline__ int emit_small(const View &v, const int X[3], const i
     if (!(maxx - minx < (1 << INLINE_LOG2) && maxy - miny < (1 << INLINE_LOG2))) return EMIT_GENERAL;
     // triangle smaller than 64 px: every product of the set-up fits 32 bits when taken
     // relative to the first pixel centre -- the same integers as the 64-bit path
-    const int area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (X[2] - X[0]) * (Y[1] - Y[0]);
+    const int area2 = mul24(X[1] - X[0], Y[2] - Y[0]) - mul24(X[2] - X[0], Y[1] - Y[0]);
     if (area2 <= 0) return EMIT_DONE;
     const int ci0 = max(i0, 0), ci1 = min(i1, v.w - 1), cj0 = max(j0, 0), cj1 = min(j1, v.h - 1);
     const float iw3[3] = {iwsrc[n0], iwsrc[n1], iwsrc[n2]};     // only now: most triangles never get here
-    if (may_park && ci1 - ci0 + 1 >= COOP_MIN_W && (ci1 - ci0 + 1) * (cj1 - cj0 + 1) >= COOP_MIN_PIX) {
+    if (may_park && ci1 - ci0 + 1 >= COOP_MIN_W && mul24(ci1 - ci0 + 1, cj1 - cj0 + 1) >= COOP_MIN_PIX) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             park->X[k] = X[k];
             park->Y[k] = Y[k];
             park->iw[k] = iw3[k];
         }
-        park->t = (unsigned)t;
+        park->t = t;
         return EMIT_PARKED;
     }
     const int px0 = ci0 * SUB + SUB / 2, py0 = cj0 * SUB + SUB / 2;
@@ -487,10 +492,10 @@ __device__ __forceinline__ int emit_small(const View &v, const int X[3], const i
         dx[k] = X[b] - X[a];
         dy[k] = Y[b] - Y[a];
         bias[k] = (dy[k] < 0 || (dy[k] == 0 && dx[k] > 0)) ? 0 : 1;
-        row[k] = dx[k] * (py0 - Y[a]) - dy[k] * (px0 - X[a]) - bias[k];
+        row[k] = mul24(dx[k], py0 - Y[a]) - mul24(dy[k], px0 - X[a]) - bias[k];
     }
     const float inv_area = 1.0f / (float)area2;
-    const unsigned long long lo = (unsigned long long)(0xFFFFFFFFu - (unsigned)t);
+    const unsigned long long lo = (unsigned long long)(0xFFFFFFFFu - t);
     RSTAT(2, 1);
     for (int j = cj0; j <= cj1; ++j) {
         int w0 = row[0], w1 = row[1], w2 = row[2];
@@ -521,7 +526,7 @@ __device__ __forceinline__ void emit_snapped(const View &v, const int X[3], cons
                                              long long t, int sub, unsigned long long *__restrict__ vis,
                                              WorkItem *__restrict__ queue, unsigned *__restrict__ qcount,
                                              unsigned qcap) {
-    if (emit_small(v, X, Y, iw3, 0, 1, 2, t, vis, nullptr, false) != EMIT_GENERAL) return;
+    if (emit_small(v, X, Y, iw3, 0, 1, 2, (unsigned)t, vis, nullptr, false) != EMIT_GENERAL) return;
     const TriSetup s = setup_snapped(v, X, Y, iw3);
     if (!s.valid) return;
     const int bw = s.i1 - s.i0 + 1, bh = s.j1 - s.j0 + 1;
@@ -596,7 +601,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const float *__restrict__ v
                 if (ok) {
                     const int X[3] = {snap(xw[0]), snap(xw[1]), snap(xw[2])};
                     const int Y[3] = {snap(yw[0]), snap(yw[1]), snap(yw[2])};
-                    code = emit_small(v, X, Y, iw, 0, 1, 2, t, vis, &park, true);
+                    code = emit_small(v, X, Y, iw, 0, 1, 2, (unsigned)t, vis, &park, true);
                 } else {
                     code = EMIT_GENERAL;
                 }
@@ -689,7 +694,6 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
     const int lc = wave * 8 + (lanes_along_rows ? (lane >> 3) : (lane & 7));
     const int r = r0 + lr, c = c0 + lc;
     const int ia = lr * GT_VW + lc, ib = ia + GT_VW, ic = ib + 1, id = ia + 1;
-    const long long cell = (long long)r * (gw - 1) + c;
     const int2 P[4] = {s_xy[ia], s_xy[ib], s_xy[ic], s_xy[id]};
     bool work = r < gh - 1 && c < gw - 1;
     if (work && P[0].x > NODATA && P[1].x > NODATA && P[2].x > NODATA && P[3].x > NODATA) {
@@ -701,11 +705,12 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
         if (i0 > i1 || j0 > j1 || i1 < 0 || j1 < 0 || i0 > v.w - 1 || j0 > v.h - 1) work = false;
     }
     // triangles of the cell (surface.py:194-201): (a, b, c) and (a, c, d)
+    const unsigned cell = (unsigned)r * (unsigned)(gw - 1) + (unsigned)c;      // < 2^31: 2 * cell + 1 fits
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int k1 = half ? ic : ib, k2 = half ? id : ic;
         const int2 A = P[0], B = half ? P[2] : P[1], C = half ? P[3] : P[2];
-        const long long t = 2 * cell + half;
+        const unsigned t = 2u * cell + (unsigned)half;
         Deferred park;
         int code = EMIT_DONE;
         if (work) {
@@ -718,7 +723,7 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
             }
             if (code == EMIT_GENERAL) {   // rare: raster_general_kernel redoes this triangle from its vertices
                 const unsigned slot = atomicAdd(gcount, 1u);
-                if (slot < gcap) gqueue[slot] = (unsigned)t;
+                if (slot < gcap) gqueue[slot] = t;
             }
         }
         coop_drain(v, code == EMIT_PARKED, park, vis);      // every lane of the wave arrives here
