@@ -696,6 +696,7 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
     const int ia = lr * GT_VW + lc, ib = ia + GT_VW, ic = ib + 1, id = ia + 1;
     const int2 P[4] = {s_xy[ia], s_xy[ib], s_xy[ic], s_xy[id]};
     bool work = r < gh - 1 && c < gw - 1;
+    const unsigned cell = (unsigned)r * (unsigned)(gw - 1) + (unsigned)c;      // < 2^31: 2 * cell + 1 fits
     if (work && P[0].x > NODATA && P[1].x > NODATA && P[2].x > NODATA && P[3].x > NODATA) {
         // the cell's bounding box holds no pixel centre of the viewport: neither can its triangles
         const int minx = min(min(P[0].x, P[1].x), min(P[2].x, P[3].x)), maxx = max(max(P[0].x, P[1].x), max(P[2].x, P[3].x));
@@ -703,9 +704,67 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
         const int i0 = (minx + SUB / 2 - 1) >> 8, i1 = (maxx - SUB / 2) >> 8;
         const int j0 = (miny + SUB / 2 - 1) >> 8, j1 = (maxy - SUB / 2) >> 8;
         if (i0 > i1 || j0 > j1 || i1 < 0 || j1 < 0 || i0 > v.w - 1 || j0 > v.h - 1) work = false;
+        const int ci0 = max(i0, 0), ci1 = min(i1, v.w - 1), cj0 = max(j0, 0), cj1 = min(j1, v.h - 1);
+        const int nx = ci1 - ci0 + 1, ny = cj1 - cj0 + 1;
+        if (work && nx <= 2 && ny <= 2) {
+            // Far and middle field: the cell's box holds at most 2 x 2 pixel centres.  Both triangles
+            // (a, b, c), (a, c, d) are decided at those centres at once: five edge functions
+            // e(P->Q)(p) = (Q - P) x (p - P) instead of two 3-edge set-ups (the diagonal is shared,
+            // e(a->c) = -e(c->a) exactly), stepped by whole pixels -- the same integers, tie rule and
+            // depth expression as emit_small.  A triangle with area <= 0 can never have all three
+            // biased values >= 0, and a centre outside a triangle's own box is outside the triangle.
+            work = false;
+            const int px = ci0 * SUB + SUB / 2, py = cj0 * SUB + SUB / 2;
+            const int2 a = P[0], b = P[1], cc = P[2], d = P[3];
+            const int pax = px - a.x, pay = py - a.y, pbx = px - b.x, pby = py - b.y;
+            const int pcx = px - cc.x, pcy = py - cc.y, pdx = px - d.x, pdy = py - d.y;
+            // directed edges: 0 b->c, 1 c->a, 2 a->b (triangle 0); 3 c->d, 4 d->a, 5 a->c (triangle 1)
+            int ex[6] = {cc.x - b.x, a.x - cc.x, b.x - a.x, d.x - cc.x, a.x - d.x, 0};
+            int ey[6] = {cc.y - b.y, a.y - cc.y, b.y - a.y, d.y - cc.y, a.y - d.y, 0};
+            ex[5] = -ex[1];
+            ey[5] = -ey[1];
+            int bs[6], w[6];
+            w[0] = mul24(ex[0], pby) - mul24(ey[0], pbx);
+            w[1] = mul24(ex[1], pcy) - mul24(ey[1], pcx);
+            w[2] = mul24(ex[2], pay) - mul24(ey[2], pax);
+            w[3] = mul24(ex[3], pcy) - mul24(ey[3], pcx);
+            w[4] = mul24(ex[4], pdy) - mul24(ey[4], pdx);
+            w[5] = -w[1];
+            const int area0 = w[0] + w[1] + w[2], area1 = w[3] + w[4] + w[5];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                bs[k] = (ey[k] < 0 || (ey[k] == 0 && ex[k] > 0)) ? 0 : 1;
+                w[k] -= bs[k];
+            }
+            const float iwa = s_iw[ia], iwb = s_iw[ib], iwc = s_iw[ic], iwd = s_iw[id];
+            const float inv0 = 1.0f / (float)area0, inv1 = 1.0f / (float)area1;      // used only where area > 0
+            const unsigned long long lo0 = 0xFFFFFFFFu - 2u * cell, lo1 = lo0 - 1u;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    if (ii < nx && jj < ny) {
+                        int u[6];
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) u[k] = w[k] - ii * ey[k] * SUB + jj * ex[k] * SUB;
+                        if ((u[0] | u[1] | u[2]) >= 0) {      // weights: edge k is opposite vertex k of (a, b, c)
+                            const float q = __builtin_fmaf((float)(u[2] + bs[2]), iwc,
+                                                           __builtin_fmaf((float)(u[1] + bs[1]), iwb,
+                                                                          (float)(u[0] + bs[0]) * iwa)) * inv0;
+                            vis_max(vis, v, ci0 + ii, cj0 + jj, ((unsigned long long)__float_as_uint(q) << 32) | lo0);
+                        }
+                        if ((u[3] | u[4] | u[5]) >= 0) {      // (a, c, d)
+                            const float q = __builtin_fmaf((float)(u[5] + bs[5]), iwd,
+                                                           __builtin_fmaf((float)(u[4] + bs[4]), iwc,
+                                                                          (float)(u[3] + bs[3]) * iwa)) * inv1;
+                            vis_max(vis, v, ci0 + ii, cj0 + jj, ((unsigned long long)__float_as_uint(q) << 32) | lo1);
+                        }
+                    }
+                }
+            }
+        }
     }
     // triangles of the cell (surface.py:194-201): (a, b, c) and (a, c, d)
-    const unsigned cell = (unsigned)r * (unsigned)(gw - 1) + (unsigned)c;      // < 2^31: 2 * cell + 1 fits
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int k1 = half ? ic : ib, k2 = half ? id : ic;
