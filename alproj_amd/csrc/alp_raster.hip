@@ -663,13 +663,14 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
     const int tile_r = blockIdx.x / tiles_x, tile_c = blockIdx.x - tile_r * tiles_x;
     const int r0 = tile_r * GT_H, c0 = tile_c * GT_W;
     for (int idx = threadIdx.x; idx < GT_NV; idx += 256) {
-        const int lr = idx / GT_VW, lc = idx - lr * GT_VW;
+        const int lr = mul24(idx, 1986) >> 16, lc = idx - lr * GT_VW;     // idx / 33 for idx < 297
         const int r = r0 + lr, c = c0 + lc;
         int2 xy = make_int2(BEHIND, 0);
-        if (r < gh && c < gw && valid && !valid[(long long)r * gw + c]) {
+        const unsigned vid = (unsigned)r * (unsigned)gw + (unsigned)c;   // < 2^31 vertices
+        if (r < gh && c < gw && valid && !valid[vid]) {
             xy.x = NODATA;
         } else if (r < gh && c < gw) {
-            const float *p = vert + 3 * ((long long)r * gw + c);
+            const float *p = vert + 3ull * vid;
             float q[3];
             to_view(v, p[0], p[1], p[2], q);
             if (q[2] >= 1.0f) {
@@ -733,7 +734,9 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
             const int area0 = w[0] + w[1] + w[2], area1 = w[3] + w[4] + w[5];
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-                bs[k] = (ey[k] < 0 || (ey[k] == 0 && ex[k] > 0)) ? 0 : 1;
+                // the edge owns its boundary iff dy < 0 or (dy == 0 and dx > 0) iff (dy << 12) - dx < 0
+                // (|dx| < 2^12 here: the cell's box spans at most three pixels)
+                bs[k] = 1 + (((ey[k] << 12) - ex[k]) >> 31);
                 w[k] -= bs[k];
             }
             const float iwa = s_iw[ia], iwb = s_iw[ib], iwc = s_iw[ic], iwd = s_iw[id];
