@@ -158,7 +158,7 @@ def main():
     from alproj_amd import dist as adist
     from alproj_amd import synthetic as syn
     from alproj_amd.cma import CMA
-    from oracle import ref_numpy as orc       # checker / cpu_baseline only
+    from oracle import ref_numpy as orc       # checker (parity spot check) and cpu_baseline only
 
     adist.init_comm(ctl.rank, ctl.world, ctl.bcast_bytes, ctl.local_rank)
     info = L.device_info()
@@ -244,7 +244,8 @@ def main():
         obs[~np.isfinite(obs)] = 0.0
         pts.set_observed(obs)
         targets = syn.TARGETS_D9 if args.dims == 9 else syn.TARGETS_D21
-        bounds = orc.bounds_to_array(base, targets)
+        from alproj_amd.optimize import bounds_to_array      # the product's own host logic
+        bounds = bounds_to_array(base, targets)
         lower, upper = bounds[:, 0], bounds[:, 1]
         cols = [L.PARAM_KEYS.index(t) for t in targets]
         basev = L.params_vector(base)
