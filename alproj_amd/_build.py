@@ -15,10 +15,10 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 BUILD = os.path.join(ROOT, "build")
 LIB = os.path.join(HERE, "libalproj_hip.so")
-SOURCES = ["alp_core.hip", "alp_points.hip", "alp_raster.hip", "alp_rasterize.hip"]
+SOURCES = ["alp_core.hip", "alp_points.hip", "alp_raster.hip", "alp_mesh.hip", "alp_rasterize.hip"]
 # the raster's coverage/visibility arithmetic is specified operation by operation (DESIGN.md
 # section 5): no implicit fused multiply-adds there
-EXTRA_FLAGS = {"alp_raster.hip": ["-ffp-contract=off"]}
+EXTRA_FLAGS = {"alp_raster.hip": ["-ffp-contract=off"], "alp_mesh.hip": ["-ffp-contract=off"]}
 ARCH = "gfx950"
 
 
@@ -39,7 +39,7 @@ def _stale(target, deps):
 def build(force=False, verbose=False):
     """Compile every HIP translation unit for gfx950 and link libalproj_hip.so."""
     os.makedirs(BUILD, exist_ok=True)
-    headers = [os.path.join(CSRC, "alp_internal.h"), os.path.join(CSRC, "alp_point_kernels.h"),
+    headers = [os.path.join(CSRC, "alp_internal.h"), os.path.join(CSRC, "alp_point_kernels.h"), os.path.join(CSRC, "alp_raster_internal.h"),
                os.path.join(INCLUDE, "alproj_hip.h"),
                os.path.abspath(__file__)]
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",

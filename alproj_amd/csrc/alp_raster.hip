@@ -35,7 +35,7 @@
 // Rasterisation rules OpenGL leaves to the implementation (sub-pixel snapping, tie-break on
 // shared edges, depth-buffer precision) cannot be pinned against the reference's GL driver:
 // see DESIGN.md "parity unpinned" -- the choices made are watertight and deterministic.
-#include "alp_internal.h"
+#include "alp_raster_internal.h"
 
 #include <climits>
 #include <cmath>
@@ -48,18 +48,6 @@ constexpr int SUB = 256;                     // sub-pixel units per pixel
 constexpr float COORD_LIMIT = 4194304.0f;    // 2^22 px
 constexpr int SMALL_PIXELS = 32;             // bbox pixel count finished inside raster_kernel
 constexpr int TILE = 64;                     // work-item edge for large triangles
-
-struct View {
-    float R[3][3];
-    float camf[3], caml[3];
-    float fx, fy, sx, sy;
-    int w, h;
-    double fxd, fyd;
-};
-
-struct RemapCoef {     // inverted coefficients of project.py:136-137, float64
-    double a1, a2, k1, k2, k3, k4, k5, k6, p1, p2, s1, s2, s3, s4, c0, c1;
-};
 
 static void make_view(const double *p, const double *offsets, View *v, RemapCoef *rc) {
     double x = p[0], y = p[1], z = p[2];
@@ -296,7 +284,6 @@ __device__ void raster_big(const View &v, const float q[3][3], unsigned tri, uns
     }
 }
 
-struct WorkItem { unsigned tri; unsigned short sub, tx, ty, pad; };   // sub: fan triangle 0/1
 
 // One triangle -> up to two window-space triangles (near-plane clip).  Returns the count and
 // fills xw/yw/iw[0..3] (fan around vertex 0); `big` when the fixed-point range is exceeded.
@@ -1050,99 +1037,11 @@ __global__ __launch_bounds__(256) void narrow_indices_kernel(const long long *__
         dst[dst_off + i] = (int)src[i];
 }
 
-// ------------------------------------------------------------------ mesh construction from rasters
-// get_colored_surface after its raster I/O (src/alproj/surface.py:173-212) on the device: the
-// DSM and the aerial bands go up once (4 + 3..12 B per vertex instead of 24 B of float32 vert +
-// col and 48 B of int64 indices), vertices / colours / the nodata mask are built in HBM and the
-// index array is never formed (implicit grid + per-vertex mask).
-template <typename Z>
-__device__ __forceinline__ double surface_z(const Z *dsm, long long i, double z_max) {
-    double z = (double)dsm[i];
-    if (z < 0) z = 0;                        // surface.py:175
-    if (z > z_max) z = z_max;                // surface.py:176
-    return z;
-}
-
-// min over the clamped elevations (>= 0, so the float64 bit patterns order like the values)
-template <typename Z>
-__global__ __launch_bounds__(256) void surface_zmin_kernel(const Z *__restrict__ dsm, long long n, double z_max,
-                                                           unsigned long long *__restrict__ out) {
-    double m = __builtin_inf();
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const double z = surface_z(dsm, i, z_max);
-        m = z < m ? z : m;                   // a NaN elevation never becomes the minimum (numpy would return NaN)
-    }
-    for (int d = 32; d >= 1; d >>= 1) {
-        const double o = __shfl_xor(m, d);
-        m = o < m ? o : m;
-    }
-    if ((threadIdx.x & 63) == 0) atomicMin(out, (unsigned long long)__double_as_longlong(m));
-}
-
-template <typename Z, typename A>
-__global__ __launch_bounds__(256) void surface_build_kernel(const Z *__restrict__ dsm, const A *__restrict__ aerial,
-                                                            const unsigned char *__restrict__ nodata,
-                                                            long long rows, long long cols, double t0, double t2,
-                                                            double t4, double t5, double z_max, double color_div,
-                                                            double ox, double oz, double oy,
-                                                            float *__restrict__ vert, float *__restrict__ value,
-                                                            unsigned char *__restrict__ valid) {
-    const long long n = rows * cols;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const long long r = i / cols, c = i - r * cols;
-    // surface.py:179-180, 189, 211-212: float64 coordinates minus the float64 offsets, then the
-    // float32 cast of persp_proj (project.py:213); this unit is compiled without fp contraction
-    const double x = (double)c * t0 + t2, y = (double)r * t4 + t5, z = surface_z(dsm, i, z_max);
-    vert[3 * i + 0] = (float)(x - ox);
-    vert[3 * i + 1] = (float)(z - oz);
-    vert[3 * i + 2] = (float)(y - oy);
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {            // _normalize_aerial, surface.py:44-66
-        double a = (double)aerial[b * n + i];
-        if (color_div > 0) a /= color_div;
-        a = a < 0 ? 0 : a;                   // np.clip keeps a NaN
-        a = a > 1 ? 1 : a;
-        value[3 * i + b] = (float)a;
-    }
-    valid[i] = nodata ? (nodata[i] ? 0 : 1) : 1;
-}
-
 }  // namespace alp
 
 using namespace alp;
 
-struct alp_mesh {
-    int64_t n_vert = 0, n_tri = 0, grid_h = 0, grid_w = 0;
-    bool implicit = false;
-    float *vert = nullptr, *value = nullptr;
-    int *ind = nullptr;
-    unsigned char *valid = nullptr;    // optional, per vertex: 0 = nodata, its triangles are not drawn
-    bool coords_as_value = false;      // render the vertices themselves (reverse_proj) although values are stored
-    // per-render state (sized on first use)
-    int w = 0, h = 0;
-    unsigned long long *vis = nullptr;
-    float *image = nullptr;
-    WorkItem *queue = nullptr;
-    unsigned qcap = 0;
-    unsigned *gqueue = nullptr;        // general queue: triangle ids set aside by raster_grid_kernel
-    unsigned gcap = 0;
-    unsigned *qcount_dev = nullptr;    // [0] work items, [1] general-queue entries
-    unsigned *qcount_host = nullptr;   // pinned copy of the two counters of the last frame
-    bool unchecked = false;            // last frame enqueued, its queue counters not yet checked (finish_frame)
-    View last_v;
-    RemapCoef last_rc;
-    double last_min_distance = 0;
-    bool rendered = false;
-    // reverse_proj compaction scratch
-    unsigned *compact_counts = nullptr;
-    unsigned long long *compact_offsets = nullptr;
-    int compact_cap = 0;
-    int64_t valid_total = -1;
-};
-
-namespace {
+namespace alp {
 
 int upload_chunked(void *dst, const void *src, size_t bytes) {
     const size_t CH = (size_t)256 << 20;
@@ -1151,19 +1050,6 @@ int upload_chunked(void *dst, const void *src, size_t bytes) {
         ALP_HIP(hipMemcpyAsync((char *)dst + off, (const char *)src + off, n, hipMemcpyHostToDevice, ctx().stream));
     }
     ALP_HIP(hipStreamSynchronize(ctx().stream));
-    return ALP_OK;
-}
-
-int ensure_frame(alp_mesh *m, int w, int h) {
-    if (m->w == w && m->h == h && m->vis) return ALP_OK;
-    if (m->vis) hipFree(m->vis);
-    if (m->image) hipFree(m->image);
-    m->vis = nullptr;
-    m->image = nullptr;
-    ALP_HIP(hipMalloc((void **)&m->vis, (size_t)w * h * sizeof(unsigned long long)));
-    ALP_HIP(hipMalloc((void **)&m->image, (size_t)w * h * 3 * sizeof(float)));
-    m->w = w;
-    m->h = h;
     return ALP_OK;
 }
 
@@ -1192,6 +1078,23 @@ int ensure_gqueue(alp_mesh *m, unsigned cap) {
     m->gqueue = nullptr;
     ALP_HIP(hipMalloc((void **)&m->gqueue, (size_t)cap * sizeof(unsigned)));
     m->gcap = cap;
+    return ALP_OK;
+}
+
+}  // namespace alp
+
+namespace {
+
+int ensure_frame(alp_mesh *m, int w, int h) {
+    if (m->w == w && m->h == h && m->vis) return ALP_OK;
+    if (m->vis) hipFree(m->vis);
+    if (m->image) hipFree(m->image);
+    m->vis = nullptr;
+    m->image = nullptr;
+    ALP_HIP(hipMalloc((void **)&m->vis, (size_t)w * h * sizeof(unsigned long long)));
+    ALP_HIP(hipMalloc((void **)&m->image, (size_t)w * h * 3 * sizeof(float)));
+    m->w = w;
+    m->h = h;
     return ALP_OK;
 }
 
@@ -1539,145 +1442,6 @@ int alp_distort_image(const float *img, int64_t h, int64_t w, int64_t c, const d
     if (e == hipSuccess) e = hipStreamSynchronize(ctx().stream);
     hipFree(dev);
     if (e != hipSuccess) return fail(ALP_EHIP, "alp_distort_image: %s", hipGetErrorString(e));
-    return ALP_OK;
-}
-
-int alp_mesh_set_value_source(alp_mesh_t *m, int source) {
-    if (int rc = require_init()) return rc;
-    ALP_REQUIRE(m, "mesh handle is NULL");
-    ALP_REQUIRE(source == ALP_VALUE_STORED || source == ALP_VALUE_VERTICES, "source must be ALP_VALUE_STORED or ALP_VALUE_VERTICES");
-    m->coords_as_value = source == ALP_VALUE_VERTICES;
-    return ALP_OK;
-}
-
-int alp_mesh_set_valid(alp_mesh_t *m, const uint8_t *valid) {
-    if (int rc = require_init()) return rc;
-    ALP_REQUIRE(m, "mesh handle is NULL");
-    if (!valid) {
-        if (m->valid) hipFree(m->valid);
-        m->valid = nullptr;
-        return ALP_OK;
-    }
-    if (!m->valid) ALP_HIP(hipMalloc((void **)&m->valid, (size_t)m->n_vert));
-    return upload_chunked(m->valid, valid, (size_t)m->n_vert);
-}
-
-int alp_mesh_from_rasters(const void *dsm, int dsm_dtype, int64_t rows, int64_t cols, const double transform[6],
-                          double z_max, const void *aerial, int aerial_dtype, double color_div,
-                          const uint8_t *nodata, double offsets_out[3], alp_mesh_t **out) {
-    if (int rc = require_init()) return rc;
-    ALP_REQUIRE(out, "out is NULL");
-    *out = nullptr;
-    ALP_REQUIRE(dsm && aerial && transform && offsets_out, "NULL argument");
-    ALP_REQUIRE(dsm_dtype == ALP_F32 || dsm_dtype == ALP_F64, "dsm_dtype must be ALP_F32 or ALP_F64");
-    ALP_REQUIRE(aerial_dtype == ALP_F32 || aerial_dtype == ALP_U8 || aerial_dtype == ALP_U16,
-                "aerial_dtype must be ALP_U8, ALP_U16 or ALP_F32");
-    ALP_REQUIRE(rows >= 2 && cols >= 2, "the raster needs at least 2 x 2 cells");
-    ALP_REQUIRE(rows * cols < ((int64_t)1 << 31), "more than 2^31 vertices");
-    ALP_REQUIRE(z_max >= 0, "z_max is negative");
-    const int64_t n = rows * cols;
-    alp_mesh *m = new alp_mesh();
-    m->n_vert = n;
-    m->grid_h = rows;
-    m->grid_w = cols;
-    m->n_tri = 2 * (rows - 1) * (cols - 1);
-    m->implicit = true;
-    int rc = ALP_OK;
-    void *dsm_dev = nullptr, *aer_dev = nullptr;
-    unsigned char *nod_dev = nullptr;
-    unsigned long long *zmin_dev = nullptr;
-    auto bail = [&](int code) {
-        for (void *p : {dsm_dev, aer_dev, (void *)nod_dev, (void *)zmin_dev})
-            if (p) hipFree(p);
-        alp_mesh_destroy(m);
-        return code;
-    };
-    const size_t zsize = dsm_dtype == ALP_F32 ? 4 : 8;
-    const size_t asize = aerial_dtype == ALP_U8 ? 1 : aerial_dtype == ALP_U16 ? 2 : 4;
-    if (hipMalloc(&dsm_dev, (size_t)n * zsize) != hipSuccess || hipMalloc(&aer_dev, (size_t)n * 3 * asize) != hipSuccess ||
-        hipMalloc((void **)&zmin_dev, 8) != hipSuccess || hipMalloc((void **)&m->vert, (size_t)n * 12) != hipSuccess ||
-        hipMalloc((void **)&m->value, (size_t)n * 12) != hipSuccess || hipMalloc((void **)&m->valid, (size_t)n) != hipSuccess ||
-        (nodata && hipMalloc((void **)&nod_dev, (size_t)n) != hipSuccess))
-        return bail(fail(ALP_EHIP, "alp_mesh_from_rasters: hipMalloc"));
-    if ((rc = upload_chunked(dsm_dev, dsm, (size_t)n * zsize))) return bail(rc);
-    if ((rc = upload_chunked(aer_dev, aerial, (size_t)n * 3 * asize))) return bail(rc);
-    if (nodata && (rc = upload_chunked(nod_dev, nodata, (size_t)n))) return bail(rc);
-    hipStream_t st = ctx().stream;
-    // offsets = vert.min(axis=0) (surface.py:211): x and y from the two coordinate vectors on the
-    // host (same float64 mul + add), z by a device reduction
-    double ox = __builtin_inf(), oy = __builtin_inf();
-    for (int64_t c = 0; c < cols; ++c) {
-        const double x = (double)c * transform[0] + transform[2];
-        ox = x < ox ? x : ox;
-    }
-    for (int64_t r = 0; r < rows; ++r) {
-        const double y = (double)r * transform[4] + transform[5];
-        oy = y < oy ? y : oy;
-    }
-    const unsigned long long inf_bits = 0x7FF0000000000000ull;
-    hipError_t e = hipMemcpyAsync(zmin_dev, &inf_bits, 8, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) {
-        const dim3 grid((unsigned)(ctx().cu_count * 8));
-        if (dsm_dtype == ALP_F32)
-            hipLaunchKernelGGL(surface_zmin_kernel<float>, grid, dim3(256), 0, st, (const float *)dsm_dev, (long long)n, z_max, zmin_dev);
-        else
-            hipLaunchKernelGGL(surface_zmin_kernel<double>, grid, dim3(256), 0, st, (const double *)dsm_dev, (long long)n, z_max, zmin_dev);
-        e = hipGetLastError();
-    }
-    double oz = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(&oz, zmin_dev, 8, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) return bail(fail(ALP_EHIP, "alp_mesh_from_rasters: %s", hipGetErrorString(e)));
-    const dim3 grid((unsigned)((n + 255) / 256));
-#define ALP_BUILD(Z, A)                                                                                              \
-    hipLaunchKernelGGL((surface_build_kernel<Z, A>), grid, dim3(256), 0, st, (const Z *)dsm_dev, (const A *)aer_dev, \
-                       (const unsigned char *)nod_dev, (long long)rows, (long long)cols, transform[0], transform[2], \
-                       transform[4], transform[5], z_max, color_div, ox, oz, oy, m->vert, m->value, m->valid)
-    if (dsm_dtype == ALP_F32) {
-        if (aerial_dtype == ALP_U8) ALP_BUILD(float, unsigned char);
-        else if (aerial_dtype == ALP_U16) ALP_BUILD(float, unsigned short);
-        else ALP_BUILD(float, float);
-    } else {
-        if (aerial_dtype == ALP_U8) ALP_BUILD(double, unsigned char);
-        else if (aerial_dtype == ALP_U16) ALP_BUILD(double, unsigned short);
-        else ALP_BUILD(double, float);
-    }
-#undef ALP_BUILD
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) return bail(fail(ALP_EHIP, "alp_mesh_from_rasters: %s", hipGetErrorString(e)));
-    if (!nodata) {                           // nothing masked: plain grid
-        hipFree(m->valid);
-        m->valid = nullptr;
-    }
-    for (void *p : {dsm_dev, aer_dev, (void *)nod_dev, (void *)zmin_dev})
-        if (p) hipFree(p);
-    dsm_dev = aer_dev = nullptr;
-    nod_dev = nullptr;
-    zmin_dev = nullptr;
-    if (hipMalloc((void **)&m->qcount_dev, 2 * sizeof(unsigned)) != hipSuccess ||
-        hipHostMalloc((void **)&m->qcount_host, 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess)
-        return bail(fail(ALP_EHIP, "hipMalloc queue counter"));
-    if ((rc = ensure_queue(m, initial_queue_cap()))) return bail(rc);
-    if ((rc = ensure_gqueue(m, initial_queue_cap()))) return bail(rc);
-    offsets_out[0] = ox;                     // X, Z, Y like `vert` (surface.py:189)
-    offsets_out[1] = oz;
-    offsets_out[2] = oy;
-    *out = m;
-    return ALP_OK;
-}
-
-int alp_mesh_fetch(alp_mesh_t *m, float *vert, float *value, uint8_t *valid) {
-    if (int rc = require_init()) return rc;
-    ALP_REQUIRE(m, "mesh handle is NULL");
-    hipStream_t st = ctx().stream;
-    if (vert) ALP_HIP(hipMemcpyAsync(vert, m->vert, (size_t)m->n_vert * 12, hipMemcpyDeviceToHost, st));
-    if (value) ALP_HIP(hipMemcpyAsync(value, m->value ? m->value : m->vert, (size_t)m->n_vert * 12, hipMemcpyDeviceToHost, st));
-    if (valid) {
-        if (m->valid) ALP_HIP(hipMemcpyAsync(valid, m->valid, (size_t)m->n_vert, hipMemcpyDeviceToHost, st));
-        else memset(valid, 1, (size_t)m->n_vert);
-    }
-    ALP_HIP(hipStreamSynchronize(st));
     return ALP_OK;
 }
 

@@ -1,0 +1,59 @@
+// Shared between the render translation units (alp_raster.hip: rasterisation, resolve, frame
+// post-processing; alp_mesh.hip: mesh construction from rasters and mesh-level accessors).
+#pragma once
+#include "alp_internal.h"
+
+namespace alp {
+
+struct View {
+    float R[3][3];
+    float camf[3], caml[3];
+    float fx, fy, sx, sy;
+    int w, h;
+    double fxd, fyd;
+};
+
+struct RemapCoef {     // inverted coefficients of project.py:136-137, float64
+    double a1, a2, k1, k2, k3, k4, k5, k6, p1, p2, s1, s2, s3, s4, c0, c1;
+};
+
+struct WorkItem { unsigned tri; unsigned short sub, tx, ty, pad; };   // sub: fan triangle 0/1
+
+}  // namespace alp
+
+struct alp_mesh {
+    int64_t n_vert = 0, n_tri = 0, grid_h = 0, grid_w = 0;
+    bool implicit = false;
+    float *vert = nullptr, *value = nullptr;
+    int *ind = nullptr;
+    unsigned char *valid = nullptr;    // optional, per vertex: 0 = nodata, its triangles are not drawn
+    bool coords_as_value = false;      // render the vertices themselves (reverse_proj) although values are stored
+    // per-render state (sized on first use)
+    int w = 0, h = 0;
+    unsigned long long *vis = nullptr;
+    float *image = nullptr;
+    alp::WorkItem *queue = nullptr;
+    unsigned qcap = 0;
+    unsigned *gqueue = nullptr;        // general queue: triangle ids set aside by raster_grid_kernel
+    unsigned gcap = 0;
+    unsigned *qcount_dev = nullptr;    // [0] work items, [1] general-queue entries
+    unsigned *qcount_host = nullptr;   // pinned copy of the two counters of the last frame
+    bool unchecked = false;            // last frame enqueued, its queue counters not yet checked (finish_frame)
+    alp::View last_v;
+    alp::RemapCoef last_rc;
+    double last_min_distance = 0;
+    bool rendered = false;
+    // reverse_proj compaction scratch
+    unsigned *compact_counts = nullptr;
+    unsigned long long *compact_offsets = nullptr;
+    int compact_cap = 0;
+    int64_t valid_total = -1;
+};
+
+namespace alp {
+// defined in alp_raster.hip
+int upload_chunked(void *dst, const void *src, size_t bytes);
+int ensure_queue(alp_mesh *m, unsigned cap);
+int ensure_gqueue(alp_mesh *m, unsigned cap);
+unsigned initial_queue_cap();
+}  // namespace alp
