@@ -87,3 +87,38 @@ def test_population_100m_shard_additivity(L, dsm):
     np.testing.assert_allclose(acc / N, whole, rtol=2e-6)
     assert int(np.argmin(acc)) == amin
     assert np.isfinite(whole).all()
+
+
+def test_projection_100m_every_vertex(L, dsm):
+    """the bench workload itself: all 100 M vertices projected in float32 (the fast mode) against
+    the float64 numpy oracle, chunk by chunk -- north_star tolerance 1e-5 relative to
+    max(|ref|, image width); float64 mode on one chunk at 1e-9; projecting twice is idempotent"""
+    from alproj_amd import synthetic as syn
+    n, s = dsm
+    xyz = syn.vert_to_xyz_local(s["vert"])
+    base = syn.local_params(syn.standoff_params(n), s["offsets"])
+    truth = syn.local_params(syn.perturbed(syn.standoff_params(n)), s["offsets"])
+    origin = [base["x"], base["y"], base["z"]]
+    pts = L.Points(xyz, origin, "f32")
+    pts.project(L.params_vector(truth))
+    u, v = pts.fetch(np.float32)
+    pts.project(L.params_vector(truth))
+    u2, v2 = pts.fetch(np.float32)
+    assert np.array_equal(u, u2) and np.array_equal(v, v2)
+    pts.close()
+    worst = 0.0
+    chunk = 10_000_000
+    for a in range(0, len(xyz), chunk):
+        ref = orc.project_points(xyz[a:a + chunk].astype(np.float64), truth)
+        got = np.stack([u[a:a + chunk], v[a:a + chunk]], 1).astype(np.float64)
+        err = np.abs(got - ref) / np.maximum(np.abs(ref), truth["w"])
+        worst = max(worst, float(err.max()))
+    assert worst <= 1e-5, worst
+    sub = xyz[:chunk]
+    p64 = L.Points(sub, origin, "f64")
+    p64.project(L.params_vector(truth))
+    u64, v64 = p64.fetch(np.float64)
+    p64.close()
+    ref = orc.project_points(sub.astype(np.float64), truth)
+    rel = np.abs(np.stack([u64, v64], 1) - ref) / np.maximum(np.abs(ref), 1.0)
+    assert float(rel.max()) <= 1e-9
