@@ -85,6 +85,10 @@ static void make_view(const double *p, const double *offsets, View *v, RemapCoef
     v->h = (int)h;
     v->sx = 0.5f * (float)v->w;
     v->sy = 0.5f * (float)v->h;
+    v->kx = 1.0 / (double)v->sx;
+    v->ky = 1.0 / (double)v->sy;
+    v->ifx = 1.0 / v->fxd;
+    v->ify = 1.0 / v->fyd;
     if (rc) {
         rc->a1 = 1 / p[7]; rc->a2 = 1 / p[8];
         rc->k1 = -p[9]; rc->k2 = -p[10]; rc->k3 = -p[11]; rc->k4 = -p[12]; rc->k5 = -p[13]; rc->k6 = -p[14];
@@ -867,15 +871,16 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float *__restrict__ 
                 }
                 const double A[3] = {qf[0][0], qf[0][1], qf[0][2]}, B[3] = {qf[1][0], qf[1][1], qf[1][2]},
                              C[3] = {qf[2][0], qf[2][1], qf[2][2]};
-                const double r[3] = {(((double)sx + 0.5) / v.sx - 1.0) / v.fxd,
-                                     (((double)j + 0.5) / v.sy - 1.0) / v.fyd, 1.0};
+                const double r[3] = {(((double)sx + 0.5) * v.kx - 1.0) * v.ifx,
+                                     (((double)j + 0.5) * v.ky - 1.0) * v.ify, 1.0};
                 const double e1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
                 const double pv[3] = {r[1] * e2[2] - r[2] * e2[1], r[2] * e2[0] - r[0] * e2[2], r[0] * e2[1] - r[1] * e2[0]};
                 const double det = e1[0] * pv[0] + e1[1] * pv[1] + e1[2] * pv[2];
                 const double tv[3] = {-A[0], -A[1], -A[2]};
-                const double beta = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) / det;
+                const double inv_det = 1.0 / det;      // the one division of the interpolation
+                const double beta = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) * inv_det;
                 const double qv[3] = {tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0]};
-                const double gamma = (r[0] * qv[0] + r[1] * qv[1] + r[2] * qv[2]) / det;
+                const double gamma = (r[0] * qv[0] + r[1] * qv[1] + r[2] * qv[2]) * inv_det;
                 const double alpha = 1.0 - beta - gamma;
                 bool masked = false;
                 if (min_distance > 0) {

@@ -11,6 +11,7 @@ struct View {
     float fx, fy, sx, sy;
     int w, h;
     double fxd, fyd;
+    double kx, ky, ifx, ify;     // 1/sx, 1/sy, 1/fx, 1/fy in float64 (ray of a pixel centre, resolve_kernel)
 };
 
 struct RemapCoef {     // inverted coefficients of project.py:136-137, float64

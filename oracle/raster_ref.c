@@ -49,6 +49,7 @@ typedef struct {
     float fx, fy, sx, sy;   /* 1/tan(fov/2), 1/tan(fov_y/2), w/2, h/2 */
     int w, h;
     double Rd[3][3], camd[3], fxd, fyd;
+    double kx, ky, ifx, ify;     /* 1/sx, 1/sy, 1/fx, 1/fy in float64: the ray of a pixel centre without divisions */
 } view_t;
 
 static void setup_view(const double *p, const double *offsets, view_t *v) {
@@ -86,10 +87,14 @@ static void setup_view(const double *p, const double *offsets, view_t *v) {
     v->fyd = 1 / tan(fov_y / 2);
     v->fx = (float)v->fxd;
     v->fy = (float)v->fyd;
+    v->ifx = 1.0 / v->fxd;
+    v->ify = 1.0 / v->fyd;
     v->w = (int)w;
     v->h = (int)h;
     v->sx = 0.5f * (float)v->w;
     v->sy = 0.5f * (float)v->h;
+    v->kx = 1.0 / (double)v->sx;
+    v->ky = 1.0 / (double)v->sy;
 }
 
 static void to_view(const view_t *v, const float *p, float out[3]) {
@@ -298,15 +303,16 @@ static void shade(const view_t *v, const float *vert, const float *value, const 
     for (int k = 0; k < 3; ++k) to_view(v, vert + 3 * idx[k], qf[k]);
     for (int c = 0; c < 3; ++c) { A[c] = qf[0][c]; B[c] = qf[1][c]; C[c] = qf[2][c]; }
     /* ray through the pixel centre: direction r = (xn/fx, yn/fy, 1), xn = (i+0.5)/sx - 1 */
-    const double r[3] = {(((double)i + 0.5) / v->sx - 1.0) / v->fxd, (((double)j + 0.5) / v->sy - 1.0) / v->fyd, 1.0};
+    const double r[3] = {(((double)i + 0.5) * v->kx - 1.0) * v->ifx, (((double)j + 0.5) * v->ky - 1.0) * v->ify, 1.0};
     /* solve A + beta (B-A) + gamma (C-A) = t r  (Cramer) */
     const double e1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
     const double pv[3] = {r[1] * e2[2] - r[2] * e2[1], r[2] * e2[0] - r[0] * e2[2], r[0] * e2[1] - r[1] * e2[0]};
     const double det = e1[0] * pv[0] + e1[1] * pv[1] + e1[2] * pv[2];
     const double tv[3] = {-A[0], -A[1], -A[2]};
-    const double beta = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) / det;
+    const double inv_det = 1.0 / det;      /* the one division of the interpolation */
+    const double beta = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) * inv_det;
     const double qv[3] = {tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0]};
-    const double gamma = (r[0] * qv[0] + r[1] * qv[1] + r[2] * qv[2]) / det;
+    const double gamma = (r[0] * qv[0] + r[1] * qv[1] + r[2] * qv[2]) * inv_det;
     const double alpha = 1.0 - beta - gamma;
     if (min_distance > 0) {
         const double dA = sqrt(A[0] * A[0] + A[1] * A[1] + A[2] * A[2]);
