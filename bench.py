@@ -374,6 +374,8 @@ def main():
         out["speedup_vs_cpu_baseline"] = gpts / out["cpu_baseline"]["value"]
 
     pts.close()
+    ctl.barrier()            # every rank has finished its collectives
+    adist.shutdown()         # ncclCommDestroy (no-op without a communicator)
     ctl.close()
     if ctl.rank == 0:
         print(json.dumps(out))
