@@ -40,8 +40,8 @@ EVAL_FLOPS = 77            # flop per point-candidate evaluation (Huber): 30 fma
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--vertices", type=int, default=100_000_000)
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--pop", type=int, default=2048)
