@@ -365,11 +365,14 @@ __device__ __forceinline__ void load_view_tri(const View &v, const float *__rest
 // its bounding box)
 __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 
+#ifndef FAST_MAX
+#define FAST_MAX 4           // cells whose box holds at most FAST_MAX x FAST_MAX pixel centres take the cell fast path
+#endif
 #ifndef COOP_MIN_W
-#define COOP_MIN_W 4        // bounding boxes at least this many pixel columns wide go to coop_raster
+#define COOP_MIN_W 3        // bounding boxes at least this many pixel columns wide go to coop_raster
 #endif
 #ifndef COOP_MIN_PIX
-#define COOP_MIN_PIX 16     // ... if they also hold at least this many pixel centres
+#define COOP_MIN_PIX 9      // ... if they also hold at least this many pixel centres
 #endif
 
 // A triangle parked by emit_snapped for coop_raster (the whole wave rasterises it together).
@@ -700,13 +703,14 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
         if (i0 > i1 || j0 > j1 || i1 < 0 || j1 < 0 || i0 > v.w - 1 || j0 > v.h - 1) work = false;
         const int ci0 = max(i0, 0), ci1 = min(i1, v.w - 1), cj0 = max(j0, 0), cj1 = min(j1, v.h - 1);
         const int nx = ci1 - ci0 + 1, ny = cj1 - cj0 + 1;
-        if (work && nx <= 2 && ny <= 2) {
-            // Far and middle field: the cell's box holds at most 2 x 2 pixel centres.  Both triangles
-            // (a, b, c), (a, c, d) are decided at those centres at once: five edge functions
-            // e(P->Q)(p) = (Q - P) x (p - P) instead of two 3-edge set-ups (the diagonal is shared,
-            // e(a->c) = -e(c->a) exactly), stepped by whole pixels -- the same integers, tie rule and
-            // depth expression as emit_small.  A triangle with area <= 0 can never have all three
-            // biased values >= 0, and a centre outside a triangle's own box is outside the triangle.
+        if (work && nx <= FAST_MAX && ny <= FAST_MAX) {
+            // Far and middle field: the cell's box holds at most FAST_MAX x FAST_MAX pixel centres.
+            // Both triangles (a, b, c), (a, c, d) are decided at those centres at once: five edge
+            // functions e(P->Q)(p) = (Q - P) x (p - P) instead of two 3-edge set-ups (the diagonal is
+            // shared, e(a->c) = -e(c->a) exactly), stepped by whole pixels -- the same integers, tie
+            // rule and depth expression as emit_small.  A triangle with area <= 0 can never have all
+            // three biased values >= 0, and a centre outside a triangle's own box is outside the
+            // triangle.  The loops run to the largest box among the wave's cells.
             work = false;
             const int px = ci0 * SUB + SUB / 2, py = cj0 * SUB + SUB / 2;
             const int2 a = P[0], b = P[1], cc = P[2], d = P[3];
@@ -717,46 +721,46 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
             int ey[6] = {cc.y - b.y, a.y - cc.y, b.y - a.y, d.y - cc.y, a.y - d.y, 0};
             ex[5] = -ex[1];
             ey[5] = -ey[1];
-            int bs[6], w[6];
-            w[0] = mul24(ex[0], pby) - mul24(ey[0], pbx);
-            w[1] = mul24(ex[1], pcy) - mul24(ey[1], pcx);
-            w[2] = mul24(ex[2], pay) - mul24(ey[2], pax);
-            w[3] = mul24(ex[3], pcy) - mul24(ey[3], pcx);
-            w[4] = mul24(ex[4], pdy) - mul24(ey[4], pdx);
-            w[5] = -w[1];
-            const int area0 = w[0] + w[1] + w[2], area1 = w[3] + w[4] + w[5];
+            int bs[6], row[6];
+            row[0] = mul24(ex[0], pby) - mul24(ey[0], pbx);
+            row[1] = mul24(ex[1], pcy) - mul24(ey[1], pcx);
+            row[2] = mul24(ex[2], pay) - mul24(ey[2], pax);
+            row[3] = mul24(ex[3], pcy) - mul24(ey[3], pcx);
+            row[4] = mul24(ex[4], pdy) - mul24(ey[4], pdx);
+            row[5] = -row[1];
+            const int area0 = row[0] + row[1] + row[2], area1 = row[3] + row[4] + row[5];
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 // the edge owns its boundary iff dy < 0 or (dy == 0 and dx > 0) iff (dy << 12) - dx < 0
-                // (|dx| < 2^12 here: the cell's box spans at most three pixels)
+                // (|dx| < 2^12 here: the cell's box spans at most FAST_MAX + 1 pixels)
                 bs[k] = 1 + (((ey[k] << 12) - ex[k]) >> 31);
-                w[k] -= bs[k];
+                row[k] -= bs[k];
             }
             const float iwa = s_iw[ia], iwb = s_iw[ib], iwc = s_iw[ic], iwd = s_iw[id];
             const float inv0 = 1.0f / (float)area0, inv1 = 1.0f / (float)area1;      // used only where area > 0
             const unsigned long long lo0 = 0xFFFFFFFFu - 2u * cell, lo1 = lo0 - 1u;
+            for (int j = cj0; j <= cj1; ++j) {
+                int u[6];
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-#pragma unroll
-                for (int ii = 0; ii < 2; ++ii) {
-                    if (ii < nx && jj < ny) {
-                        int u[6];
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) u[k] = w[k] - ii * ey[k] * SUB + jj * ex[k] * SUB;
-                        if ((u[0] | u[1] | u[2]) >= 0) {      // weights: edge k is opposite vertex k of (a, b, c)
-                            const float q = __builtin_fmaf((float)(u[2] + bs[2]), iwc,
-                                                           __builtin_fmaf((float)(u[1] + bs[1]), iwb,
-                                                                          (float)(u[0] + bs[0]) * iwa)) * inv0;
-                            vis_max(vis, v, ci0 + ii, cj0 + jj, ((unsigned long long)__float_as_uint(q) << 32) | lo0);
-                        }
-                        if ((u[3] | u[4] | u[5]) >= 0) {      // (a, c, d)
-                            const float q = __builtin_fmaf((float)(u[5] + bs[5]), iwd,
-                                                           __builtin_fmaf((float)(u[4] + bs[4]), iwc,
-                                                                          (float)(u[3] + bs[3]) * iwa)) * inv1;
-                            vis_max(vis, v, ci0 + ii, cj0 + jj, ((unsigned long long)__float_as_uint(q) << 32) | lo1);
-                        }
+                for (int k = 0; k < 6; ++k) u[k] = row[k];
+                for (int i = ci0; i <= ci1; ++i) {
+                    if ((u[0] | u[1] | u[2]) >= 0) {      // weights: edge k is opposite vertex k of (a, b, c)
+                        const float q = __builtin_fmaf((float)(u[2] + bs[2]), iwc,
+                                                       __builtin_fmaf((float)(u[1] + bs[1]), iwb,
+                                                                      (float)(u[0] + bs[0]) * iwa)) * inv0;
+                        vis_max(vis, v, i, j, ((unsigned long long)__float_as_uint(q) << 32) | lo0);
                     }
+                    if ((u[3] | u[4] | u[5]) >= 0) {      // (a, c, d)
+                        const float q = __builtin_fmaf((float)(u[5] + bs[5]), iwd,
+                                                       __builtin_fmaf((float)(u[4] + bs[4]), iwc,
+                                                                      (float)(u[3] + bs[3]) * iwa)) * inv1;
+                        vis_max(vis, v, i, j, ((unsigned long long)__float_as_uint(q) << 32) | lo1);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) u[k] -= ey[k] * SUB;
                 }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) row[k] += ex[k] * SUB;
             }
         }
     }
