@@ -242,7 +242,9 @@ template <> struct PopCfg<double> : PopCfgT<double, 2, 128, 1> {};
 // (perspective) + 3 (x^2, y^2, r2) + 4 fma (radial numerator/denominator polynomials) + 4 fma
 // (+1, +1+a1, +1, +1+a2) + 13 (tangential/prism terms with shared 2p1xy and 2p2r2, ratios) +
 // 4 (residuals, squared distance) + 4 (Huber as 0.5 c (2r - c), c = min(r, f), fused into the
-// accumulation) = 43 full-rate + 4 quarter-rate (1/Z, two denominators, sqrt).
+// accumulation) = 43 full-rate + 4 quarter-rate (1/Z, two denominators, sqrt) in float64; the
+// float32 form shares ONE reciprocal between the two denominators (3 multiplies instead of a
+// quarter-rate v_rcp_f32) and folds 2 p2 r2 into the thin-prism Horner form: 45 + 3.
 // normalised, centred image coordinates of V points for the pose in rows 0..11 of r
 template <typename T, int V>
 struct NormCoords {
@@ -305,19 +307,34 @@ __device__ __forceinline__ T group_loss_sum(const T *r, const T (&qx)[V], const 
     }
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-        dx[j] = N::rcp(dx[j]);
-        dy[j] = N::rcp(dy[j]);
+        if constexpr (sizeof(T) == 4) {
+            // one quarter-rate reciprocal for both denominators: 1/dx = dy / (dx dy), 1/dy = dx / (dx dy)
+            const T inv = N::rcp(dx[j] * dy[j]);
+            const T idx = dy[j] * inv;
+            dy[j] = dx[j] * inv;
+            dx[j] = idx;
+        } else {
+            dx[j] = N::rcp(dx[j]);
+            dy[j] = N::rcp(dy[j]);
+        }
     }
 #pragma unroll
     for (int j = 0; j < V; ++j) {
         // x1_d = x1 num/den + 2 p1 x y + 2 p2 r2 x^2 + r2 (s1 + s2 r2)   (optimize.py:112-116, Q1)
         const T t1 = r[20] * (x1[j] * y1[j]);             // 2 p1 x y       (shared by x and y)
-        const T pp = r[21] * r2[j];                       // 2 p2 r2        (shared)
-        T a = N::fma(pp, xx[j], t1);
-        a = N::fma(N::fma(r[23], r2[j], r[22]), r2[j], a);
+        T a, b;
+        if constexpr (sizeof(T) == 4) {
+            // r2 (2 p2 x^2 + s1 + s2 r2) + t1: one multiply fewer per coordinate pair
+            a = N::fma(r2[j], N::fma(r[21], xx[j], N::fma(r[23], r2[j], r[22])), t1);
+            b = N::fma(r2[j], N::fma(r[21], yy[j], N::fma(r[25], r2[j], r[24])), t1);
+        } else {
+            const T pp = r[21] * r2[j];                   // 2 p2 r2        (shared)
+            a = N::fma(pp, xx[j], t1);
+            a = N::fma(N::fma(r[23], r2[j], r[22]), r2[j], a);
+            b = N::fma(pp, yy[j], t1);
+            b = N::fma(N::fma(r[25], r2[j], r[24]), r2[j], b);
+        }
         a = N::fma(x1[j], nx[j] * dx[j], a);
-        T b = N::fma(pp, yy[j], t1);
-        b = N::fma(N::fma(r[25], r2[j], r[24]), r2[j], b);
         b = N::fma(y1[j], ny[j] * dy[j], b);
         // pixels u = a c0 + c0 (optimize.py:117-118): residual uo - u = (uo - c0) - c0 a
         const T du = N::fma(a, r[28], uoc[j]);
