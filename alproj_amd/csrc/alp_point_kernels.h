@@ -220,16 +220,18 @@ template <typename T> struct PopCfg;
 // Measured on MI355X (tools/popeval_lab.hip, 10 M points x 256 candidates, Huber):
 //   V=1 TC=256 4 wg/CU 512 Gevals/s | V=4 TC=256 4 wg/CU 699 | V=8 TC=256 4 wg/CU 693
 //   V=4 TC=128 8 wg/CU 736          | V=8 TC=128 6 wg/CU 744 | V=16 TC=256 2 wg/CU 549
+// After the reciprocal / Horner trims (45 + 3 instructions) on the library kernel, 100 M x 2048:
+//   V=3 251 ms | V=4 238.5 | V=5 234.1 | V=6 231.6 (230.0 with 4 waves/SIMD asked for) | V=7 -- (123 VGPRs) | V=8 241.2
 // The bare arithmetic of group_losses (no LDS, no reduction; tools/eval_rate.hip) runs at
 // 780-880 Gevals/s: ~50 VALU instructions of which 4 are quarter-rate v_rcp/v_sqrt.
 // Reading the records with scalar loads straight from global memory (s_load_dwordx16, SGPR
 // operands, no LDS tile) measured 709-718 against 732 Gevals/s for the LDS tile, V=8 on top of
 // it 679.
 #ifndef POP_V
-#define POP_V 4
+#define POP_V 6
 #endif
 #ifndef POP_MINW
-#define POP_MINW 2
+#define POP_MINW 4
 #endif
 template <> struct PopCfg<float> : PopCfgT<float, POP_V, 128, POP_MINW> {};
 template <> struct PopCfg<double> : PopCfgT<double, 2, 128, 1> {};
@@ -438,6 +440,9 @@ __global__ __launch_bounds__(256, Cfg::MINW) void popeval_kernel(
         const PoseRec<T> *recs = s_c;
         for (; base + 256 * V <= end; base += 256 * V)
             pop_group<T, LOSS, V, false, SHARED_POSE>(x, y, z, uo, vo, base, end, recs, s_sum[wave], tc, f_scale, half_f2);
+        if constexpr (V > 2)       // the rows left over by the wide groups, two at a time
+            for (; base + 512 <= end; base += 512)
+                pop_group<T, LOSS, 2, false, SHARED_POSE>(x, y, z, uo, vo, base, end, recs, s_sum[wave], tc, f_scale, half_f2);
         for (; base < end; base += 256)
             pop_group<T, LOSS, 1, true, SHARED_POSE>(x, y, z, uo, vo, base, end, recs, s_sum[wave], tc, f_scale, half_f2);
         __syncthreads();
