@@ -222,6 +222,7 @@ template <typename T> struct PopCfg;
 //   V=4 TC=128 8 wg/CU 736          | V=8 TC=128 6 wg/CU 744 | V=16 TC=256 2 wg/CU 549
 // After the reciprocal / Horner trims (45 + 3 instructions) on the library kernel, 100 M x 2048:
 //   V=3 251 ms | V=4 238.5 | V=5 234.1 | V=6 231.6 (230.0 with 4 waves/SIMD asked for) | V=7 -- (123 VGPRs) | V=8 241.2
+//   candidate tile at V=6: TC=64 230.2 | TC=128 229.3 | TC=256 246.9
 // The bare arithmetic of group_losses (no LDS, no reduction; tools/eval_rate.hip) runs at
 // 780-880 Gevals/s: ~50 VALU instructions of which 4 are quarter-rate v_rcp/v_sqrt.
 // Reading the records with scalar loads straight from global memory (s_load_dwordx16, SGPR
@@ -233,7 +234,10 @@ template <typename T> struct PopCfg;
 #ifndef POP_MINW
 #define POP_MINW 4
 #endif
-template <> struct PopCfg<float> : PopCfgT<float, POP_V, 128, POP_MINW> {};
+#ifndef POP_TC
+#define POP_TC 128
+#endif
+template <> struct PopCfg<float> : PopCfgT<float, POP_V, POP_TC, POP_MINW> {};
 template <> struct PopCfg<double> : PopCfgT<double, 2, 128, 1> {};
 
 // Sum of the losses of V points against one pose record r (wave-uniform).  uoc/voc are the
