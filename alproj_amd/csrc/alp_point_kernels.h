@@ -238,7 +238,10 @@ template <typename T> struct PopCfg;
 #define POP_TC 128
 #endif
 template <> struct PopCfg<float> : PopCfgT<float, POP_V, POP_TC, POP_MINW> {};
-template <> struct PopCfg<double> : PopCfgT<double, 2, 128, 1> {};
+#ifndef POP_VD
+#define POP_VD 3
+#endif
+template <> struct PopCfg<double> : PopCfgT<double, POP_VD, 128, 1> {};
 
 // Sum of the losses of V points against one pose record r (wave-uniform).  uoc/voc are the
 // observed pixels minus the image centre (c0, c1 are the same for every candidate of a call:
