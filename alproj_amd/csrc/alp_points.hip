@@ -161,10 +161,19 @@ int enqueue_popeval(alp_points *p, const double *cand, int64_t P, int loss_kind,
                                popeval_kernel<T, ALP_LOSS_MEAN_DIST, PopCfg<T>, true>,
                                popeval_kernel<T, ALP_LOSS_HUBER, PopCfg<T>, false>,
                                popeval_kernel<T, ALP_LOSS_HUBER, PopCfg<T>, true>};
-    // grid of 8 (float) / 4 (double) workgroups per CU, each with an equal stripe of the points.
-    // Registers let 5 float workgroups run per CU at once; sizing the grid to exactly that
-    // (hipOccupancyMaxActiveBlocksPerMultiprocessor) measured no faster: 728 vs 741 Gevals/s
-    int nblk = ctx().cu_count * (sizeof(T) == 4 ? 8 : 4);
+    // one workgroup per stripe of ~24 rows of 256 points (four groups of V = 6), between 4 and 64
+    // workgroups per CU: a stripe is re-read once per tile of 128 candidates and a short one stays
+    // in cache between those passes.  Measured, 100 M x 2048 float32: 4 workgroups per CU 244 ms,
+    // 8: 229, 16: 224, 32: 221, 64: 219, 128: 219; 10 M x 256: 8 per CU (stripes of 19 rows) 3.31
+    // ms, 16: 3.46, 32: 3.73.  float64 keeps 4 per CU.
+    int nblk = ctx().cu_count * 4;
+    if (sizeof(T) == 4) {
+        const int64_t want = ((p->n + 255) / 256 + 23) / 24;
+        const int64_t lo = (int64_t)ctx().cu_count * 4, hi = (int64_t)ctx().cu_count * 64;
+        // whole rounds of the 4 workgroups a CU holds at once while the grid is only a few rounds deep
+        const int64_t rounded = (want + lo - 1) / lo * lo;
+        nblk = (int)(want < lo ? lo : (want > hi ? hi : (want < 4 * lo ? rounded : want)));
+    }
     const int64_t rows = (p->n + 255) / 256;
     if (rows < nblk) nblk = (int)(rows > 0 ? rows : 1);
     if (int rc = ensure_pop_scratch(p, P, nblk)) return rc;
