@@ -766,6 +766,7 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
             }
         }
     }
+    if (!__ballot(work)) return;          // the whole wave is done (the usual case in the far field)
     // triangles of the cell (surface.py:194-201): (a, b, c) and (a, c, d)
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
