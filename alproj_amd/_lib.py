@@ -51,6 +51,7 @@ _SIGNATURES = {
     "alp_comm_init": [ctypes.c_char_p, _c_int, _c_int],
     "alp_comm_destroy": [],
     "alp_comm_info": [ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)],
+    "alp_comm_bcast": [_c_void_p, _c_i64, _c_int],
     "alp_points_create": [_c_void_p, _c_int, _c_i64, _c_dp, _c_int, ctypes.POINTER(_c_void_p)],
     "alp_points_destroy": [_c_void_p],
     "alp_points_count": [_c_void_p, ctypes.POINTER(_c_i64)],
@@ -76,6 +77,7 @@ _SIGNATURES = {
     "alp_mesh_from_rasters": [_c_void_p, _c_int, _c_i64, _c_i64, _c_dp, ctypes.c_double, _c_void_p, _c_int,
                               ctypes.c_double, ctypes.POINTER(ctypes.c_uint8), _c_dp, ctypes.POINTER(_c_void_p)],
     "alp_mesh_fetch": [_c_void_p, _c_fp, _c_fp, ctypes.POINTER(ctypes.c_uint8)],
+    "alp_render_load": [_c_void_p, _c_fp, _c_i64, _c_i64],
     "alp_render_valid_count": [_c_void_p, ctypes.POINTER(_c_i64)],
     "alp_render_fetch_valid": [_c_void_p, _c_dp, ctypes.POINTER(ctypes.c_uint32), _c_dp],
     "alp_render_gather": [_c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), _c_i64, _c_dp,
@@ -83,6 +85,7 @@ _SIGNATURES = {
     "alp_rasterize_points": [_c_dp, _c_dp, _c_dp, _c_i64, _c_i64, _c_double, _c_double, _c_double, _c_i64, _c_i64,
                              _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_uint8)],
     "alp_distort_image": [_c_fp, _c_i64, _c_i64, _c_i64, _c_dp, _c_fp],
+    "alp_distort_map": [_c_i64, _c_i64, _c_dp, _c_fp, _c_fp],
 }
 _RESTYPE = {"alp_last_error": ctypes.c_char_p}
 
@@ -141,7 +144,13 @@ def device_info():
 
 def params_vector(params):
     """dict -> float64[25] in ABI order (raises KeyError on a missing key like the reference)."""
-    return np.array([float(params[k]) for k in PARAM_KEYS], dtype=np.float64)
+    out = np.array([0.0 if params[k] is None else float(params[k]) for k in PARAM_KEYS], dtype=np.float64)
+    # the reference's intrinsic_mat substitutes w/2, h/2 for cx/cy = None (optimize.py:27-30)
+    if params["cx"] is None:
+        out[23] = out[21] / 2
+    if params["cy"] is None:
+        out[24] = out[22] / 2
+    return out
 
 
 def as_dp(a):
@@ -388,6 +397,16 @@ class Mesh:
         self.render_enqueue(pvec, offsets, min_distance)
         return self.fetch()
 
+    def load_image(self, image):
+        """Install an (h, w, 3) float32 coordinate image produced elsewhere as the current frame
+        (alp_render_load): ``fetch_valid`` / ``gather`` then run on it."""
+        image = np.ascontiguousarray(image, dtype=np.float32)
+        if image.ndim != 3 or image.shape[2] != 3:
+            raise ValueError("image must have shape (h, w, 3)")
+        check(self._lib.alp_render_load(self._h, as_fp(image), image.shape[0], image.shape[1]))
+        self.generation = getattr(self, "generation", 0) + 1
+        self.shape = image.shape
+
     def fetch_valid(self, offsets=None):
         """After a render of the vertices themselves: (idx, xyz) of the pixels that see the
         surface (first channel > 0), row-major; xyz = channels (0, 2, 1) + offsets, float64."""
@@ -429,6 +448,17 @@ def distort_image(img, coeffs):
     return out
 
 
+def distort_map(h, w, coeffs):
+    """float32 (map_x, map_y) of ``distort`` for an (h, w) image (alp_distort_map)."""
+    cf = np.ascontiguousarray(coeffs, dtype=np.float64)
+    if cf.shape != (14,):
+        raise ValueError("distort_coeffs must have 14 entries")
+    mx = np.empty((int(h), int(w)), dtype=np.float32)
+    my = np.empty((int(h), int(w)), dtype=np.float32)
+    check(lib().alp_distort_map(int(h), int(w), as_dp(cf), as_fp(mx), as_fp(my)))
+    return mx, my
+
+
 def synchronize():
     check(lib().alp_synchronize())
 
@@ -453,6 +483,20 @@ def comm_init(uid, rank, world_size):
     if len(uid) != UNIQUE_ID_BYTES:
         raise ValueError("unique id must be 128 bytes")
     check(lib().alp_comm_init(uid, int(rank), int(world_size)))
+
+
+def comm_info():
+    r, w = _c_int(), _c_int()
+    check(lib().alp_comm_info(ctypes.byref(r), ctypes.byref(w)))
+    return r.value, w.value
+
+
+def comm_bcast(array, root=0):
+    """In-place broadcast of a C-contiguous numpy array from ``root`` (no-op without a communicator)."""
+    if not array.flags["C_CONTIGUOUS"]:
+        raise ValueError("array must be C-contiguous")
+    check(lib().alp_comm_bcast(array.ctypes.data_as(_c_void_p), array.nbytes, int(root)))
+    return array
 
 
 def comm_destroy():

@@ -36,6 +36,23 @@ int require_init() {
     return ALP_OK;
 }
 
+int scratch_reserve(size_t bytes, void **out) {
+    Context &c = ctx();
+    if (bytes > c.scratch_cap) {
+        if (c.scratch) {
+            ALP_HIP(hipStreamSynchronize(c.stream));
+            hipFree(c.scratch);
+        }
+        c.scratch = nullptr;
+        c.scratch_cap = 0;
+        const size_t cap = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        ALP_HIP(hipMalloc(&c.scratch, cap));
+        c.scratch_cap = cap;
+    }
+    *out = c.scratch;
+    return ALP_OK;
+}
+
 #define ALP_NCCL(expr)                                                                    \
     do {                                                                                  \
         ncclResult_t r__ = (expr);                                                        \
@@ -172,6 +189,9 @@ int alp_shutdown(void) {
     if (!c.ready) return ALP_OK;
     alp_comm_destroy();
     hipStreamSynchronize(c.stream);
+    if (c.scratch) hipFree(c.scratch);
+    c.scratch = nullptr;
+    c.scratch_cap = 0;
     for (auto &ev : c.events) {
         if (ev) hipEventDestroy(ev);
         ev = nullptr;
@@ -253,6 +273,21 @@ int alp_comm_destroy(void) {
     }
     c.rank = 0;
     c.world = 1;
+    return ALP_OK;
+}
+
+int alp_comm_bcast(void *buf, int64_t bytes, int root) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(bytes >= 0 && (bytes == 0 || buf), "bad buffer");
+    Context &c = ctx();
+    if (!c.comm || bytes == 0) return ALP_OK;
+    ALP_REQUIRE(root >= 0 && root < c.world, "root out of range");
+    void *dev = nullptr;
+    if (int rc = scratch_reserve((size_t)bytes, &dev)) return rc;
+    if (c.rank == root) ALP_HIP(hipMemcpyAsync(dev, buf, (size_t)bytes, hipMemcpyHostToDevice, c.stream));
+    ALP_NCCL(ncclBroadcast(dev, dev, (size_t)bytes, ncclChar, root, (ncclComm_t)c.comm, c.stream));
+    ALP_HIP(hipMemcpyAsync(buf, dev, (size_t)bytes, hipMemcpyDeviceToHost, c.stream));
+    ALP_HIP(hipStreamSynchronize(c.stream));
     return ALP_OK;
 }
 

@@ -36,6 +36,11 @@ struct Context {
     int cu_count = 0;
     hipStream_t stream = nullptr;
     hipEvent_t events[64] = {};
+    // grow-only device scratch shared by the entry points that stage data for ONE call and
+    // synchronise before they return (alp_residuals*, alp_loss_uv, alp_render_gather, ...): no
+    // hipMalloc / hipFree on the per-call path once it has reached its working size
+    void *scratch = nullptr;
+    size_t scratch_cap = 0;
     // RCCL
     void *comm = nullptr;   // ncclComm_t
     int rank = 0;
@@ -43,6 +48,8 @@ struct Context {
 };
 Context &ctx();
 int require_init();
+// *out = device scratch of at least `bytes` bytes (valid until the next scratch_reserve / alp_shutdown)
+int scratch_reserve(size_t bytes, void **out);
 
 // all-reduce (sum, double) of `count` doubles in place on the library stream; no-op
 // when no communicator exists.

@@ -1,6 +1,6 @@
 // Device code of the point-set path (included by alp_points.hip and by the development
 // micro-benchmarks under tools/): element-type helpers, the projection arithmetic, and the
-// kernels K1 project_kernel, K2 popeval_kernel (+ reduce_partials_kernel), K3 residual_kernel,
+// kernels K1 project_kernel, K2 popeval_kernel (+ reduce_partials_kernel), K3 residual_batch_kernel,
 // the stand-alone loss kernel and the upload helpers.
 //
 // Reference arithmetic: src/alproj/optimize.py  project :122-155, _distort :98-120,
@@ -137,22 +137,8 @@ __global__ __launch_bounds__(256) void project_kernel(const T *__restrict__ x, c
     Num<T>::nt_store(ov, v4 + i);
 }
 
-// ------------------------------------------------------------------ K3: residual vector
-// out[2i] = uo - u, out[2i+1] = vo - v  (optimize.py:233-236), float64 output.
-template <typename T>
-__global__ __launch_bounds__(256) void residual_kernel(const T *__restrict__ x, const T *__restrict__ y,
-                                                       const T *__restrict__ z, const T *__restrict__ uo,
-                                                       const T *__restrict__ vo, double2 *__restrict__ out,
-                                                       int64_t n, PoseRec<T> pose) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        T xd, yd, u, v;
-        project_norm<T>(pose.v, x[i], y[i], z[i], xd, yd);
-        to_pixels<T>(pose.v, xd, yd, u, v);
-        out[i] = make_double2((double)(uo[i] - u), (double)(vo[i] - v));
-    }
-}
-
+// ------------------------------------------------------------------ K3: residual vectors
+// out[b][2i] = uo - u_b, out[b][2i+1] = vo - v_b  (optimize.py:233-236), float64 output.
 // Residual vectors of B poses at once (finite-difference Jacobian of the least-squares path:
 // scipy's 2-point scheme needs D+1 evaluations per iteration, optimize.py:510-528).  Each point
 // is loaded once; the pose records are read with wave-uniform (scalar) loads.
@@ -375,10 +361,12 @@ __device__ __forceinline__ T group_loss_sum(const T *r, const T (&qx)[V], const 
     return acc;
 }
 
-template <typename T, int LOSS, int V, bool MASKED, bool SHARED_POSE>
-__device__ __forceinline__ void pop_group(const T *__restrict__ x, const T *__restrict__ y,
-                                          const T *__restrict__ z, const T *__restrict__ uo,
-                                          const T *__restrict__ vo, int64_t base, int64_t end,
+// TS = element type of the planes in HBM, T = arithmetic type (TS = float with T = double is the
+// float64 re-evaluation of a float32 point set: alp_eval_population's argmin confirmation)
+template <typename T, int LOSS, int V, bool MASKED, bool SHARED_POSE, typename TS = T>
+__device__ __forceinline__ void pop_group(const TS *__restrict__ x, const TS *__restrict__ y,
+                                          const TS *__restrict__ z, const TS *__restrict__ uo,
+                                          const TS *__restrict__ vo, int64_t base, int64_t end,
                                           const PoseRec<T> *s_c, double *s_sum_wave, int tc,
                                           T f_scale, T half_f2) {
     const int tid = threadIdx.x;
@@ -391,9 +379,9 @@ __device__ __forceinline__ void pop_group(const T *__restrict__ x, const T *__re
         int64_t i = base + (int64_t)j * 256 + tid;
         ok[j] = MASKED ? (i < end) : true;
         if (MASKED && !ok[j]) i = base;       // any valid point; its loss is discarded
-        qx[j] = x[i]; qy[j] = y[i]; qz[j] = z[i];
-        uoc[j] = uo[i] - c0;
-        voc[j] = vo[i] - c1;
+        qx[j] = (T)x[i]; qy[j] = (T)y[i]; qz[j] = (T)z[i];
+        uoc[j] = (T)uo[i] - c0;
+        voc[j] = (T)vo[i] - c1;
     }
     NormCoords<T, V> pre;
     if constexpr (SHARED_POSE) norm_coords<T, V>(s_c[0].v, qx, qy, qz, pre);
@@ -412,10 +400,10 @@ __device__ __forceinline__ void pop_group(const T *__restrict__ x, const T *__re
     }
 }
 
-template <typename T, int LOSS, typename Cfg = PopCfg<T>, bool SHARED_POSE = false>
+template <typename T, int LOSS, typename Cfg = PopCfg<T>, bool SHARED_POSE = false, typename TS = T>
 __global__ __launch_bounds__(256, Cfg::MINW) void popeval_kernel(
-    const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ z, const T *__restrict__ uo,
-    const T *__restrict__ vo, int64_t n, const PoseRec<T> *__restrict__ cands, int P, T f_scale,
+    const TS *__restrict__ x, const TS *__restrict__ y, const TS *__restrict__ z, const TS *__restrict__ uo,
+    const TS *__restrict__ vo, int64_t n, const PoseRec<T> *__restrict__ cands, int P, T f_scale,
     double *__restrict__ partials) {
     constexpr int TC = Cfg::TC;
     constexpr int V = Cfg::V;
@@ -446,12 +434,12 @@ __global__ __launch_bounds__(256, Cfg::MINW) void popeval_kernel(
         int64_t base = beg;
         const PoseRec<T> *recs = s_c;
         for (; base + 256 * V <= end; base += 256 * V)
-            pop_group<T, LOSS, V, false, SHARED_POSE>(x, y, z, uo, vo, base, end, recs, s_sum[wave], tc, f_scale, half_f2);
+            pop_group<T, LOSS, V, false, SHARED_POSE, TS>(x, y, z, uo, vo, base, end, recs, s_sum[wave], tc, f_scale, half_f2);
         if constexpr (V > 2)       // the rows left over by the wide groups, two at a time
             for (; base + 512 <= end; base += 512)
-                pop_group<T, LOSS, 2, false, SHARED_POSE>(x, y, z, uo, vo, base, end, recs, s_sum[wave], tc, f_scale, half_f2);
+                pop_group<T, LOSS, 2, false, SHARED_POSE, TS>(x, y, z, uo, vo, base, end, recs, s_sum[wave], tc, f_scale, half_f2);
         for (; base < end; base += 256)
-            pop_group<T, LOSS, 1, true, SHARED_POSE>(x, y, z, uo, vo, base, end, recs, s_sum[wave], tc, f_scale, half_f2);
+            pop_group<T, LOSS, 1, true, SHARED_POSE, TS>(x, y, z, uo, vo, base, end, recs, s_sum[wave], tc, f_scale, half_f2);
         __syncthreads();
         if (tid < tc)
             partials[(int64_t)blockIdx.x * P + c0 + tid] =

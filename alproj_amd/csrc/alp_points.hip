@@ -2,7 +2,7 @@
 //   project_kernel   forward projection of every point with ONE pose (HBM-bound stream)
 //   popeval_kernel   P candidate poses x every point -> per-candidate loss sums
 //                    (VALU-bound; candidates staged in LDS, wave64 DPP reductions)
-//   residual_kernel  observed - projected, interleaved (least-squares path)
+//   residual_batch_kernel  observed - projected for B poses, interleaved (least-squares path)
 //
 // Reference arithmetic: src/alproj/optimize.py  project :122-155, _distort :98-120,
 // rmse :157-178, huber_loss :181-212, compute_residuals :215-237, and the generation loop
@@ -16,6 +16,7 @@
 // whole-workgroup tiles never leave the allocation.
 #include "alp_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -43,8 +44,21 @@ struct alp_points {
     double *sums_dev = nullptr;    // cand_cap + 1
     double *sums_host = nullptr;   // pinned, cand_cap + 1
     int64_t pending_P = 0;
+    int pending_loss = 0;
+    double pending_f_scale = 0;
+    std::vector<double> cand_copy;   // the P x 25 parameter vectors of the pending call (argmin confirmation)
+    // argmin confirmation (float32 sets): float64 records, partial sums and sums of up to CONFIRM_MAX candidates
+    void *conf_dev = nullptr;
+    int conf_nblk = 0;
+    double *conf_host = nullptr;   // pinned, CONFIRM_MAX + 1
     size_t esize() const { return precision == ALP_F64 ? 8 : 4; }
 };
+
+// float32 point sets: when the smallest loss and its runner-up differ by less than CONFIRM_GAP
+// (relative) the candidates inside that band are evaluated again in float64 arithmetic before the
+// argmin is returned (north star: "argmin pose index bit-exact"; float32 losses carry ~1e-6..1e-5)
+constexpr int CONFIRM_MAX = 16;
+constexpr double CONFIRM_GAP = 5e-5;
 
 namespace {
 
@@ -139,6 +153,10 @@ int ensure_pop_scratch(alp_points *p, int64_t P, int nblk) {
 
 template <typename T>
 int enqueue_popeval(alp_points *p, const double *cand, int64_t P, int loss_kind, double f_scale) {
+    // one pinned staging buffer per handle: a second enqueue would rewrite it under the first one's
+    // asynchronous copy (and lose its result)
+    if (p->pending_P > 0)
+        return fail(ALP_ESTATE, "alp_eval_population_enqueue: the previous enqueue has not been waited for");
     if (int rc = ensure_pop_scratch(p, P, 0)) return rc;
     PoseRec<T> *h = (PoseRec<T> *)p->cand_host;
     // the kernel centres the observations once per point: every candidate of a call must share
@@ -188,6 +206,82 @@ int enqueue_popeval(alp_points *p, const double *cand, int64_t P, int loss_kind,
     ALP_HIP(hipMemcpyAsync(p->sums_host, p->sums_dev, (size_t)(P + 1) * sizeof(double),
                            hipMemcpyDeviceToHost, ctx().stream));
     p->pending_P = P;
+    p->pending_loss = loss_kind;
+    p->pending_f_scale = f_scale;
+    if (sizeof(T) == 4) p->cand_copy.assign(cand, cand + P * ALP_NPARAM);
+    return ALP_OK;
+}
+
+// float64 re-evaluation of K <= CONFIRM_MAX candidates of a float32 point set (same stored
+// coordinates, double arithmetic, same fixed-order reduction and the same all-reduce):
+// sums_out[0..K) = loss sums, sums_out[K] = vertex count.  Synchronous.
+int confirm_losses(alp_points *p, const double *cand, const int64_t *which, int K, int loss_kind, double f_scale,
+                   double *sums_out) {
+    const int nblk_want = ctx().cu_count * 4;
+    const int64_t rows = (p->n + 255) / 256;
+    const int nblk = (int)(rows < nblk_want ? (rows > 0 ? rows : 1) : nblk_want);
+    const size_t rec_bytes = (size_t)CONFIRM_MAX * sizeof(PoseRec<double>);
+    if (!p->conf_dev || p->conf_nblk < nblk) {
+        if (p->conf_dev) hipFree(p->conf_dev);
+        p->conf_dev = nullptr;
+        ALP_HIP(hipMalloc(&p->conf_dev, rec_bytes + (size_t)(nblk + 2) * CONFIRM_MAX * sizeof(double)));
+        p->conf_nblk = nblk;
+    }
+    if (!p->conf_host) ALP_HIP(hipHostMalloc((void **)&p->conf_host, (CONFIRM_MAX + 1) * sizeof(double), hipHostMallocDefault));
+    PoseRec<double> recs[CONFIRM_MAX];
+    for (int k = 0; k < K; ++k) fold_pose_t<double>(cand + which[k] * ALP_NPARAM, p->origin, &recs[k]);
+    PoseRec<double> *recs_dev = (PoseRec<double> *)p->conf_dev;
+    double *partials = (double *)((char *)p->conf_dev + rec_bytes);
+    double *sums_dev = partials + (size_t)nblk * CONFIRM_MAX;
+    ALP_HIP(hipMemcpyAsync(recs_dev, recs, (size_t)K * sizeof(PoseRec<double>), hipMemcpyHostToDevice, ctx().stream));
+    const float *x = (const float *)p->x, *y = (const float *)p->y, *z = (const float *)p->z;
+    const float *uo = (const float *)p->uo, *vo = (const float *)p->vo;
+    if (loss_kind == ALP_LOSS_HUBER)
+        hipLaunchKernelGGL((popeval_kernel<double, ALP_LOSS_HUBER, PopCfg<double>, false, float>), dim3(nblk), dim3(256), 0,
+                           ctx().stream, x, y, z, uo, vo, p->n, recs_dev, K, f_scale, partials);
+    else
+        hipLaunchKernelGGL((popeval_kernel<double, ALP_LOSS_MEAN_DIST, PopCfg<double>, false, float>), dim3(nblk), dim3(256),
+                           0, ctx().stream, x, y, z, uo, vo, p->n, recs_dev, K, f_scale, partials);
+    ALP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, ctx().stream, partials, nblk, K, (double)p->n, sums_dev);
+    ALP_HIP(hipGetLastError());
+    if (int rc = comm_allreduce_sum_f64(sums_dev, K + 1)) return rc;
+    ALP_HIP(hipMemcpyAsync(p->conf_host, sums_dev, (size_t)(K + 1) * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
+    ALP_HIP(hipStreamSynchronize(ctx().stream));      // recs (stack) must outlive the H2D copy too
+    memcpy(sums_out, p->conf_host, (size_t)(K + 1) * sizeof(double));
+    return ALP_OK;
+}
+
+// device staging of the residual entry points: at most RES_CHUNK_BYTES of output per launch
+constexpr size_t RES_CHUNK_BYTES = (size_t)256 << 20;
+
+template <typename T>
+int residuals_impl(alp_points *p, const double *cand, int64_t B, double *out) {
+    // B pose records (kernel argument for B == 1 would save the copy; one path keeps it simple)
+    const size_t rec_bytes = round_up((int64_t)(B * sizeof(PoseRec<T>)), 256);
+    int64_t chunk = (int64_t)(RES_CHUNK_BYTES / ((size_t)B * sizeof(double2)));
+    chunk = chunk / 1024 * 1024;
+    if (chunk < 1024) chunk = 1024;
+    if (chunk > p->n) chunk = p->n;
+    char *dev = nullptr;
+    if (int rc = scratch_reserve(rec_bytes + (size_t)B * chunk * sizeof(double2), (void **)&dev)) return rc;
+    PoseRec<T> *poses_dev = (PoseRec<T> *)dev;
+    double2 *res_dev = (double2 *)(dev + rec_bytes);
+    std::vector<PoseRec<T>> poses((size_t)B);
+    for (int64_t b = 0; b < B; ++b) fold_pose_t<T>(cand + b * ALP_NPARAM, p->origin, &poses[b]);
+    hipStream_t st = ctx().stream;
+    ALP_HIP(hipMemcpyAsync(poses_dev, poses.data(), (size_t)B * sizeof(PoseRec<T>), hipMemcpyHostToDevice, st));
+    for (int64_t off = 0; off < p->n; off += chunk) {
+        const int64_t cnt = p->n - off < chunk ? p->n - off : chunk;
+        hipLaunchKernelGGL(residual_batch_kernel<T>, dim3(stream_grid(cnt)), dim3(256), 0, st, (const T *)p->x + off,
+                           (const T *)p->y + off, (const T *)p->z + off, (const T *)p->uo + off, (const T *)p->vo + off,
+                           res_dev, cnt, poses_dev, (int)B);
+        ALP_HIP(hipGetLastError());
+        // row b of the chunk -> out[b][off .. off + cnt)
+        ALP_HIP(hipMemcpy2DAsync(out + 2 * off, (size_t)p->n * sizeof(double2), res_dev, (size_t)cnt * sizeof(double2),
+                                 (size_t)cnt * sizeof(double2), (size_t)B, hipMemcpyDeviceToHost, st));
+        ALP_HIP(hipStreamSynchronize(st));       // the staging buffer is reused; poses must outlive their copy
+    }
     return ALP_OK;
 }
 
@@ -234,6 +328,8 @@ int alp_points_destroy(alp_points_t *p) {
         if (q) hipFree(q);
     if (p->cand_host) hipHostFree(p->cand_host);
     if (p->sums_host) hipHostFree(p->sums_host);
+    if (p->conf_dev) hipFree(p->conf_dev);
+    if (p->conf_host) hipHostFree(p->conf_host);
     delete p;
     return ALP_OK;
 }
@@ -312,7 +408,7 @@ int alp_projected_fetch_strided(alp_points_t *p, int64_t first, int64_t stride, 
     if (count == 0) return ALP_OK;
     ALP_REQUIRE(first + (count - 1) * stride < p->n, "range exceeds the point count");
     double *tmp = nullptr;
-    ALP_HIP(hipMalloc((void **)&tmp, (size_t)count * 2 * sizeof(double)));
+    if (int rc = scratch_reserve((size_t)count * 2 * sizeof(double), (void **)&tmp)) return rc;
     const unsigned grid = (unsigned)((count + 255) / 256);
     if (p->precision == ALP_F64)
         hipLaunchKernelGGL(gather_strided_kernel<double>, dim3(grid), dim3(256), 0, ctx().stream,
@@ -324,7 +420,6 @@ int alp_projected_fetch_strided(alp_points_t *p, int64_t first, int64_t stride, 
     if (e == hipSuccess)
         e = hipMemcpyAsync(v_out, tmp + count, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx().stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx().stream);
-    hipFree(tmp);
     if (e != hipSuccess) return fail(ALP_EHIP, "strided fetch: %s", hipGetErrorString(e));
     return ALP_OK;
 }
@@ -335,27 +430,7 @@ int alp_residuals(alp_points_t *p, const double params[ALP_NPARAM], double *out)
     if (!p->uo) return fail(ALP_ESTATE, "alp_residuals: observed uv not set");
     if (p->n == 0) return ALP_OK;
     ALP_REQUIRE(out, "out is NULL");
-    double2 *dev = nullptr;
-    ALP_HIP(hipMalloc((void **)&dev, (size_t)p->n * sizeof(double2)));
-    const int grid = stream_grid(p->n);
-    if (p->precision == ALP_F64) {
-        PoseRec<double> pose;
-        fold_pose_t<double>(params, p->origin, &pose);
-        hipLaunchKernelGGL(residual_kernel<double>, dim3(grid), dim3(256), 0, ctx().stream,
-                           (const double *)p->x, (const double *)p->y, (const double *)p->z,
-                           (const double *)p->uo, (const double *)p->vo, dev, p->n, pose);
-    } else {
-        PoseRec<float> pose;
-        fold_pose_t<float>(params, p->origin, &pose);
-        hipLaunchKernelGGL(residual_kernel<float>, dim3(grid), dim3(256), 0, ctx().stream,
-                           (const float *)p->x, (const float *)p->y, (const float *)p->z,
-                           (const float *)p->uo, (const float *)p->vo, dev, p->n, pose);
-    }
-    hipError_t e = hipMemcpyAsync(out, dev, (size_t)p->n * sizeof(double2), hipMemcpyDeviceToHost, ctx().stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx().stream);
-    hipFree(dev);
-    if (e != hipSuccess) return fail(ALP_EHIP, "residuals: %s", hipGetErrorString(e));
-    return ALP_OK;
+    return p->precision == ALP_F64 ? residuals_impl<double>(p, params, 1, out) : residuals_impl<float>(p, params, 1, out);
 }
 
 int alp_residuals_batch(alp_points_t *p, const double *cand, int64_t B, double *out) {
@@ -365,36 +440,7 @@ int alp_residuals_batch(alp_points_t *p, const double *cand, int64_t B, double *
     if (!p->uo) return fail(ALP_ESTATE, "alp_residuals_batch: observed uv not set");
     if (p->n == 0) return ALP_OK;
     ALP_REQUIRE(out, "out is NULL");
-    const size_t rec = POSE_WORDS * p->esize();
-    const size_t out_bytes = (size_t)B * p->n * sizeof(double2);
-    char *dev = nullptr;
-    ALP_HIP(hipMalloc((void **)&dev, out_bytes + (size_t)B * rec));
-    void *poses_dev = dev + out_bytes;
-    std::vector<char> poses_host((size_t)B * rec);
-    for (int64_t b = 0; b < B; ++b) {
-        if (p->precision == ALP_F64) fold_pose_t<double>(cand + b * ALP_NPARAM, p->origin, (PoseRec<double> *)poses_host.data() + b);
-        else fold_pose_t<float>(cand + b * ALP_NPARAM, p->origin, (PoseRec<float> *)poses_host.data() + b);
-    }
-    hipError_t e = hipMemcpyAsync(poses_dev, poses_host.data(), poses_host.size(), hipMemcpyHostToDevice, ctx().stream);
-    if (e == hipSuccess) {
-        const int grid = stream_grid(p->n);
-        if (p->precision == ALP_F64)
-            hipLaunchKernelGGL(residual_batch_kernel<double>, dim3(grid), dim3(256), 0, ctx().stream,
-                               (const double *)p->x, (const double *)p->y, (const double *)p->z,
-                               (const double *)p->uo, (const double *)p->vo, (double2 *)dev, p->n,
-                               (const PoseRec<double> *)poses_dev, (int)B);
-        else
-            hipLaunchKernelGGL(residual_batch_kernel<float>, dim3(grid), dim3(256), 0, ctx().stream,
-                               (const float *)p->x, (const float *)p->y, (const float *)p->z,
-                               (const float *)p->uo, (const float *)p->vo, (double2 *)dev, p->n,
-                               (const PoseRec<float> *)poses_dev, (int)B);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(out, dev, out_bytes, hipMemcpyDeviceToHost, ctx().stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx().stream);     // poses_host must outlive the H2D copy
-    hipFree(dev);
-    if (e != hipSuccess) return fail(ALP_EHIP, "alp_residuals_batch: %s", hipGetErrorString(e));
-    return ALP_OK;
+    return p->precision == ALP_F64 ? residuals_impl<double>(p, cand, B, out) : residuals_impl<float>(p, cand, B, out);
 }
 
 int alp_loss_uv(const double *observed, const double *projected, int64_t n, int loss_kind, double f_scale,
@@ -411,7 +457,7 @@ int alp_loss_uv(const double *observed, const double *projected, int64_t n, int 
     const int grid = stream_grid(n);
     char *dev = nullptr;
     const size_t bytes = (size_t)n * sizeof(double2);
-    ALP_HIP(hipMalloc((void **)&dev, 2 * bytes + (size_t)(grid + 2) * sizeof(double)));
+    if (int rc = scratch_reserve(2 * bytes + (size_t)(grid + 2) * sizeof(double), (void **)&dev)) return rc;
     double *partials = (double *)(dev + 2 * bytes);
     hipError_t e = hipMemcpyAsync(dev, observed, bytes, hipMemcpyHostToDevice, ctx().stream);
     if (e == hipSuccess) e = hipMemcpyAsync(dev + bytes, projected, bytes, hipMemcpyHostToDevice, ctx().stream);
@@ -430,7 +476,6 @@ int alp_loss_uv(const double *observed, const double *projected, int64_t n, int 
     if (e == hipSuccess)
         e = hipMemcpyAsync(res, partials + grid, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx().stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx().stream);
-    hipFree(dev);
     if (e != hipSuccess) return fail(ALP_EHIP, "alp_loss_uv: %s", hipGetErrorString(e));
     *loss_out = res[0] / (double)n;
     return ALP_OK;
@@ -455,14 +500,57 @@ int alp_eval_population_wait(alp_points_t *p, double *loss_out, int64_t *argmin_
     const int64_t P = p->pending_P;
     p->pending_P = 0;
     const double n_total = p->sums_host[P];
+    std::vector<double> local;
+    double *loss = loss_out;
+    if (!loss) {
+        local.resize((size_t)P);
+        loss = local.data();
+    }
     int64_t best = -1;
     double best_v = 0;
     for (int64_t i = 0; i < P; ++i) {
         const double l = p->sums_host[i] / n_total;    // np.mean over all vertices
-        if (loss_out) loss_out[i] = l;
+        loss[i] = l;
         if (l == l && (best < 0 || l < best_v)) {       // NaN never wins; first index on ties
             best = i;
             best_v = l;
+        }
+    }
+    if (best >= 0 && p->precision == ALP_F32 && P > 1 && best_v < INFINITY) {
+        // candidates whose float32 loss lies within CONFIRM_GAP of the smallest one: if there is
+        // more than one, float32 cannot order them -- evaluate (up to CONFIRM_MAX of) them again in
+        // float64 arithmetic and take the argmin of those; identical on every rank (the sums are
+        // all-reduced, so every rank sees the same band and joins the same second all-reduce)
+        const double band = best_v + CONFIRM_GAP * std::fabs(best_v);
+        int64_t which[CONFIRM_MAX];
+        int K = 0;
+        int64_t in_band = 0;
+        for (int64_t i = 0; i < P; ++i)
+            if (loss[i] <= band) {
+                ++in_band;
+                if (K < CONFIRM_MAX) {
+                    which[K++] = i;
+                } else {           // keep the CONFIRM_MAX smallest: replace the largest kept one if this is smaller
+                    int worst = 0;
+                    for (int k = 1; k < CONFIRM_MAX; ++k)
+                        if (loss[which[k]] > loss[which[worst]] || (loss[which[k]] == loss[which[worst]] && which[k] > which[worst])) worst = k;
+                    if (loss[i] < loss[which[worst]]) which[worst] = i;
+                }
+            }
+        if (in_band > 1) {
+            std::sort(which, which + K);
+            double sums[CONFIRM_MAX + 1];
+            if (int rc = confirm_losses(p, p->cand_copy.data(), which, K, p->pending_loss, p->pending_f_scale, sums)) return rc;
+            best = -1;
+            for (int k = 0; k < K; ++k) {
+                const double l = sums[k] / sums[K];
+                loss[which[k]] = l;
+                if (l == l && (best < 0 || l < best_v)) {
+                    best = which[k];
+                    best_v = l;
+                }
+            }
+            if (best < 0) best = which[0];
         }
     }
     if (argmin_out) *argmin_out = best < 0 ? 0 : best;

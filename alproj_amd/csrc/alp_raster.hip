@@ -69,9 +69,11 @@ static void make_view(const double *p, const double *offsets, View *v, RemapCoef
             double s = 0;
             for (int k = 0; k < 3; ++k) s += t[i][k] * ry[k][j];
             v->R[i][j] = (float)s;
+            v->Rd[i][j] = s;
         }
     const double cam[3] = {x, z, y};      // vertices are stored X, Z(up), Y
     for (int i = 0; i < 3; ++i) {
+        v->camd[i] = cam[i];
         v->camf[i] = (float)cam[i];
         v->caml[i] = (float)(cam[i] - (double)v->camf[i]);
     }
@@ -705,7 +707,11 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
         if (i0 > i1 || j0 > j1 || i1 < 0 || j1 < 0 || i0 > v.w - 1 || j0 > v.h - 1) work = false;
         const int ci0 = max(i0, 0), ci1 = min(i1, v.w - 1), cj0 = max(j0, 0), cj1 = min(j1, v.h - 1);
         const int nx = ci1 - ci0 + 1, ny = cj1 - cj0 + 1;
-        if (work && nx <= FAST_MAX && ny <= FAST_MAX) {
+        // the UNCLAMPED box must be small too: a near-field cell that only pokes a corner into the
+        // viewport has edge vectors far beyond the 24-bit products and the 2^12 tie key below;
+        // i1 - i0 < 8 bounds its extent by 10 px = 2560 sub-pixel units (such a cell falls through
+        // to emit_small, which sends it to the general 64-bit path)
+        if (work && nx <= FAST_MAX && ny <= FAST_MAX && ((i1 - i0) | (j1 - j0)) < 8) {
             // Far and middle field: the cell's box holds at most FAST_MAX x FAST_MAX pixel centres.
             // Both triangles (a, b, c), (a, c, d) are decided at those centres at once: five edge
             // functions e(P->Q)(p) = (Q - P) x (p - P) instead of two 3-edge set-ups (the diagonal is
@@ -734,7 +740,7 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 // the edge owns its boundary iff dy < 0 or (dy == 0 and dx > 0) iff (dy << 12) - dx < 0
-                // (|dx| < 2^12 here: the cell's box spans at most FAST_MAX + 1 pixels)
+                // (|dx| < 2^12 here: the cell's unclamped box spans fewer than 10 pixels)
                 bs[k] = 1 + (((ey[k] << 12) - ex[k]) >> 31);
                 row[k] -= bs[k];
             }
@@ -834,7 +840,8 @@ __global__ __launch_bounds__(256) void raster_large_kernel(const float *__restri
 }
 
 // ------------------------------------------------------------------ kernel 4: resolve + remap
-__device__ __forceinline__ bool remap_source(const RemapCoef &c, int w, int h, int x, int y, int &sx, int &sy) {
+__device__ __forceinline__ bool remap_source(const RemapCoef &c, int w, int h, int x, int y, int &sx, int &sy,
+                                             float *mapx = nullptr, float *mapy = nullptr) {
     const double x1 = (x - c.c0) / c.c0, y1 = (y - c.c1) / c.c1;
     const double r = __builtin_sqrt(x1 * x1 + y1 * y1), r2 = r * r, r4 = r2 * r2, r6 = r4 * r2;
     const double xd = x1 * (1 + c.k1 * r2 + c.k2 * r4 + c.k3 * r6) / (1 + c.k4 * r2 + c.k5 * r4 + c.k6 * r6) +
@@ -842,11 +849,24 @@ __device__ __forceinline__ bool remap_source(const RemapCoef &c, int w, int h, i
     const double yd = y1 * (1 + c.a1 + c.k1 * r2 + c.k2 * r4 + c.k3 * r6) / (1 + c.a2 + c.k4 * r2 + c.k5 * r4 + c.k6 * r6) +
                       2 * c.p1 * x1 * y1 + c.p2 * (r2 * 2 * y1 * y1) + c.s3 * r2 + c.s4 * r4;
     const float mx = (float)(xd * c.c0 + c.c0), my = (float)(yd * c.c1 + c.c1);
+    if (mapx) { *mapx = mx; *mapy = my; }
     const double rx = __builtin_rint((double)mx), ry = __builtin_rint((double)my);
     if (!(rx >= 0 && rx < w && ry >= 0 && ry < h)) return false;
     sx = (int)rx;
     sy = (int)ry;
     return true;
+}
+
+// the float32 source map itself (what distort() hands to cv2.remap, project.py:140-141)
+__global__ __launch_bounds__(256) void distort_map_kernel(int w, int h, RemapCoef rc, float *__restrict__ map_x,
+                                                          float *__restrict__ map_y) {
+    const long long npix = (long long)w * h;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += stride) {
+        const int y = (int)(p / w), x = (int)(p - (long long)y * w);
+        int sx, sy;
+        remap_source(rc, w, h, x, y, sx, sy, map_x + p, map_y + p);
+    }
 }
 
 template <bool IMPLICIT>
@@ -870,14 +890,16 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float *__restrict__ 
                 const long long t = (long long)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
                 const Idx3 id = tri_vertices<IMPLICIT>(ind, gw, t);
                 const long long ids[3] = {id.a, id.b, id.c};
-                float qf[3][3];
+                // float64 view-space vertices: Rd (v - camd)
+                double Q[3][3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const float *pp = vert + 3 * ids[k];
-                    to_view(v, pp[0], pp[1], pp[2], qf[k]);
+                    const double d0 = (double)pp[0] - v.camd[0], d1 = (double)pp[1] - v.camd[1], d2 = (double)pp[2] - v.camd[2];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) Q[k][c] = (v.Rd[c][0] * d0 + v.Rd[c][1] * d1) + v.Rd[c][2] * d2;
                 }
-                const double A[3] = {qf[0][0], qf[0][1], qf[0][2]}, B[3] = {qf[1][0], qf[1][1], qf[1][2]},
-                             C[3] = {qf[2][0], qf[2][1], qf[2][2]};
+                const double *A = Q[0], *B = Q[1], *C = Q[2];
                 const double r[3] = {(((double)sx + 0.5) * v.kx - 1.0) * v.ifx,
                                      (((double)j + 0.5) * v.ky - 1.0) * v.ify, 1.0};
                 const double e1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
@@ -1357,7 +1379,7 @@ int alp_render_gather(alp_mesh_t *m, const int32_t *u, const int32_t *v, int64_t
     ALP_REQUIRE(u && v && xyz_out, "NULL argument");
     char *dev = nullptr;
     const size_t uv_bytes = (size_t)n * sizeof(int32_t), xyz_bytes = (size_t)n * 3 * sizeof(double);
-    ALP_HIP(hipMalloc((void **)&dev, xyz_bytes + 2 * uv_bytes));
+    if (int rc = scratch_reserve(xyz_bytes + 2 * uv_bytes, (void **)&dev)) return rc;
     double *xyz_dev = (double *)dev;
     int32_t *u_dev = (int32_t *)(dev + xyz_bytes), *v_dev = u_dev + n;
     hipStream_t st = ctx().stream;
@@ -1371,7 +1393,6 @@ int alp_render_gather(alp_mesh_t *m, const int32_t *u, const int32_t *v, int64_t
     }
     if (e == hipSuccess) e = hipMemcpyAsync(xyz_out, xyz_dev, xyz_bytes, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    hipFree(dev);
     if (e != hipSuccess) return fail(ALP_EHIP, "alp_render_gather: %s", hipGetErrorString(e));
     return ALP_OK;
 }
@@ -1417,7 +1438,7 @@ int alp_render_fetch_valid(alp_mesh_t *m, const double *offsets, uint32_t *idx_o
     const int chunks = (int)((npix + COMPACT_CHUNK - 1) / COMPACT_CHUNK);
     char *dev = nullptr;
     const size_t xyz_bytes = (size_t)M * 3 * sizeof(double), idx_bytes = (size_t)M * sizeof(unsigned);
-    ALP_HIP(hipMalloc((void **)&dev, xyz_bytes + idx_bytes));
+    if (int rc = scratch_reserve(xyz_bytes + idx_bytes, (void **)&dev)) return rc;
     double *xyz_dev = (double *)dev;
     unsigned *idx_dev = (unsigned *)(dev + xyz_bytes);
     hipStream_t st = ctx().stream;
@@ -1428,7 +1449,6 @@ int alp_render_fetch_valid(alp_mesh_t *m, const double *offsets, uint32_t *idx_o
     if (e == hipSuccess) e = hipMemcpyAsync(xyz_out, xyz_dev, xyz_bytes, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(idx_out, idx_dev, idx_bytes, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    hipFree(dev);
     if (e != hipSuccess) return fail(ALP_EHIP, "alp_render_fetch_valid: %s", hipGetErrorString(e));
     return ALP_OK;
 }
@@ -1450,7 +1470,7 @@ int alp_distort_image(const float *img, int64_t h, int64_t w, int64_t c, const d
     make_view(p, nullptr, &v, &rc);
     const size_t bytes = (size_t)h * w * c * sizeof(float);
     float *dev = nullptr;
-    ALP_HIP(hipMalloc((void **)&dev, 2 * bytes));
+    if (int e2 = scratch_reserve(2 * bytes, (void **)&dev)) return e2;
     hipError_t e = hipMemcpyAsync(dev, img, bytes, hipMemcpyHostToDevice, ctx().stream);
     if (e == hipSuccess) {
         const long long want = ((long long)h * w + 255) / 256;
@@ -1460,8 +1480,44 @@ int alp_distort_image(const float *img, int64_t h, int64_t w, int64_t c, const d
         e = hipMemcpyAsync(out, (char *)dev + bytes, bytes, hipMemcpyDeviceToHost, ctx().stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx().stream);
-    hipFree(dev);
     if (e != hipSuccess) return fail(ALP_EHIP, "alp_distort_image: %s", hipGetErrorString(e));
+    return ALP_OK;
+}
+
+int alp_distort_map(int64_t h, int64_t w, const double coeffs[14], float *map_x, float *map_y) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(coeffs && map_x && map_y, "NULL argument");
+    ALP_REQUIRE(h >= 1 && w >= 1 && h <= 32768 && w <= 32768, "bad image shape");
+    double p[ALP_NPARAM] = {0};
+    for (int i = 0; i < 14; ++i) p[7 + i] = coeffs[i];
+    p[3] = 60; p[21] = (double)w; p[22] = (double)h;
+    View v;
+    RemapCoef rc;
+    make_view(p, nullptr, &v, &rc);
+    const size_t bytes = (size_t)h * w * sizeof(float);
+    float *dev = nullptr;
+    if (int e2 = scratch_reserve(2 * bytes, (void **)&dev)) return e2;
+    const long long want = ((long long)h * w + 255) / 256;
+    const int grid = (int)(want < 4096 ? want : 4096);
+    hipLaunchKernelGGL(distort_map_kernel, dim3(grid), dim3(256), 0, ctx().stream, (int)w, (int)h, rc, dev, dev + (size_t)h * w);
+    ALP_HIP(hipGetLastError());
+    ALP_HIP(hipMemcpyAsync(map_x, dev, bytes, hipMemcpyDeviceToHost, ctx().stream));
+    ALP_HIP(hipMemcpyAsync(map_y, dev + (size_t)h * w, bytes, hipMemcpyDeviceToHost, ctx().stream));
+    ALP_HIP(hipStreamSynchronize(ctx().stream));
+    return ALP_OK;
+}
+
+int alp_render_load(alp_mesh_t *m, const float *image, int64_t h, int64_t w) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(m && image, "NULL argument");
+    ALP_REQUIRE(h >= 1 && w >= 1 && h <= 32768 && w <= 32768, "image size w,h must be in [1, 32768]");
+    if (m->unchecked) ALP_HIP(hipStreamSynchronize(ctx().stream));
+    m->unchecked = false;
+    if (int e = ensure_frame(m, (int)w, (int)h)) return e;
+    if (int e = upload_chunked(m->image, image, (size_t)h * w * 3 * sizeof(float))) return e;
+    ALP_HIP(hipMemsetAsync(m->vis, 0, (size_t)h * w * sizeof(unsigned long long), ctx().stream));   // no visibility belongs to it
+    m->rendered = true;
+    m->valid_total = -1;
     return ALP_OK;
 }
 

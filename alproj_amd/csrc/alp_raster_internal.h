@@ -12,6 +12,7 @@ struct View {
     int w, h;
     double fxd, fyd;
     double kx, ky, ifx, ify;     // 1/sx, 1/sy, 1/fx, 1/fy in float64 (ray of a pixel centre, resolve_kernel)
+    double Rd[3][3], camd[3];    // float64 rotation and camera position: the interpolation of resolve_kernel
 };
 
 struct RemapCoef {     // inverted coefficients of project.py:136-137, float64

@@ -166,7 +166,7 @@ static int run_rasterize(const double *dx, const double *dy, const double *dv, l
 
 // ------------------------------------------------------------------ median
 // groupby median needs the values of every pixel in order: the points of one band are sorted
-// by value, then stably by pixel (two hipCUB radix sorts: a library sort, nothing to hand-tune),
+// by value, then stably by pixel (two rocPRIM radix sorts: a library sort, nothing to hand-tune),
 // and the middle element(s) of each pixel's run are averaged like numpy/pandas do.
 __global__ __launch_bounds__(256) void rz_median_keys_kernel(const double *__restrict__ x, const double *__restrict__ y,
                                                              const double *__restrict__ values, long long n, int nb,
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void rz_focal_median_kernel(const float *__res
 
 }  // namespace alp
 
-#include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 namespace alp {
 
@@ -264,29 +264,30 @@ static int run_rasterize_median(const double *dx, const double *dy, const double
         const long long want = (items + 255) / 256;
         return (unsigned)(want < 1 ? 1 : (want < (long long)cu * 8 ? want : (long long)cu * 8));
     };
-    // scratch: value keys (2 x u64), point ids (2 x u32), pixel ids (3 x u32), hipCUB temporary storage
+    // scratch: value keys (2 x u64), point ids (2 x u32), pixel ids (3 x u32), rocPRIM temporary storage
     size_t tmp1 = 0, tmp2 = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, tmp1, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
-                                       (unsigned *)nullptr, (unsigned *)nullptr, (int)n, 0, 64, st);
-    hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, (unsigned *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr,
-                                       (unsigned *)nullptr, (int)n, 0, 32, st);
+    const size_t count = (size_t)n;
+    rocprim::radix_sort_pairs(nullptr, tmp1, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                              (unsigned *)nullptr, (unsigned *)nullptr, count, 0u, 64u, st);
+    rocprim::radix_sort_pairs(nullptr, tmp2, (unsigned *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr,
+                              (unsigned *)nullptr, count, 0u, 32u, st);
     const size_t tmp = tmp1 > tmp2 ? tmp1 : tmp2;
     char *scratch = nullptr;
     ALP_HIP(hipMalloc((void **)&scratch, (size_t)n * (16 + 8 + 12) + tmp + 256));
     unsigned long long *vkey = (unsigned long long *)scratch, *vkey2 = vkey + n;
     unsigned *idx = (unsigned *)(vkey2 + n), *idx2 = idx + n, *cell = idx2 + n, *cell_s = cell + n, *cell_s2 = cell_s + n;
-    void *cub_tmp = (void *)(((uintptr_t)(cell_s2 + n) + 255) & ~(uintptr_t)255);
+    void *sort_tmp = (void *)(((uintptr_t)(cell_s2 + n) + 255) & ~(uintptr_t)255);
     hipLaunchKernelGGL(rz_fill_nan_kernel, dim3(grid(total)), dim3(256), 0, st, ra, total);
     hipError_t e = hipSuccess;
     for (int b = 0; b < nb && e == hipSuccess; ++b) {
         hipLaunchKernelGGL(rz_median_keys_kernel, dim3(grid(n)), dim3(256), 0, st, dx, dy, dv, n, nb, b, x_min, y_max, res,
                            width, height, vkey, idx, cell);
         size_t t = tmp;
-        e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, t, vkey, vkey2, idx, idx2, (int)n, 0, 64, st);   // by value
+        e = rocprim::radix_sort_pairs(sort_tmp, t, vkey, vkey2, idx, idx2, count, 0u, 64u, st);   // by value
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(rz_gather_cell_kernel, dim3(grid(n)), dim3(256), 0, st, idx2, cell, n, cell_s);
         t = tmp;
-        e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, t, cell_s, cell_s2, idx2, idx, (int)n, 0, 32, st);   // stably by pixel
+        e = rocprim::radix_sort_pairs(sort_tmp, t, cell_s, cell_s2, idx2, idx, count, 0u, 32u, st);   // stably by pixel
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(rz_median_runs_kernel, dim3(grid(n)), dim3(256), 0, st, cell_s2, idx, dv, n, nb, b, ra + b * hw);
     }

@@ -228,23 +228,45 @@ class CMAOptimizer(BaseOptimizer):
         loss_function = self._loss_function(bounds, f_scale, precision)
         pts = loss_function.points
         try:
+            # Several ranks (one process per GPU, vertices sharded): every population evaluation
+            # all-reduces the per-candidate sums, so every rank MUST evaluate the same candidates.
+            # The reference seeds nothing (optimize.py:410-416); here rank 0's seed (its own entropy
+            # when seed is None) and, every generation, rank 0's candidate matrix are broadcast.
+            _, world = _lib.comm_info()
+            if world > 1:
+                s = np.array([np.random.SeedSequence().entropy % (1 << 63) if seed is None else int(seed)],
+                             dtype=np.uint64)
+                _lib.comm_bcast(s, root=0)
+                seed = int(s[0])
             optimizer = CMA(mean=normalized_init.astype("float64"), sigma=float(sigma),
                             bounds=normalized_bounds, population_size=population_size,
                             n_max_resampling=n_max_resampling, seed=seed)
             it = range(generation)
             best_normalized = normalized_init
             for _ in (tqdm(it) if progress else it):
-                X = optimizer.ask_population()
+                X = np.ascontiguousarray(optimizer.ask_population())
+                if world > 1:
+                    _lib.comm_bcast(X, root=0)
                 losses, amin = loss_function(X)
                 best_normalized = X[amin].copy()
                 optimizer.tell_population(X, losses)
             best_values = best_normalized * (upper - lower) + lower
             params = self._result_params(best_values)
-            # final error is always the mean distance (optimize.py:435-437)
-            err, _ = pts.eval_population(self._candidate_matrix(best_values), _lib.LOSS_MEAN_DIST, 0.0)
+            # final error is always the mean distance (optimize.py:435-437), and float64 like the
+            # reference's (and like LsqOptimizer's): a float32 point set of GCP size is evaluated once
+            # more from a float64 copy; DSM-sized sets keep their float32 residency (a collective when
+            # several ranks hold shards: every rank must reach this line)
+            final = self._candidate_matrix(best_values)
+            if pts.precision == _lib.ALP_F32 and pts.n <= self.F64_FINAL_MAX_POINTS:
+                with self._device_points("f64") as p64:
+                    err, _ = p64.eval_population(final, _lib.LOSS_MEAN_DIST, 0.0)
+            else:
+                err, _ = pts.eval_population(final, _lib.LOSS_MEAN_DIST, 0.0)
         finally:
             pts.close()
         return params, float(err[0])
+
+    F64_FINAL_MAX_POINTS = 4_000_000
 
 
 class LsqOptimizer(BaseOptimizer):

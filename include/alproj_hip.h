@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ALP_ABI_VERSION 1
+#define ALP_ABI_VERSION 2
 
 /* x,y,z,fov,pan,tilt,roll,a1,a2,k1..k6,p1,p2,s1..s4,w,h,cx,cy */
 #define ALP_NPARAM 25
@@ -94,6 +94,12 @@ int alp_comm_unique_id(char id[ALP_UNIQUE_ID_BYTES]);
 int alp_comm_init(const char id[ALP_UNIQUE_ID_BYTES], int rank, int world_size);
 int alp_comm_destroy(void);
 int alp_comm_info(int *rank, int *world_size); /* 0,1 when no communicator */
+/* Broadcast `bytes` bytes of the host buffer `buf` from rank `root` to every rank (ncclBroadcast on
+ * the library stream); no-op without a communicator.  The optimiser shim uses it so that every
+ * rank draws the SAME population: the reference constructs its sampler without a seed
+ * (src/alproj/optimize.py:410-416), which is fine for one process and silently wrong for several
+ * that must all-reduce the sums of identical candidates. */
+int alp_comm_bcast(void *buf, int64_t bytes, int root);
 
 /* ---------------------------------------------------------------- point sets ---------- */
 /* Device-resident set of 3-D points (GCPs or DSM vertices) -- the `obj_points` DataFrame
@@ -235,6 +241,11 @@ int alp_render_fetch_visibility(alp_mesh_t *mesh, uint64_t *out);
  * M; alp_render_fetch_valid then writes idx_out[M] (linear pixel index v * w + u) and
  * xyz_out[M][3] = (x, y, z) = channels (0, 2, 1) (:361) plus offsets[0], offsets[2],
  * offsets[1] (:370-373; NULL = no offsets), float64. */
+/* Install a coordinate image produced elsewhere (h x w x 3 float32, row 0 = top: what persp_proj(vert,
+ * vert, ...) returns, src/alproj/project.py:360) as the mesh's current frame, so that the
+ * post-processing below runs on it as it would after alp_render_enqueue.  Its visibility buffer
+ * is empty. */
+int alp_render_load(alp_mesh_t *mesh, const float *image, int64_t h, int64_t w);
 int alp_render_valid_count(alp_mesh_t *mesh, int64_t *count);
 int alp_render_fetch_valid(alp_mesh_t *mesh, const double *offsets, uint32_t *idx_out, double *xyz_out);
 
@@ -262,6 +273,10 @@ int alp_rasterize_points(const double *x, const double *y, const double *values,
  * img/out: h x w x c float32 host images; coeffs: a1,a2,k1..k6,p1,p2,s1..s4. */
 int alp_distort_image(const float *img, int64_t h, int64_t w, int64_t c,
                       const double coeffs[14], float *out);
+/* The float32 source map of that remap alone: map_x, map_y (h x w each) = what distort() hands to
+ * cv2.remap, src/alproj/project.py:128-140 (_distort of the pixel grid with 1/a1, 1/a2 and every other
+ * coefficient negated, cast to float32). */
+int alp_distort_map(int64_t h, int64_t w, const double coeffs[14], float *map_x, float *map_y);
 
 #ifdef __cplusplus
 }

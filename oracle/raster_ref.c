@@ -298,10 +298,14 @@ static void shade(const view_t *v, const float *vert, const float *value, const 
     const int64_t t = (int64_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu));
     int64_t idx[3];
     tri_vertices(ind, ind_i64, gw, t, idx);
-    float qf[3][3];
-    double A[3], B[3], C[3];
-    for (int k = 0; k < 3; ++k) to_view(v, vert + 3 * idx[k], qf[k]);
-    for (int c = 0; c < 3; ++c) { A[c] = qf[0][c]; B[c] = qf[1][c]; C[c] = qf[2][c]; }
+    /* float64 view-space vertices: Rd (v - camd), row by row, left to right */
+    double Q[3][3];
+    for (int k = 0; k < 3; ++k) {
+        const float *p = vert + 3 * idx[k];
+        const double d0 = (double)p[0] - v->camd[0], d1 = (double)p[1] - v->camd[1], d2 = (double)p[2] - v->camd[2];
+        for (int c = 0; c < 3; ++c) Q[k][c] = (v->Rd[c][0] * d0 + v->Rd[c][1] * d1) + v->Rd[c][2] * d2;
+    }
+    const double *A = Q[0], *B = Q[1], *C = Q[2];
     /* ray through the pixel centre: direction r = (xn/fx, yn/fy, 1), xn = (i+0.5)/sx - 1 */
     const double r[3] = {(((double)i + 0.5) * v->kx - 1.0) * v->ifx, (((double)j + 0.5) * v->ky - 1.0) * v->ify, 1.0};
     /* solve A + beta (B-A) + gamma (C-A) = t r  (Cramer) */

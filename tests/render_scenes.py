@@ -1,0 +1,35 @@
+"""Small render scenes shared by the CPU oracle tests and the GPU parity tests of the render:
+meshes and poses on which the frozen raster oracle (oracle/raster_ref.c), the independent float64
+ray caster (oracle/raycast_ref.c) and the HIP kernels are compared."""
+import numpy as np
+
+from alproj_amd import synthetic as syn
+
+
+def _grid_scene(n, w, h, **kw):
+    s = syn.surface(n)
+    p = dict(syn.base_params(n), w=w, h=h, cx=w / 2.0, cy=h / 2.0)
+    p["z"] += kw.pop("dz", 0.0)
+    p.update(kw)
+    return dict(vert=s["vert"], ind=None, grid=(n, n), params=p, offsets=s["offsets"])
+
+
+def _hand_made():
+    """An explicit-index mesh that is not a grid: two interpenetrating quads and a back-facing
+    triangle, seen with tilt and roll (no offsets)."""
+    vert = np.array([[-40, 0, 60], [40, 0, 60], [40, 50, 90], [-40, 50, 90],        # sloping quad
+                     [-30, 25, 50], [35, 20, 100], [30, 45, 100], [-35, 40, 50],     # quad crossing it
+                     [-10, 5, 40], [10, 5, 40], [0, 20, 40]], dtype=np.float32)     # small triangle in front
+    ind = np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 7], [8, 9, 10], [8, 10, 9]], dtype=np.int32)
+    p = dict(syn.BASE_CAMERA, x=3.0, y=-20.0, z=22.0, pan=4.0, tilt=6.0, roll=-9.0, fov=70.0, w=192, h=128,
+             cx=96.0, cy=64.0)
+    return dict(vert=vert, ind=ind, grid=None, params=p, offsets=None)
+
+
+SCENES = {
+    "grid_tilted": lambda: _grid_scene(120, 320, 200, tilt=-10.0),
+    "grid_tilt_roll": lambda: _grid_scene(90, 240, 160, tilt=-12.0, roll=7.0, pan=80.0),
+    "grid_near_plane": lambda: _grid_scene(60, 200, 140, dz=-48.5, tilt=-20.0),       # triangles cross vz = 1
+    "grid_wide_fov": lambda: _grid_scene(100, 256, 192, fov=88.0, tilt=-30.0, pan=120.0),
+    "hand_made_indices": _hand_made,
+}

@@ -39,7 +39,8 @@ def test_ctypes_table_matches_header():
     from alproj_amd import _lib
     assert sorted(_lib._SIGNATURES) == header_functions()
     lib = _lib.load()
-    assert lib.alp_abi_version() == 1
+    version = int(re.search(r"#define ALP_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+    assert lib.alp_abi_version() == version == 2
 
 
 def test_header_cites_reference_for_each_entry_point():

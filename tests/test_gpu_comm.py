@@ -29,9 +29,20 @@ def test_allreduce_path_world1():
             with pytest.raises(L.AlprojHipError):
                 L.comm_init(uid, 0, 1)                                   # already exists
             after, amin1 = pts.eval_population(cand, L.LOSS_HUBER, 10.0)
+            assert L.comm_info() == (0, 1)
+            seed = np.array([0x1234567890ABCDEF], dtype=np.uint64)
+            L.comm_bcast(seed, root=0)                                   # ncclBroadcast through the library stream
+            assert int(seed[0]) == 0x1234567890ABCDEF
+            X = np.random.default_rng(0).random((50, 21))
+            Y = X.copy()
+            L.comm_bcast(Y)
+            np.testing.assert_array_equal(X, Y)
         finally:
             L.comm_destroy()
         again, amin2 = pts.eval_population(cand, L.LOSS_HUBER, 10.0)
+    assert L.comm_info() == (0, 1)
+    z = np.arange(4.0)
+    L.comm_bcast(z)                                                     # no communicator: no-op
     np.testing.assert_array_equal(before, after)
     np.testing.assert_array_equal(before, again)
     assert amin0 == amin1 == amin2

@@ -1,0 +1,92 @@
+"""GPU: the render wrappers, the distortion map and LsqOptimizer against vectors captured from the
+reference's own functions (tests/golden/gen_golden_render.py: g12, g13, g14), through the C ABI."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from oracle import ref_numpy as orc
+from tests.test_oracle_golden_render import COEFFS, SIZES, check_frame
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def L():
+    from alproj_amd import _lib
+    _lib.init(0)
+    return _lib
+
+
+@pytest.mark.parametrize("otag", ["off", "nooff"])
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_g12_reverse_proj_post_processing_on_the_device(L, tag, otag):
+    """the reference's reverse_proj (project.py:361-373) ran unmodified on a seeded raw render; the same
+    raw image installed as the device frame must give the same DataFrame: x > 0 selection incl.
+    0 / negative / tiny / NaN / inf, channel reorder, int16 u, v, offsets, row labels."""
+    from alproj_amd import project as aproj
+    g = load("g12_wrappers.npz")
+    raw, array = g[f"{tag}_raw"], g[f"{tag}_array"]
+    off = g["offsets"] if otag == "off" else None
+    h, w = raw.shape[:2]
+    vert = np.array([[0, 0, 0], [1, 0, 0], [0, 0, 1], [1, 0, 1]], dtype=np.float32)      # any mesh: the frame is loaded
+    with L.Mesh(vert, None, None, grid=(2, 2)) as m:
+        m.load_image(raw)
+        rp = aproj.ReverseProjection(m, off, w, h, False, None)
+        check_frame(rp.to_frame(array, list(g[f"{tag}_chnames"])), g, tag, otag)
+        # set_gcp's gather on the same frame = a lookup in the reference's table
+        df = pd.DataFrame(g[f"{tag}_{otag}_values"], columns=list(g[f"{tag}_{otag}_columns"]))
+        pick = df.iloc[:: max(1, len(df) // 50)]
+        got = rp.lookup(pick["u"].to_numpy(), pick["v"].to_numpy())
+        np.testing.assert_array_equal(got, pick[["x", "y", "z"]].to_numpy())
+        assert np.isnan(rp.lookup([0], [0])).all()            # raw[0, 0] has x == 0: not in the table
+
+
+@pytest.mark.parametrize("size", SIZES)
+@pytest.mark.parametrize("name", COEFFS)
+def test_g13_distort_map_on_the_device(L, name, size):
+    """alp_distort_map = the float32 map_x / map_y the reference's distort() handed to cv2.remap, bit
+    for bit; alp_distort_image gathers from its round-half-even (constant-0 border)."""
+    g = load("g13_distort_map.npz")
+    h, w = (int(s) for s in size.split("x"))
+    mx, my = L.distort_map(h, w, g[f"coeffs_{name}"])
+    np.testing.assert_array_equal(mx, g[f"mapx_{name}_{size}"])
+    np.testing.assert_array_equal(my, g[f"mapy_{name}_{size}"])
+    index_img = (np.arange(h * w, dtype=np.float32) + 1).reshape(h, w, 1)
+    got = L.distort_image(index_img, g[f"coeffs_{name}"])
+    np.testing.assert_array_equal(got, orc.remap_nearest(index_img, g[f"mapx_{name}_{size}"], g[f"mapy_{name}_{size}"]))
+
+
+@pytest.mark.parametrize("case", ["trf_linear_d7", "trf_huber_d9", "dogbox_softl1_d4", "lm_d4"])
+def test_g14_lsq_optimizer_matches_the_reference_run(L, case):
+    """LsqOptimizer.optimize of the reference (optimize.py:467-539, scipy least_squares) on a seeded GCP
+    set: same optimum and error from the device residuals.  jac='2-point' = scipy's own sequential
+    differences (the reference's call), and the batched Jacobian (one launch for D+1 poses)."""
+    from alproj_amd import optimize as aopt
+    g = load("g14_lsq.npz")
+    keys = [str(k) for k in g["param_keys"]]
+    init = dict(zip(keys, g["params_init"]))
+    dfx = pd.DataFrame(g["xyz"], columns=["x", "y", "z"])
+    dfu = pd.DataFrame(g["uv"], columns=["u", "v"])
+    kw = {"trf_linear_d7": dict(method="trf"),
+          "trf_huber_d9": dict(method="trf", loss="huber", f_scale=5.0),
+          "dogbox_softl1_d4": dict(method="dogbox", loss="soft_l1", f_scale=3.0,
+                                   bound_widths={"fov": 10, "pan": 10, "tilt": 10, "roll": 10}),
+          "lm_d4": dict(method="lm")}[case]
+    targets = [str(t) for t in g[f"{case}_targets"]]
+    want = dict(zip(keys, g[f"{case}_params"]))
+    for jac in ("2-point", "batched"):
+        o = aopt.LsqOptimizer(dfx, dfu, dict(init))
+        o.set_target(targets)
+        params, err = o.optimize(jac=jac, **kw)
+        assert set(params) == set(want)
+        tol = 1e-7 if jac == "2-point" else 1e-5
+        for k in targets:
+            assert params[k] == pytest.approx(want[k], rel=tol, abs=tol * 1e-2), (jac, k)
+        assert err == pytest.approx(float(g[f"{case}_error"]), rel=1e-8 if jac == "2-point" else 1e-6)

@@ -437,3 +437,42 @@ def test_frame_size_changes_and_tiny_frames(L, scene):
             ref = orast.render(scene["vert"], scene["col"], scene["ind"], p, scene["offsets"])
             assert got.shape == (h, w, 3)
             np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("corner", ["b_top_right", "d_bottom_left", "a_bottom_right", "c_top_left"])
+def test_near_field_cell_poking_a_viewport_corner(L, corner):
+    """A grid cell ~600 x 500 px large of which only one corner reaches a viewport corner (at most 2 x 2
+    pixel centres).  Its viewport-clamped box is tiny, but its edge vectors are far beyond the 24-bit
+    products and the 2^12 tie key of the cell fast path: such a cell must take the general 64-bit path
+    (a host emulation of the unguarded fast path got 2 of 9 coverage decisions wrong here)."""
+    w, h, fov = 64, 48, 60.0
+    p = dict(x=0.0, y=0.0, z=0.0, fov=fov, pan=0.0, tilt=0.0, roll=0.0, a1=1, a2=1, k1=0, k2=0, k3=0, k4=0, k5=0, k6=0,
+             p1=0, p2=0, s1=0, s2=0, s3=0, s4=0, w=w, h=h, cx=w / 2, cy=h / 2)
+    fx = 1 / np.tan(np.radians(fov) / 2) * (w / 2)
+    fy = 1 / np.tan(np.radians(fov) * h / w / 2) * (h / 2)
+    depth = 2.0
+
+    def view_xy(xw, yw):                        # window (pixels) -> view-space x, y at `depth`
+        return (xw - w / 2) / fx * depth, (yw - h / 2) / fy * depth
+
+    # window rectangle of the cell: x0..x1, y0..y1 (GL window, y up), one corner 2 px inside the viewport
+    rect = {"b_top_right": (w - 2.2, w + 598.0, h - 2.3, h + 498.0),        # cell's bottom-left vertex (b) inside
+            "d_bottom_left": (-598.0, 2.2, -498.0, 2.3),                   # top-right vertex (d) inside
+            "a_bottom_right": (w - 2.2, w + 598.0, -498.0, 2.3),           # top-left vertex (a) inside
+            "c_top_left": (-598.0, 2.2, h - 2.3, h + 498.0)}[corner]       # bottom-right vertex (c) inside
+    x0, x1, y0, y1 = rect
+    (vx0, vy0), (vx1, vy1) = view_xy(x0, y0), view_xy(x1, y1)
+    # grid 2 x 2, vertex id = row * 2 + col; row 0 = top (high Z), columns left to right; stored X, Z(up), Y(forward)
+    vert = np.array([[vx0, vy1, depth], [vx1, vy1, depth], [vx0, vy0, depth], [vx1, vy0, depth]], dtype=np.float32)
+    ref = orast.visibility(vert, None, p, None, grid=(2, 2))
+    assert 1 <= (ref != 0).sum() <= 9
+    with L.Mesh(vert, None, None, grid=(2, 2)) as m:
+        m.render_enqueue(L.params_vector(p), None)
+        got = m.fetch_visibility()
+    assert_vis_equal(got, ref)
+    # and as part of a larger grid whose other cells are ordinary
+    from alproj_amd import synthetic as syn
+    ind = syn.grid_indices(2, np.int32)
+    with L.Mesh(vert, None, ind) as m:
+        m.render_enqueue(L.params_vector(p), None)
+        assert_vis_equal(m.fetch_visibility(), ref)
