@@ -37,6 +37,7 @@
 // see DESIGN.md "parity unpinned" -- the choices made are watertight and deterministic.
 #include "alp_raster_internal.h"
 
+#include <algorithm>
 #include <climits>
 #include <cmath>
 #include <cstdlib>
@@ -101,8 +102,15 @@ static void make_view(const double *p, const double *offsets, View *v, RemapCoef
 }
 
 // ------------------------------------------------------------------ device helpers
+#ifdef ALP_WG_TIMING        // development build: start / end time of every workgroup of raster_grid_kernel (100 MHz)
+__device__ unsigned long long g_wgtime[8 * 131072];
+#define WGT(k) do { if (threadIdx.x == 0 && blockIdx.x < 131072) g_wgtime[8 * blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define WGT(k) ((void)0)
+#endif
 #ifdef ALP_RASTER_STATS     // development build: fragment / request census printed after every frame
-__device__ unsigned long long g_rstat[16];
+__device__ unsigned long long g_rstat[24];
+
 #define RSTAT(k, n) atomicAdd(&g_rstat[k], (unsigned long long)(n))
 #else
 #define RSTAT(k, n) ((void)0)
@@ -220,7 +228,13 @@ __device__ __forceinline__ void vis_max(unsigned long long *vis, const View &v, 
     unsigned long long *dst = vis + (unsigned)(__umul24((unsigned)j, (unsigned)v.w) + (unsigned)i);   // j, w <= 2^15
     // unconditional: a plain-load pre-test ("only if larger") measured SLOWER (3.35 vs 3.02 ms per
     // 100 M-vertex frame) -- the load serialises behind the atomic it was meant to save
+#ifdef VIS_PLAIN_STORE          // development: the same address arithmetic without the atomic (wrong image)
+    __builtin_nontemporal_store(key, dst);
+#elif defined(VIS_NEVER)        // development: the arithmetic stays, the memory operation (almost) never happens
+    if (key == 0x123456789ull) atomicMax(dst, key);
+#else
     atomicMax(dst, key);
+#endif
 }
 
 // every pixel centre of the (small) bounding box: the three edge functions are stepped
@@ -377,12 +391,6 @@ __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 #define COOP_MIN_PIX 9      // ... if they also hold at least this many pixel centres
 #endif
 
-// A triangle parked by emit_snapped for coop_raster (the whole wave rasterises it together).
-struct Deferred {
-    int X[3], Y[3];
-    float iw[3];
-    unsigned t;
-};
 
 // The inline walk of emit_snapped done by all 64 lanes of the wave on ONE triangle (arguments
 // wave-uniform): lane = one pixel of an 8x8 block (8 consecutive pixels of a row = one 64-byte
@@ -449,7 +457,7 @@ __device__ __forceinline__ void coop_drain(const View &v, bool parked, const Def
     }
 }
 
-enum { EMIT_DONE = 0, EMIT_PARKED = 1, EMIT_GENERAL = 2 };
+enum { EMIT_DONE = 0, EMIT_PARKED = 1, EMIT_GENERAL = 2, EMIT_PARKED_SMALL = 3 };   // _SMALL: box of at most 8 x 8 centres (if asked for)
 
 // One snapped window-space triangle, 32-bit part: bounding-box rejection, then -- for triangles
 // under 64 px -- back-face test and the inline walk (or parking for coop_raster if may_park).
@@ -457,7 +465,7 @@ enum { EMIT_DONE = 0, EMIT_PARKED = 1, EMIT_GENERAL = 2 };
 __device__ __forceinline__ int emit_small(const View &v, const int X[3], const int Y[3], const float *iwsrc,
                                           int n0, int n1, int n2, unsigned t, unsigned long long *__restrict__ vis,
                                           Deferred *park, bool may_park, int coop_min_w = COOP_MIN_W,
-                                          int coop_min_pix = COOP_MIN_PIX) {
+                                          int coop_min_pix = COOP_MIN_PIX, bool tell_small = false) {
     // bounding box without a pixel centre, or entirely outside the viewport
     const int minx = min(X[0], min(X[1], X[2])), maxx = max(X[0], max(X[1], X[2]));
     const int miny = min(Y[0], min(Y[1], Y[2])), maxy = max(Y[0], max(Y[1], Y[2]));
@@ -479,7 +487,7 @@ __device__ __forceinline__ int emit_small(const View &v, const int X[3], const i
             park->iw[k] = iw3[k];
         }
         park->t = t;
-        return EMIT_PARKED;
+        return (tell_small && ci1 - ci0 < 8 && cj1 - cj0 < 8) ? EMIT_PARKED_SMALL : EMIT_PARKED;
     }
     const int px0 = ci0 * SUB + SUB / 2, py0 = cj0 * SUB + SUB / 2;
     // the tie rule is folded into the stepped value: w = e - (edge owns its boundary ? 0 : 1),
@@ -563,6 +571,95 @@ __device__ __forceinline__ void emit_general(const View &v, const float q[3][3],
     }
 }
 
+// ------------------------------------------------------------------ parked triangles of the grid kernel
+// raster_grid_kernel does not rasterise the triangles emit_small parks (boxes of at least 3 columns
+// and 9 centres, under 64 px): a tile next to the camera holds a thousand of them, and walking them
+// one after the other inside the workgroup made those few workgroups the critical path of the whole
+// frame (0.8 ms for a handful of tiles while the rest of the chip idled).  They are appended to two
+// device queues instead and rasterised by their own launches, spread over every CU:
+//   raster_coop4_kernel  boxes of at most 8 x 8 centres: FOUR triangles per wave, 16 lanes = a 4 x 4
+//                        pixel block each (a 6 x 3 box costs two steps of a quarter wave instead of two
+//                        steps of a whole one);
+//   raster_coop_kernel   larger boxes: one triangle per wave, 8 x 8 pixel blocks (coop_raster).
+// Same integers and the same float32 depth expression as the inline walk.
+__device__ __forceinline__ void park_append(bool take, const Deferred &d, Deferred *__restrict__ queue,
+                                            unsigned *__restrict__ count, unsigned cap) {
+    const unsigned long long m = __ballot(take);
+    if (!m) return;
+    const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)m) - 1;
+    unsigned base = 0;
+#ifdef PARK_NOATOMIC      // development: no global counter (wrong image), to time its contention
+    base = (blockIdx.x * 64u) % (cap - 64u);
+#else
+    if (lane == leader) base = atomicAdd(count, (unsigned)__popcll(m));
+    base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+#endif
+    const unsigned slot = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    if (take && slot < cap) queue[slot] = d;       // an overflow is noticed by finish_frame (queue grown, frame redone)
+}
+
+__global__ __launch_bounds__(256) void raster_coop_kernel(View v, unsigned long long *__restrict__ vis,
+                                                          const Deferred *__restrict__ queue,
+                                                          const unsigned *__restrict__ count, unsigned cap) {
+    const unsigned n = min(*count, cap);
+    const int lane = (int)(threadIdx.x & 63);
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (unsigned it = wave; it < n; it += nwaves) {
+        const Deferred d = queue[it];          // wave-uniform address
+        int X[3], Y[3];
+        float iw3[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            X[k] = __builtin_amdgcn_readfirstlane(d.X[k]);
+            Y[k] = __builtin_amdgcn_readfirstlane(d.Y[k]);
+            iw3[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(d.iw[k])));
+        }
+        coop_raster(v, X, Y, iw3, (unsigned)__builtin_amdgcn_readfirstlane((int)d.t), vis, lane);
+    }
+}
+
+__global__ __launch_bounds__(256) void raster_coop4_kernel(View v, unsigned long long *__restrict__ vis,
+                                                           const Deferred *__restrict__ queue,
+                                                           const unsigned *__restrict__ count, unsigned cap) {
+    const unsigned n = min(*count, cap);
+    const unsigned group = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, ngroups = (gridDim.x * blockDim.x) >> 4;
+    const int lx = (int)(threadIdx.x & 3), ly = (int)((threadIdx.x >> 2) & 3);
+    for (unsigned it = group; it < n; it += ngroups) {
+        const Deferred d = queue[it];          // the 16 lanes of a group read the same entry
+        const int minx = min(d.X[0], min(d.X[1], d.X[2])), maxx = max(d.X[0], max(d.X[1], d.X[2]));
+        const int miny = min(d.Y[0], min(d.Y[1], d.Y[2])), maxy = max(d.Y[0], max(d.Y[1], d.Y[2]));
+        const int ci0 = max((minx + SUB / 2 - 1) >> 8, 0), ci1 = min((maxx - SUB / 2) >> 8, v.w - 1);
+        const int cj0 = max((miny + SUB / 2 - 1) >> 8, 0), cj1 = min((maxy - SUB / 2) >> 8, v.h - 1);
+        const int area2 = mul24(d.X[1] - d.X[0], d.Y[2] - d.Y[0]) - mul24(d.X[2] - d.X[0], d.Y[1] - d.Y[0]);
+        int dx[3], dy[3], bias[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int a = (k + 1) % 3, b = (k + 2) % 3;
+            dx[k] = d.X[b] - d.X[a];
+            dy[k] = d.Y[b] - d.Y[a];
+            bias[k] = (dy[k] < 0 || (dy[k] == 0 && dx[k] > 0)) ? 0 : 1;
+        }
+        const float inv_area = 1.0f / (float)area2;
+        const unsigned long long lo = (unsigned long long)(0xFFFFFFFFu - d.t);
+        for (int by = cj0; by <= cj1; by += 4)
+            for (int bx = ci0 & ~3; bx <= ci1; bx += 4) {
+                const int i = bx + lx, j = by + ly;
+                if (i < ci0 || i > ci1 || j > cj1) continue;
+                const int px = i * SUB + SUB / 2, py = j * SUB + SUB / 2;
+                const int w0 = mul24(dx[0], py - d.Y[1]) - mul24(dy[0], px - d.X[1]) - bias[0];
+                const int w1 = mul24(dx[1], py - d.Y[2]) - mul24(dy[1], px - d.X[2]) - bias[1];
+                const int w2 = mul24(dx[2], py - d.Y[0]) - mul24(dy[2], px - d.X[0]) - bias[2];
+                if ((w0 | w1 | w2) >= 0) {
+                    const float q = __builtin_fmaf((float)(w2 + bias[2]), d.iw[2],
+                                                   __builtin_fmaf((float)(w1 + bias[1]), d.iw[1],
+                                                                  (float)(w0 + bias[0]) * d.iw[0])) * inv_area;
+                    vis_max(vis, v, i, j, ((unsigned long long)__float_as_uint(q) << 32) | lo);
+                }
+            }
+    }
+}
+
 // ------------------------------------------------------------------ kernel 2: per-triangle raster
 // One thread per triangle, three gathered vertices.  Like raster_grid_kernel it finishes only the
 // common case itself (all vertices in front and in range, under 64 px) and sets the rest aside
@@ -639,13 +736,341 @@ __global__ __launch_bounds__(256) void raster_general_kernel(const float *__rest
 }
 
 // ------------------------------------------------------------------ kernel 2b: implicit grid, LDS-tiled
-// One workgroup = a tile of GT_W x GT_H grid cells.  Phase 1 transforms the (GT_W+1) x (GT_H+1)
-// vertices of the tile ONCE (raster_kernel does it 6 times per vertex), projects and snaps
-// those in front of the near plane, and parks view-space + window-space data in LDS.  Phase 2:
-// one thread per cell = two triangles read from LDS; the common case (three vertices in front,
-// inside the fixed-point range) goes straight to the integer set-up, everything else takes
-// the same clip_project path as raster_kernel.  Same arithmetic, same results.
-constexpr int GT_W = 32, GT_H = 8, GT_VW = GT_W + 1, GT_VH = GT_H + 1, GT_NV = GT_VW * GT_VH;
+// One workgroup = a tile of GT_W x GT_H grid cells (64 x 16 = 1024 cells, four per thread).
+//   Phase 0  the tile comes from a list made by the frame plan (tile_plan_kernel, one lane per
+//            tile): tiles whose bounding box (precomputed once per mesh: tile_bounds_kernel) lies
+//            entirely beyond a side plane of the frustum or behind the near plane are not listed at
+//            all -- conservatively (margins far above float32 rounding): such a tile draws nothing
+//            in the exact path either, every one of its triangles is dropped by step 3 of the
+//            specification or has no pixel centre inside the viewport.  FAR tiles (cells under about
+//            a pixel) are listed for a second launch, after tile_occlusion_kernel has dropped those
+//            that the depth pyramid of the first round proves to be hidden.
+//   Phase 1  transforms, projects and snaps the (GT_W+1) x (GT_H+1) vertices of the tile ONCE
+//            into LDS (raster_kernel does it 6 times per vertex).
+//   Phase 2  classifies the cells (one lane per cell, four rounds): no pixel centre / outside
+//            the viewport -> nothing; box of at most FAST_MAX x FAST_MAX centres -> FAST queue;
+//            anything else -> SLOW queue.  Both queues live in LDS (cell ids, 2 bytes).
+//   Phase 3  the FAST queue, 64 entries per wave: both triangles of a cell decided at once from
+//            five shared edge functions.  In the far field only 1-3 % of the cells hold a pixel
+//            centre; compacting them means ONE wave of a workgroup runs this (the most expensive)
+//            stage for the whole tile instead of sixteen waves running it for one or two lanes each.
+//   Phase 4  the SLOW queue: per triangle emit_small (inline walk, or parking: appended to the
+//            device queues of raster_coop4_kernel / raster_coop_kernel), rare cases recorded in the
+//            global general queue.
+// Same integers, same tie rule, same float32 depth expression as the per-triangle path.
+#ifndef GT_W_LOG2
+#define GT_W_LOG2 6
+#endif
+#ifndef GT_H_LOG2
+#define GT_H_LOG2 4
+#endif
+constexpr int GT_W = 1 << GT_W_LOG2, GT_H = 1 << GT_H_LOG2, GT_VW = GT_W + 1, GT_VH = GT_H + 1, GT_NV = GT_VW * GT_VH,
+              GT_NC = GT_W * GT_H;
+static_assert(GT_NC % 256 == 0 && GT_NC <= 65536, "tile size");
+
+// idx / GT_VW for idx < GT_NV as a 24-bit multiply and a shift
+constexpr int GT_DIV_SHIFT = 18;
+constexpr int GT_DIV_MAGIC = ((1 << GT_DIV_SHIFT) + GT_VW - 1) / GT_VW;
+constexpr bool gt_div_ok() {
+    for (int i = 0; i < GT_NV; ++i)
+        if (((i * GT_DIV_MAGIC) >> GT_DIV_SHIFT) != i / GT_VW) return false;
+    return (long long)GT_NV * GT_DIV_MAGIC < (1ll << 31) && GT_DIV_MAGIC < (1 << 23);
+}
+static_assert(gt_div_ok(), "magic division");
+
+// per-tile bounding boxes of an implicit-grid mesh: centre and half extent per axis (6 floats)
+__global__ __launch_bounds__(256) void tile_bounds_kernel(const float *__restrict__ vert, int gh, int gw, int tiles_x,
+                                                          float *__restrict__ bounds) {
+    __shared__ float s_min[4][3], s_max[4][3];
+    const int tile_r = blockIdx.x / tiles_x, tile_c = blockIdx.x - tile_r * tiles_x;
+    const int r0 = tile_r * GT_H, c0 = tile_c * GT_W;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int idx = threadIdx.x; idx < GT_NV; idx += 256) {
+        const int lr = idx / GT_VW, lc = idx - lr * GT_VW;
+        const int r = r0 + lr, c = c0 + lc;
+        if (r < gh && c < gw) {
+            const float *p = vert + 3ull * ((unsigned)r * (unsigned)gw + (unsigned)c);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = fminf(lo[k], p[k]);       // a NaN coordinate is ignored here; such a vertex fails every test later
+                hi[k] = fmaxf(hi[k], p[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (int m = 32; m >= 1; m >>= 1) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], m, 64));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m, 64));
+        }
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 3; ++k) {
+            s_min[threadIdx.x >> 6][k] = lo[k];
+            s_max[threadIdx.x >> 6][k] = hi[k];
+        }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        const float a = fminf(fminf(s_min[0][k], s_min[1][k]), fminf(s_min[2][k], s_min[3][k]));
+        const float b = fmaxf(fmaxf(s_max[0][k], s_max[1][k]), fmaxf(s_max[2][k], s_max[3][k]));
+        bounds[6 * blockIdx.x + k] = 0.5f * a + 0.5f * b;
+        bounds[6 * blockIdx.x + 3 + k] = (0.5f * b - 0.5f * a) * 1.000001f + 1e-30f;
+    }
+}
+
+// the five planes of the tile test, in the stored (X, Z, Y) frame relative to the camera:
+//   0..3  right, left, top, bottom: a point with n . d > 0 is beyond the plane (fx vx > vz, ...)
+//   4     near: a point with n . d < 1 is behind it
+// an = |n|; am = the component-wise magnitude bound of the float32 expressions the exact path
+// evaluates (fx |R0| + |R2|, ...), which scales the safety margin.
+struct TileCull {
+    float cam[3];
+    float n[5][3], an[5][3], am[5][3];
+    float R[3][3];            // view rotation (rows x, y, z)
+    float fx, fy, sx, sy;     // as in View
+    float near_limit;         // a tile is "near" (drawn in the first round) when vz_min < near_limit * cell size
+    int w, h;
+    int enabled, occlusion;
+};
+
+static void make_tile_cull(const View &v, TileCull *c) {
+    for (int i = 0; i < 3; ++i) c->cam[i] = (float)((double)v.camf[i] + (double)v.caml[i]);
+    const double f[2] = {(double)v.fx, (double)v.fy};
+    for (int k = 0; k < 5; ++k)
+        for (int i = 0; i < 3; ++i) {
+            double n, am;
+            if (k < 4) {
+                const int axis = k >> 1;                          // 0: x (right / left), 1: y (top / bottom)
+                const double sgn = (k & 1) ? -1.0 : 1.0;
+                n = sgn * f[axis] * (double)v.R[axis][i] - (double)v.R[2][i];
+                am = f[axis] * std::fabs((double)v.R[axis][i]) + std::fabs((double)v.R[2][i]);
+            } else {
+                n = (double)v.R[2][i];
+                am = std::fabs(n);
+            }
+            c->n[k][i] = (float)n;
+            c->an[k][i] = (float)std::fabs(n) * 1.000001f;
+            c->am[k][i] = (float)am * 1.000001f;
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c->R[i][j] = v.R[i][j];
+    c->fx = v.fx; c->fy = v.fy; c->sx = v.sx; c->sy = v.sy;
+    c->w = v.w; c->h = v.h;
+    // cells that project to about a pixel or more: vz < focal length in pixels x cell size
+    const double focal_px = std::fmax((double)v.fx * v.sx, (double)v.fy * v.sy);
+    double near_px = 1.0;
+    if (const char *e = getenv("ALP_NEAR_PX")) near_px = atof(e);      // development: where the first round ends
+    c->near_limit = (float)(focal_px * near_px);
+    c->enabled = 1;
+    c->occlusion = 1;
+}
+
+// ---- frame plan, one lane per tile: drop the tiles outside the frustum, split the rest into the NEAR
+// list (drawn first: the occluders) and the FAR list (tested against the depth pyramid of the first
+// round before they are drawn).  counts[0] = near, counts[1] = far.  Wave-aggregated appends keep the
+// lists roughly in tile order.
+__device__ __forceinline__ void list_append(bool take, unsigned value, unsigned *__restrict__ list, unsigned *count) {
+    const unsigned long long m = __ballot(take);
+    if (!m) return;
+    const int lane = (int)(threadIdx.x & 63);
+    unsigned base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(count, (unsigned)__popcll(m));
+    base = (unsigned)__builtin_amdgcn_readlane((int)base, __ffsll((long long)m) - 1);
+    if (take) list[base + __popcll(m & ((1ull << lane) - 1ull))] = value;
+}
+
+__global__ __launch_bounds__(256) void tile_plan_kernel(const float *__restrict__ tile_bounds, unsigned n_tiles, TileCull cull,
+                                                        unsigned *__restrict__ near_list, unsigned *__restrict__ far_list,
+                                                        unsigned *__restrict__ counts) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    int kind = 0;                       // 0 dropped, 1 near, 2 far
+    if (t < n_tiles) {
+        kind = 1;
+        if (cull.enabled) {
+            const float *tb = tile_bounds + 6ull * t;
+            const float d0 = tb[0] - cull.cam[0], d1 = tb[1] - cull.cam[1], d2 = tb[2] - cull.cam[2];
+            const float e0 = tb[3], e1 = tb[4], e2 = tb[5];
+            const float a0 = fabsf(d0) + e0, a1 = fabsf(d1) + e1, a2 = fabsf(d2) + e2;
+            bool outside = false;
+            float vz_min = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const float sd = cull.n[k][0] * d0 + cull.n[k][1] * d1 + cull.n[k][2] * d2;
+                const float rr = cull.an[k][0] * e0 + cull.an[k][1] * e1 + cull.an[k][2] * e2;
+                const float mg = 1e-5f * (cull.am[k][0] * a0 + cull.am[k][1] * a1 + cull.am[k][2] * a2);
+                if (k < 4) outside = outside || (sd - rr > mg);                 // every point beyond a side plane
+                else {
+                    outside = outside || (sd + rr < 1.0f - mg - 1e-5f);        // every point behind the near plane
+                    vz_min = sd - rr - mg;                                      // lower bound of the view depth in the tile
+                }
+            }
+            if (outside) kind = 0;
+            else if (cull.occlusion) {
+                const float cell = fmaxf(2.0f * e0 / (float)GT_W, 2.0f * e2 / (float)GT_H);
+                kind = (vz_min >= 2.0f && vz_min >= cull.near_limit * cell) ? 2 : 1;
+            }
+        }
+    }
+    list_append(kind == 1, t, near_list, counts + 0);
+    list_append(kind == 2, t, far_list, counts + 1);
+}
+
+// ---- depth pyramid of the visibility buffer after the first round.  Level L holds, per block of
+// (8 << L) x (8 << L) pixels, the SMALLEST float32 1/vz among the block's pixels inside the viewport
+// (0 where a pixel is still empty): whatever is drawn later with a strictly smaller 1/vz everywhere in
+// the block cannot win a single pixel there (the visibility word only grows; equal depth is not
+// "strictly smaller", so the lower-triangle-index tie rule is never pre-empted).
+constexpr int HIZ_LEVELS = 6;
+
+struct HizDims { int w[HIZ_LEVELS], h[HIZ_LEVELS]; long long off[HIZ_LEVELS]; };
+
+static HizDims hiz_dims(int w, int h) {
+    HizDims d;
+    long long off = 0;
+    for (int l = 0; l < HIZ_LEVELS; ++l) {
+        const int b = 8 << l;
+        d.w[l] = (w + b - 1) / b;
+        d.h[l] = (h + b - 1) / b;
+        d.off[l] = off;
+        off += (long long)d.w[l] * d.h[l];
+    }
+    return d;
+}
+static long long hiz_total(int w, int h) {
+    const HizDims d = hiz_dims(w, h);
+    return d.off[HIZ_LEVELS - 1] + (long long)d.w[HIZ_LEVELS - 1] * d.h[HIZ_LEVELS - 1];
+}
+
+// one workgroup per 64 x 64 pixels: levels 0..3
+__global__ __launch_bounds__(256) void hiz_build_kernel(const unsigned long long *__restrict__ vis, int w, int h, HizDims dm,
+                                                        unsigned *__restrict__ hiz) {
+    __shared__ unsigned s_min[64 + 16 + 4 + 1];
+    const int rx = blockIdx.x * 64, ry = blockIdx.y * 64;
+    if (threadIdx.x < 85) s_min[threadIdx.x] = 0x7F800000u;       // +inf: no pixel of the viewport in the block yet
+    __syncthreads();
+    const int col = threadIdx.x & 63;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int row = (threadIdx.x >> 6) + 4 * k;
+        const int x = rx + col, y = ry + row;
+        if (x < w && y < h) {
+            const unsigned q = (unsigned)(vis[(size_t)y * w + x] >> 32);      // float32 bits of 1/vz (positive: ordered as integers)
+            // 8 lanes share a block; one LDS atomic per lane is fine here (21 M pixels, ~30 us)
+            atomicMin(&s_min[(row >> 3) * 8 + (col >> 3)], q);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int bx = threadIdx.x & 3, by = threadIdx.x >> 2;
+        unsigned m = 0x7F800000u;
+        for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < 2; ++i) m = min(m, s_min[(2 * by + j) * 8 + 2 * bx + i]);
+        s_min[64 + threadIdx.x] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int bx = threadIdx.x & 1, by = threadIdx.x >> 1;
+        unsigned m = 0x7F800000u;
+        for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < 2; ++i) m = min(m, s_min[64 + (2 * by + j) * 4 + 2 * bx + i]);
+        s_min[80 + threadIdx.x] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_min[84] = min(min(s_min[80], s_min[81]), min(s_min[82], s_min[83]));
+    __syncthreads();
+    // write the texels of this region that exist in each level
+    if (threadIdx.x < 64) {
+        const int tx = blockIdx.x * 8 + (threadIdx.x & 7), ty = blockIdx.y * 8 + (threadIdx.x >> 3);
+        if (tx < dm.w[0] && ty < dm.h[0]) hiz[dm.off[0] + (long long)ty * dm.w[0] + tx] = s_min[threadIdx.x];
+    } else if (threadIdx.x < 80) {
+        const int k = threadIdx.x - 64, tx = blockIdx.x * 4 + (k & 3), ty = blockIdx.y * 4 + (k >> 2);
+        if (tx < dm.w[1] && ty < dm.h[1]) hiz[dm.off[1] + (long long)ty * dm.w[1] + tx] = s_min[threadIdx.x];
+    } else if (threadIdx.x < 84) {
+        const int k = threadIdx.x - 80, tx = blockIdx.x * 2 + (k & 1), ty = blockIdx.y * 2 + (k >> 1);
+        if (tx < dm.w[2] && ty < dm.h[2]) hiz[dm.off[2] + (long long)ty * dm.w[2] + tx] = s_min[threadIdx.x];
+    } else if (threadIdx.x == 84) {
+        hiz[dm.off[3] + (long long)blockIdx.y * dm.w[3] + blockIdx.x] = s_min[84];
+    }
+}
+
+// levels 4 and 5 from level 3: one thread per level-5 texel
+__global__ __launch_bounds__(256) void hiz_top_kernel(HizDims dm, unsigned *__restrict__ hiz) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= dm.w[5] * dm.h[5]) return;
+    const int tx = t % dm.w[5], ty = t / dm.w[5];
+    unsigned m5 = 0x7F800000u;
+    for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i) {
+            const int x4 = 2 * tx + i, y4 = 2 * ty + j;
+            if (x4 >= dm.w[4] || y4 >= dm.h[4]) continue;
+            unsigned m4 = 0x7F800000u;
+            for (int jj = 0; jj < 2; ++jj)
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int x3 = 2 * x4 + ii, y3 = 2 * y4 + jj;
+                    if (x3 < dm.w[3] && y3 < dm.h[3]) m4 = min(m4, hiz[dm.off[3] + (long long)y3 * dm.w[3] + x3]);
+                }
+            hiz[dm.off[4] + (long long)y4 * dm.w[4] + x4] = m4;
+            m5 = min(m5, m4);
+        }
+    hiz[dm.off[5] + (long long)ty * dm.w[5] + tx] = m5;
+}
+
+// ---- occlusion test of the FAR tiles, one lane per tile: the tile's bounding box is projected
+// (its eight corners lie in front of the camera: vz_min >= 2), the screen rectangle is widened by two
+// pixels (float32 rounding, 1/256-pixel snapping), and the largest 1/vz anything in the tile can reach
+// (1 / vz_min, with margin) is compared with the pyramid texels under the rectangle.  Survivors are
+// appended to the list of the second round.
+__global__ __launch_bounds__(256) void tile_occlusion_kernel(const float *__restrict__ tile_bounds, TileCull cull,
+                                                             const unsigned *__restrict__ far_list,
+                                                             const unsigned *__restrict__ counts, HizDims dm,
+                                                             const unsigned *__restrict__ hiz, unsigned *__restrict__ out_list,
+                                                             unsigned *__restrict__ out_count) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned n = counts[1];
+    bool keep = false;
+    unsigned t = 0;
+    if (i < n) {
+        t = far_list[i];
+        keep = true;
+        const float *tb = tile_bounds + 6ull * t;
+        const float c[3] = {tb[0] - cull.cam[0], tb[1] - cull.cam[1], tb[2] - cull.cam[2]};
+        const float e[3] = {tb[3], tb[4], tb[5]};
+        float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY, zmin = INFINITY;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float d0 = c[0] + ((k & 1) ? e[0] : -e[0]), d1 = c[1] + ((k & 2) ? e[1] : -e[1]), d2 = c[2] + ((k & 4) ? e[2] : -e[2]);
+            const float vx = cull.R[0][0] * d0 + cull.R[0][1] * d1 + cull.R[0][2] * d2;
+            const float vy = cull.R[1][0] * d0 + cull.R[1][1] * d1 + cull.R[1][2] * d2;
+            const float vz = cull.R[2][0] * d0 + cull.R[2][1] * d1 + cull.R[2][2] * d2;
+            const float iz = 1.0f / vz;
+            const float xw = (cull.fx * vx * iz + 1.0f) * cull.sx, yw = (cull.fy * vy * iz + 1.0f) * cull.sy;
+            x0 = fminf(x0, xw); x1 = fmaxf(x1, xw);
+            y0 = fminf(y0, yw); y1 = fmaxf(y1, yw);
+            zmin = fminf(zmin, vz);
+        }
+        // zmin >= 2 by construction of the far list (up to rounding: re-checked, NaN keeps the tile)
+        if (zmin >= 1.5f && x1 - x0 < 2048.0f && y1 - y0 < 2048.0f) {
+            // pixels whose centres can be touched: [x0 - 2, x1 + 2] clamped to the viewport
+            const int px0 = max((int)floorf(x0 - 2.0f), 0), px1 = min((int)floorf(x1 + 2.0f), cull.w - 1);
+            const int py0 = max((int)floorf(y0 - 2.0f), 0), py1 = min((int)floorf(y1 + 2.0f), cull.h - 1);
+            if (px0 > px1 || py0 > py1) {
+                keep = false;                       // nothing of it can reach the viewport
+            } else {
+                const float qmax = (1.0f / zmin) * 1.00002f;    // >= every interpolated float32 1/vz of the tile
+                int L = 0;
+                while (L < HIZ_LEVELS && (((px1 >> (3 + L)) - (px0 >> (3 + L))) > 1 || ((py1 >> (3 + L)) - (py0 >> (3 + L))) > 1)) ++L;
+                if (L < HIZ_LEVELS) {
+                    unsigned m = 0x7F800000u;
+                    for (int ty = py0 >> (3 + L); ty <= (py1 >> (3 + L)); ++ty)
+                        for (int tx = px0 >> (3 + L); tx <= (px1 >> (3 + L)); ++tx)
+                            m = min(m, hiz[dm.off[L] + (long long)ty * dm.w[L] + tx]);
+                    keep = !(qmax < __uint_as_float(m));
+                }
+            }
+        }
+    }
+    list_append(keep, t, out_list, out_count);
+}
 
 #ifndef GRID_WAVES_PER_EU
 #define GRID_WAVES_PER_EU 8
@@ -653,26 +1078,71 @@ constexpr int GT_W = 32, GT_H = 8, GT_VW = GT_W + 1, GT_VH = GT_H + 1, GT_NV = G
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRID_WAVES_PER_EU)))
 void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__restrict__ valid, int gh, int gw, View v,
                         unsigned long long *__restrict__ vis, unsigned *__restrict__ gqueue,
-                        unsigned *__restrict__ gcount, unsigned gcap, int lanes_along_rows) {
+                        unsigned *__restrict__ gcount, unsigned gcap, int lanes_along_rows,
+                        const unsigned *__restrict__ tile_list, const unsigned *__restrict__ tile_count,
+                        Deferred *__restrict__ park_small, Deferred *__restrict__ park_large,
+                        unsigned *__restrict__ park_counts, unsigned park_cap_small, unsigned park_cap_large) {
     // s_xy[].x of a vertex without window coordinates: behind the near plane / outside the
     // fixed-point range / masked out (nodata: its triangles do not exist, surface.py:203-205)
     constexpr int BEHIND = INT_MIN, RANGE = INT_MIN + 1, NODATA = INT_MIN + 2;
     __shared__ int2 s_xy[GT_NV];          // snapped window coordinates
     __shared__ float s_iw[GT_NV];
+    __shared__ unsigned short s_q[GT_NC]; // FAST cell ids from the front, SLOW cell ids from the back
+    __shared__ unsigned short s_park[2 * GT_NC];   // parked triangles (2 * cell id + half): small boxes from the front, large from the back
+    __shared__ unsigned s_nfast, s_nslow, s_npark[2], s_park_base[2];
+    // ---- phase 0: this workgroup's tile (the frame plan dropped, deferred or culled the others)
+    // Workgroups are handed to the 8 XCDs round-robin; each XCD has its own L2.  List position =
+    // (XCD) * chunk + (turn): one XCD walks a CONTIGUOUS eighth of the list, i.e. neighbouring tiles,
+    // whose fragments fall on neighbouring pixels, meet in the same L2.
+    const unsigned n_list = *tile_count;
+#ifndef GRID_NO_XCD_SWIZZLE
+    const unsigned chunk = (n_list + 7u) >> 3;
+    const unsigned pos = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= chunk || pos >= n_list) return;
+#else
+    const unsigned pos = blockIdx.x;
+    if (pos >= n_list) return;
+#endif
+    const unsigned tile = tile_list[pos];
+    WGT(0);
     const int tiles_x = (gw - 1 + GT_W - 1) / GT_W;
-    const int tile_r = blockIdx.x / tiles_x, tile_c = blockIdx.x - tile_r * tiles_x;
+    const int tile_r = (int)(tile / (unsigned)tiles_x), tile_c = (int)(tile - (unsigned)tile_r * (unsigned)tiles_x);
     const int r0 = tile_r * GT_H, c0 = tile_c * GT_W;
-    for (int idx = threadIdx.x; idx < GT_NV; idx += 256) {
-        const int lr = mul24(idx, 1986) >> 16, lc = idx - lr * GT_VW;     // idx / 33 for idx < 297
+    if (threadIdx.x == 0) {
+        s_nfast = 0;
+        s_nslow = 0;
+        s_npark[0] = 0;
+        s_npark[1] = 0;
+    }
+    // ---- phase 1: vertices.  Every load of the thread's (up to) GT_VPT vertices is issued before the
+    // first one is used: ONE memory round trip per tile instead of one per vertex (the round trip is what
+    // this phase costs: measured 50 us per workgroup with five dependent trips while the atomics of the
+    // neighbouring workgroups keep the memory pipeline busy).
+    constexpr int GT_VPT = (GT_NV + 255) / 256;
+    float vx[GT_VPT], vy[GT_VPT], vz[GT_VPT];
+    unsigned char vok[GT_VPT];
+#pragma unroll
+    for (int k = 0; k < GT_VPT; ++k) {
+        const int idx = (int)threadIdx.x + 256 * k;
+        const int lr = mul24(idx, GT_DIV_MAGIC) >> GT_DIV_SHIFT, lc = idx - lr * GT_VW;
         const int r = r0 + lr, c = c0 + lc;
+        const bool inside = idx < GT_NV && r < gh && c < gw;
+        const unsigned vid = inside ? (unsigned)r * (unsigned)gw + (unsigned)c : 0u;   // < 2^31 vertices
+        const float *p = vert + 3ull * vid;
+        vx[k] = p[0];
+        vy[k] = p[1];
+        vz[k] = p[2];
+        vok[k] = inside ? (valid ? (valid[vid] ? 1 : 2) : 1) : 0;       // 0 outside the grid, 1 vertex, 2 nodata
+    }
+#pragma unroll
+    for (int k = 0; k < GT_VPT; ++k) {
+        const int idx = (int)threadIdx.x + 256 * k;
         int2 xy = make_int2(BEHIND, 0);
-        const unsigned vid = (unsigned)r * (unsigned)gw + (unsigned)c;   // < 2^31 vertices
-        if (r < gh && c < gw && valid && !valid[vid]) {
+        if (vok[k] == 2) {
             xy.x = NODATA;
-        } else if (r < gh && c < gw) {
-            const float *p = vert + 3ull * vid;
+        } else if (vok[k] == 1) {
             float q[3];
-            to_view(v, p[0], p[1], p[2], q);
+            to_view(v, vx[k], vy[k], vz[k], q);
             if (q[2] >= 1.0f) {
                 float xw, yw, iw;
                 to_window(v, q, xw, yw, iw);
@@ -683,119 +1153,232 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
                 }
             }
         }
-        s_xy[idx] = xy;
+        if (idx < GT_NV) s_xy[idx] = xy;
     }
     __syncthreads();
-    // Phase 2: one wave = 8 x 8 cells; consecutive lanes take cells along the grid axis that runs
-    // ACROSS the view, so that their fragments fall on neighbouring pixels of one row and the
-    // atomics of one instruction share 64-byte lines (the memory side serves one request per
-    // instruction and line).
-    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
-    const int lr = lanes_along_rows ? (lane & 7) : (lane >> 3);
-    const int lc = wave * 8 + (lanes_along_rows ? (lane >> 3) : (lane & 7));
-    const int r = r0 + lr, c = c0 + lc;
-    const int ia = lr * GT_VW + lc, ib = ia + GT_VW, ic = ib + 1, id = ia + 1;
-    const int2 P[4] = {s_xy[ia], s_xy[ib], s_xy[ic], s_xy[id]};
-    bool work = r < gh - 1 && c < gw - 1;
-    const unsigned cell = (unsigned)r * (unsigned)(gw - 1) + (unsigned)c;      // < 2^31: 2 * cell + 1 fits
-    if (work && P[0].x > NODATA && P[1].x > NODATA && P[2].x > NODATA && P[3].x > NODATA) {
-        // the cell's bounding box holds no pixel centre of the viewport: neither can its triangles
-        const int minx = min(min(P[0].x, P[1].x), min(P[2].x, P[3].x)), maxx = max(max(P[0].x, P[1].x), max(P[2].x, P[3].x));
-        const int miny = min(min(P[0].y, P[1].y), min(P[2].y, P[3].y)), maxy = max(max(P[0].y, P[1].y), max(P[2].y, P[3].y));
-        const int i0 = (minx + SUB / 2 - 1) >> 8, i1 = (maxx - SUB / 2) >> 8;
-        const int j0 = (miny + SUB / 2 - 1) >> 8, j1 = (maxy - SUB / 2) >> 8;
-        if (i0 > i1 || j0 > j1 || i1 < 0 || j1 < 0 || i0 > v.w - 1 || j0 > v.h - 1) work = false;
-        const int ci0 = max(i0, 0), ci1 = min(i1, v.w - 1), cj0 = max(j0, 0), cj1 = min(j1, v.h - 1);
-        const int nx = ci1 - ci0 + 1, ny = cj1 - cj0 + 1;
-        // the UNCLAMPED box must be small too: a near-field cell that only pokes a corner into the
-        // viewport has edge vectors far beyond the 24-bit products and the 2^12 tie key below;
-        // i1 - i0 < 8 bounds its extent by 10 px = 2560 sub-pixel units (such a cell falls through
-        // to emit_small, which sends it to the general 64-bit path)
-        if (work && nx <= FAST_MAX && ny <= FAST_MAX && ((i1 - i0) | (j1 - j0)) < 8) {
-            // Far and middle field: the cell's box holds at most FAST_MAX x FAST_MAX pixel centres.
-            // Both triangles (a, b, c), (a, c, d) are decided at those centres at once: five edge
-            // functions e(P->Q)(p) = (Q - P) x (p - P) instead of two 3-edge set-ups (the diagonal is
-            // shared, e(a->c) = -e(c->a) exactly), stepped by whole pixels -- the same integers, tie
-            // rule and depth expression as emit_small.  A triangle with area <= 0 can never have all
-            // three biased values >= 0, and a centre outside a triangle's own box is outside the
-            // triangle.  The loops run to the largest box among the wave's cells.
-            work = false;
-            const int px = ci0 * SUB + SUB / 2, py = cj0 * SUB + SUB / 2;
-            const int2 a = P[0], b = P[1], cc = P[2], d = P[3];
-            const int pax = px - a.x, pay = py - a.y, pbx = px - b.x, pby = py - b.y;
-            const int pcx = px - cc.x, pcy = py - cc.y, pdx = px - d.x, pdy = py - d.y;
-            // directed edges: 0 b->c, 1 c->a, 2 a->b (triangle 0); 3 c->d, 4 d->a, 5 a->c (triangle 1)
-            int ex[6] = {cc.x - b.x, a.x - cc.x, b.x - a.x, d.x - cc.x, a.x - d.x, 0};
-            int ey[6] = {cc.y - b.y, a.y - cc.y, b.y - a.y, d.y - cc.y, a.y - d.y, 0};
-            ex[5] = -ex[1];
-            ey[5] = -ey[1];
-            int bs[6], row[6];
-            row[0] = mul24(ex[0], pby) - mul24(ey[0], pbx);
-            row[1] = mul24(ex[1], pcy) - mul24(ey[1], pcx);
-            row[2] = mul24(ex[2], pay) - mul24(ey[2], pax);
-            row[3] = mul24(ex[3], pcy) - mul24(ey[3], pcx);
-            row[4] = mul24(ex[4], pdy) - mul24(ey[4], pdx);
-            row[5] = -row[1];
-            const int area0 = row[0] + row[1] + row[2], area1 = row[3] + row[4] + row[5];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                // the edge owns its boundary iff dy < 0 or (dy == 0 and dx > 0) iff (dy << 12) - dx < 0
-                // (|dx| < 2^12 here: the cell's unclamped box spans fewer than 10 pixels)
-                bs[k] = 1 + (((ey[k] << 12) - ex[k]) >> 31);
-                row[k] -= bs[k];
+    WGT(1);
+#if defined(GRID_STOP_AFTER) && GRID_STOP_AFTER == 1
+    if (s_xy[threadIdx.x].x == 12345) vis[0] = 1;     // keep phase 1 alive
+    return;
+#endif
+    // ---- phase 2: classify the cells.  Consecutive cell ids run along the grid axis that runs ACROSS
+    // the view, so that the fragments of neighbouring queue entries fall on neighbouring pixels of one
+    // row and the atomics of one instruction share 64-byte lines.
+    const int lane = (int)(threadIdx.x & 63);
+    auto cell_rc = [&](int id, int &lr, int &lc) {
+        if (lanes_along_rows) { lr = id & (GT_H - 1); lc = id >> GT_H_LOG2; }
+        else { lc = id & (GT_W - 1); lr = id >> GT_W_LOG2; }
+    };
+#pragma unroll 1
+    for (int id = threadIdx.x; id < GT_NC; id += 256) {
+        int lr, lc;
+        cell_rc(id, lr, lc);
+        const int ia = lr * GT_VW + lc;
+        const int2 P0 = s_xy[ia], P1 = s_xy[ia + GT_VW], P2 = s_xy[ia + GT_VW + 1], P3 = s_xy[ia + 1];
+        int kind = 0;                      // 0 nothing, 1 FAST, 2 SLOW
+        if (r0 + lr < gh - 1 && c0 + lc < gw - 1) {
+            if (P0.x > NODATA && P1.x > NODATA && P2.x > NODATA && P3.x > NODATA) {
+                // the cell's bounding box holds no pixel centre of the viewport: neither can its triangles
+                const int minx = min(min(P0.x, P1.x), min(P2.x, P3.x)), maxx = max(max(P0.x, P1.x), max(P2.x, P3.x));
+                const int miny = min(min(P0.y, P1.y), min(P2.y, P3.y)), maxy = max(max(P0.y, P1.y), max(P2.y, P3.y));
+                const int i0 = (minx + SUB / 2 - 1) >> 8, i1 = (maxx - SUB / 2) >> 8;
+                const int j0 = (miny + SUB / 2 - 1) >> 8, j1 = (maxy - SUB / 2) >> 8;
+                if (!(i0 > i1 || j0 > j1 || i1 < 0 || j1 < 0 || i0 > v.w - 1 || j0 > v.h - 1)) {
+                    const int nx = min(i1, v.w - 1) - max(i0, 0), ny = min(j1, v.h - 1) - max(j0, 0);     // centres - 1
+                    // FAST needs the UNCLAMPED box small too: a near-field cell that only pokes a corner
+                    // into the viewport has edge vectors far beyond the 24-bit products and the 2^12 tie
+                    // key; i1 - i0 < 8 bounds its extent by 10 px = 2560 sub-pixel units
+                    kind = (nx < FAST_MAX && ny < FAST_MAX && ((i1 - i0) | (j1 - j0)) < 8) ? 1 : 2;
+                }
+            } else if (!(P0.x == BEHIND && P1.x == BEHIND && P2.x == BEHIND && P3.x == BEHIND)) {
+                kind = 2;                  // sentinels among the corners: sorted out per triangle
             }
-            const float iwa = s_iw[ia], iwb = s_iw[ib], iwc = s_iw[ic], iwd = s_iw[id];
-            const float inv0 = 1.0f / (float)area0, inv1 = 1.0f / (float)area1;      // used only where area > 0
-            const unsigned long long lo0 = 0xFFFFFFFFu - 2u * cell, lo1 = lo0 - 1u;
-            for (int j = cj0; j <= cj1; ++j) {
-                int u[6];
+        }
+        const unsigned long long mf = __ballot(kind == 1), ms = __ballot(kind == 2);
+        if (mf) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&s_nfast, (unsigned)__popcll(mf));
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if (kind == 1) s_q[base + __popcll(mf & ((1ull << lane) - 1ull))] = (unsigned short)id;
+        }
+        if (ms) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&s_nslow, (unsigned)__popcll(ms));
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if (kind == 2) s_q[GT_NC - 1 - (base + __popcll(ms & ((1ull << lane) - 1ull)))] = (unsigned short)id;
+        }
+    }
+    __syncthreads();
+    WGT(2);
+    const int nfast = (int)s_nfast, nslow = (int)s_nslow;
+#if defined(GRID_STOP_AFTER) && GRID_STOP_AFTER == 2
+    if (nfast + nslow == 123456) vis[0] = s_q[threadIdx.x];
+    return;
+#endif
+    if (threadIdx.x == 0) {
+        RSTAT(10, 1);
+        RSTAT(11, nfast);
+        RSTAT(12, nslow);
+        RSTAT(13, (nfast + 63) / 64);
+        RSTAT(14, (nslow + 63) / 64);
+    }
+    // ---- phase 3: FAST cells.  The cell's box holds at most FAST_MAX x FAST_MAX pixel centres.  Both
+    // triangles (a, b, c), (a, c, d) are decided at those centres at once: five edge functions
+    // e(P->Q)(p) = (Q - P) x (p - P) instead of two 3-edge set-ups (the diagonal is shared,
+    // e(a->c) = -e(c->a) exactly), stepped by whole pixels -- the same integers, tie rule and depth
+    // expression as emit_small.  A triangle with area <= 0 can never have all three biased values
+    // >= 0, and a centre outside a triangle's own box is outside the triangle.
+#pragma unroll 1
+    for (int e = threadIdx.x; e < nfast; e += 256) {
+        const int id = s_q[e];
+        int lr, lc;
+        cell_rc(id, lr, lc);
+        const int ia = lr * GT_VW + lc, ib = ia + GT_VW, ic = ib + 1, idd = ia + 1;
+        const int2 a = s_xy[ia], b = s_xy[ib], cc = s_xy[ic], d = s_xy[idd];
+        const unsigned cell = (unsigned)(r0 + lr) * (unsigned)(gw - 1) + (unsigned)(c0 + lc);      // < 2^31: 2 * cell + 1 fits
+        const int minx = min(min(a.x, b.x), min(cc.x, d.x)), maxx = max(max(a.x, b.x), max(cc.x, d.x));
+        const int miny = min(min(a.y, b.y), min(cc.y, d.y)), maxy = max(max(a.y, b.y), max(cc.y, d.y));
+        const int ci0 = max((minx + SUB / 2 - 1) >> 8, 0), ci1 = min((maxx - SUB / 2) >> 8, v.w - 1);
+        const int cj0 = max((miny + SUB / 2 - 1) >> 8, 0), cj1 = min((maxy - SUB / 2) >> 8, v.h - 1);
+        const int px = ci0 * SUB + SUB / 2, py = cj0 * SUB + SUB / 2;
+        const int pax = px - a.x, pay = py - a.y, pbx = px - b.x, pby = py - b.y;
+        const int pcx = px - cc.x, pcy = py - cc.y, pdx = px - d.x, pdy = py - d.y;
+        // directed edges: 0 b->c, 1 c->a, 2 a->b (triangle 0); 3 c->d, 4 d->a, 5 a->c (triangle 1)
+        int ex[6] = {cc.x - b.x, a.x - cc.x, b.x - a.x, d.x - cc.x, a.x - d.x, 0};
+        int ey[6] = {cc.y - b.y, a.y - cc.y, b.y - a.y, d.y - cc.y, a.y - d.y, 0};
+        ex[5] = -ex[1];
+        ey[5] = -ey[1];
+        int bs[6], row[6];
+        row[0] = mul24(ex[0], pby) - mul24(ey[0], pbx);
+        row[1] = mul24(ex[1], pcy) - mul24(ey[1], pcx);
+        row[2] = mul24(ex[2], pay) - mul24(ey[2], pax);
+        row[3] = mul24(ex[3], pcy) - mul24(ey[3], pcx);
+        row[4] = mul24(ex[4], pdy) - mul24(ey[4], pdx);
+        row[5] = -row[1];
+        const int area0 = row[0] + row[1] + row[2], area1 = row[3] + row[4] + row[5];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) u[k] = row[k];
-                for (int i = ci0; i <= ci1; ++i) {
-                    if ((u[0] | u[1] | u[2]) >= 0) {      // weights: edge k is opposite vertex k of (a, b, c)
-                        const float q = __builtin_fmaf((float)(u[2] + bs[2]), iwc,
-                                                       __builtin_fmaf((float)(u[1] + bs[1]), iwb,
-                                                                      (float)(u[0] + bs[0]) * iwa)) * inv0;
-                        vis_max(vis, v, i, j, ((unsigned long long)__float_as_uint(q) << 32) | lo0);
-                    }
-                    if ((u[3] | u[4] | u[5]) >= 0) {      // (a, c, d)
-                        const float q = __builtin_fmaf((float)(u[5] + bs[5]), iwd,
-                                                       __builtin_fmaf((float)(u[4] + bs[4]), iwc,
-                                                                      (float)(u[3] + bs[3]) * iwa)) * inv1;
-                        vis_max(vis, v, i, j, ((unsigned long long)__float_as_uint(q) << 32) | lo1);
-                    }
+        for (int k = 0; k < 6; ++k) {
+            // the edge owns its boundary iff dy < 0 or (dy == 0 and dx > 0) iff (dy << 12) - dx < 0
+            // (|dx| < 2^12 here: the cell's unclamped box spans fewer than 10 pixels)
+            bs[k] = 1 + (((ey[k] << 12) - ex[k]) >> 31);
+            row[k] -= bs[k];
+        }
+        const float iwa = s_iw[ia], iwb = s_iw[ib], iwc = s_iw[ic], iwd = s_iw[idd];
+        const float inv0 = 1.0f / (float)area0, inv1 = 1.0f / (float)area1;      // used only where area > 0
+        const unsigned long long lo0 = 0xFFFFFFFFu - 2u * cell, lo1 = lo0 - 1u;
+        for (int j = cj0; j <= cj1; ++j) {
+            int u[6];
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) u[k] -= ey[k] * SUB;
+            for (int k = 0; k < 6; ++k) u[k] = row[k];
+            for (int i = ci0; i <= ci1; ++i) {
+                if ((u[0] | u[1] | u[2]) >= 0) {      // weights: edge k is opposite vertex k of (a, b, c)
+                    const float q = __builtin_fmaf((float)(u[2] + bs[2]), iwc,
+                                                   __builtin_fmaf((float)(u[1] + bs[1]), iwb,
+                                                                  (float)(u[0] + bs[0]) * iwa)) * inv0;
+                    vis_max(vis, v, i, j, ((unsigned long long)__float_as_uint(q) << 32) | lo0);
+                }
+                if ((u[3] | u[4] | u[5]) >= 0) {      // (a, c, d)
+                    const float q = __builtin_fmaf((float)(u[5] + bs[5]), iwd,
+                                                   __builtin_fmaf((float)(u[4] + bs[4]), iwc,
+                                                                  (float)(u[3] + bs[3]) * iwa)) * inv1;
+                    vis_max(vis, v, i, j, ((unsigned long long)__float_as_uint(q) << 32) | lo1);
                 }
 #pragma unroll
-                for (int k = 0; k < 6; ++k) row[k] += ex[k] * SUB;
+                for (int k = 0; k < 6; ++k) u[k] -= ey[k] * SUB;
             }
-        }
-    }
-    if (!__ballot(work)) return;          // the whole wave is done (the usual case in the far field)
-    // triangles of the cell (surface.py:194-201): (a, b, c) and (a, c, d)
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int k1 = half ? ic : ib, k2 = half ? id : ic;
-        const int2 A = P[0], B = half ? P[2] : P[1], C = half ? P[3] : P[2];
-        const unsigned t = 2u * cell + (unsigned)half;
-        Deferred park;
-        int code = EMIT_DONE;
-        if (work) {
-            if (A.x > NODATA && B.x > NODATA && C.x > NODATA) {
-                const int X[3] = {A.x, B.x, C.x}, Y[3] = {A.y, B.y, C.y};
-                code = emit_small(v, X, Y, s_iw, ia, k1, k2, t, vis, &park, true);
-            } else if (A.x != NODATA && B.x != NODATA && C.x != NODATA &&
-                       !(A.x == BEHIND && B.x == BEHIND && C.x == BEHIND)) {
-                code = EMIT_GENERAL;      // near-plane crossing or out of range (all three behind: nothing to draw)
+            for (int k = 0; k < 6; ++k) row[k] += ex[k] * SUB;
+        }
+    }
+#if defined(GRID_STOP_AFTER) && GRID_STOP_AFTER == 3
+    return;
+#endif
+#ifdef ALP_WG_TIMING
+    __syncthreads();
+#endif
+    WGT(3);
+    // ---- phase 4: SLOW cells, triangle by triangle: (a, b, c) and (a, c, d) (surface.py:194-201).
+    // Wave-converged (coop_drain is wave-wide): every lane of a wave makes the same number of rounds.
+#pragma unroll 1
+    for (int e0 = (int)(threadIdx.x & ~63u); e0 < nslow; e0 += 256) {
+        const int e = e0 + lane;
+        const bool work = e < nslow;
+        const int id = work ? (int)s_q[GT_NC - 1 - e] : 0;
+        int lr, lc;
+        cell_rc(id, lr, lc);
+        const int ia = lr * GT_VW + lc, ib = ia + GT_VW, ic = ib + 1, idd = ia + 1;
+        const int2 P0 = s_xy[ia], P1 = s_xy[ib], P2 = s_xy[ic], P3 = s_xy[idd];
+        const unsigned cell = (unsigned)(r0 + lr) * (unsigned)(gw - 1) + (unsigned)(c0 + lc);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int k1 = half ? ic : ib, k2 = half ? idd : ic;
+            const int2 A = P0, B = half ? P2 : P1, C = half ? P3 : P2;
+            const unsigned t = 2u * cell + (unsigned)half;
+            Deferred park;
+            int code = EMIT_DONE;
+            if (work) {
+                if (A.x > NODATA && B.x > NODATA && C.x > NODATA) {
+                    const int X[3] = {A.x, B.x, C.x}, Y[3] = {A.y, B.y, C.y};
+                    code = emit_small(v, X, Y, s_iw, ia, k1, k2, t, vis, &park, true, COOP_MIN_W, COOP_MIN_PIX, true);
+                } else if (A.x != NODATA && B.x != NODATA && C.x != NODATA &&
+                           !(A.x == BEHIND && B.x == BEHIND && C.x == BEHIND)) {
+                    code = EMIT_GENERAL;      // near-plane crossing or out of range (all three behind: nothing to draw)
+                }
+                if (code == EMIT_GENERAL) {   // rare: raster_general_kernel redoes this triangle from its vertices
+                    const unsigned slot = atomicAdd(gcount, 1u);
+                    if (slot < gcap) gqueue[slot] = t;
+                }
             }
-            if (code == EMIT_GENERAL) {   // rare: raster_general_kernel redoes this triangle from its vertices
-                const unsigned slot = atomicAdd(gcount, 1u);
-                if (slot < gcap) gqueue[slot] = t;
+            // parked triangles are only noted here (every lane of the wave arrives here) ...
+            const unsigned long long ms = __ballot(code == EMIT_PARKED_SMALL), ml = __ballot(code == EMIT_PARKED);
+            if (ms) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(&s_npark[0], (unsigned)__popcll(ms));
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                if (code == EMIT_PARKED_SMALL) s_park[base + __popcll(ms & ((1ull << lane) - 1ull))] = (unsigned short)(2 * id + half);
+            }
+            if (ml) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(&s_npark[1], (unsigned)__popcll(ml));
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                if (code == EMIT_PARKED) s_park[2 * GT_NC - 1 - (base + __popcll(ml & ((1ull << lane) - 1ull)))] = (unsigned short)(2 * id + half);
             }
         }
-        coop_drain(v, code == EMIT_PARKED, park, vis);      // every lane of the wave arrives here
     }
+    // ---- phase 5: ... and leave the workgroup together: ONE reservation per queue and workgroup in the
+    // device queues (a reservation per wave and round made the two global counters the bottleneck of the
+    // near tiles: 0.5 ms of same-address atomics), then every thread writes whole entries.
+    __syncthreads();
+    const unsigned np_small = s_npark[0], np_large = s_npark[1];
+    if (np_small + np_large == 0) return;
+    if (threadIdx.x < 2) {
+        const unsigned cnt = threadIdx.x ? np_large : np_small;
+        s_park_base[threadIdx.x] = cnt ? atomicAdd(park_counts + threadIdx.x, cnt) : 0u;
+    }
+    __syncthreads();
+    for (unsigned e = threadIdx.x; e < np_small + np_large; e += 256) {
+        const bool large = e >= np_small;
+        const unsigned k = large ? e - np_small : e;
+        const unsigned code = large ? s_park[2 * GT_NC - 1 - k] : s_park[k];
+        const int id = (int)(code >> 1), half = (int)(code & 1u);
+        int lr, lc;
+        cell_rc(id, lr, lc);
+        const int ia = lr * GT_VW + lc, ib = ia + GT_VW, ic = ib + 1, idd = ia + 1;
+        const int k1 = half ? ic : ib, k2 = half ? idd : ic;
+        const int2 A = s_xy[ia], B = s_xy[k1], C = s_xy[k2];
+        Deferred d;
+        d.X[0] = A.x; d.X[1] = B.x; d.X[2] = C.x;
+        d.Y[0] = A.y; d.Y[1] = B.y; d.Y[2] = C.y;
+        d.iw[0] = s_iw[ia]; d.iw[1] = s_iw[k1]; d.iw[2] = s_iw[k2];
+        d.t = 2u * ((unsigned)(r0 + lr) * (unsigned)(gw - 1) + (unsigned)(c0 + lc)) + (unsigned)half;
+        const unsigned slot = s_park_base[large ? 1 : 0] + k;
+        Deferred *queue = large ? park_large : park_small;
+        if (slot < (large ? park_cap_large : park_cap_small)) queue[slot] = d;    // an overflow is noticed by finish_frame
+    }
+#ifdef ALP_WG_TIMING
+    __syncthreads();
+#endif
+    WGT(4);
 }
 
 // ------------------------------------------------------------------ kernel 3: large triangles
@@ -1108,6 +1691,18 @@ unsigned initial_queue_cap() {
     return 1u << 20;
 }
 
+int ensure_park(alp_mesh *m, unsigned cap_small, unsigned cap_large) {
+    if (m->park_small && m->park_cap[0] >= cap_small && m->park_cap[1] >= cap_large) return ALP_OK;
+    if (m->park_small) hipFree(m->park_small);
+    m->park_small = nullptr;
+    m->park_large = nullptr;
+    ALP_HIP(hipMalloc((void **)&m->park_small, ((size_t)cap_small + cap_large) * sizeof(Deferred)));
+    m->park_large = (Deferred *)m->park_small + cap_small;
+    m->park_cap[0] = cap_small;
+    m->park_cap[1] = cap_large;
+    return ALP_OK;
+}
+
 int ensure_gqueue(alp_mesh *m, unsigned cap) {
     if (m->gqueue && m->gcap >= cap) return ALP_OK;
     if (m->gqueue) hipFree(m->gqueue);
@@ -1129,6 +1724,9 @@ int ensure_frame(alp_mesh *m, int w, int h) {
     m->image = nullptr;
     ALP_HIP(hipMalloc((void **)&m->vis, (size_t)w * h * sizeof(unsigned long long)));
     ALP_HIP(hipMalloc((void **)&m->image, (size_t)w * h * 3 * sizeof(float)));
+    if (m->hiz) hipFree(m->hiz);
+    m->hiz = nullptr;
+    ALP_HIP(hipMalloc((void **)&m->hiz, (size_t)hiz_total(w, h) * sizeof(unsigned)));
     m->w = w;
     m->h = h;
     return ALP_OK;
@@ -1143,15 +1741,128 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
     const int cu = ctx().cu_count;
     ALP_HIP(hipMemsetAsync(m->vis, 0, (size_t)v.w * v.h * sizeof(unsigned long long), st));
     if (m->n_tri > 0) {
-        ALP_HIP(hipMemsetAsync(m->qcount_dev, 0, 2 * sizeof(unsigned), st));
+        // queue counters, four per round: [0] work items, [1] general entries, [2] small parked, [3] large parked
+        ALP_HIP(hipMemsetAsync(m->qcount_dev, 0, 8 * sizeof(unsigned), st));
+        // the consumers of the rare cases (near-plane crossings, 64 px and more) of one round
+        auto drain_round = [&](int round) -> int {
+            unsigned *items = m->qcount_dev + 4 * round, *general = items + 1;
+            hipLaunchKernelGGL((raster_general_kernel<IMPLICIT>), dim3(cu * 2), dim3(256), 0, st, m->vert, m->ind,
+                               (long long)m->grid_w, v, m->vis, m->gqueue, general, m->gcap, m->queue, items, m->qcap);
+            ALP_HIP(hipGetLastError());
+            hipLaunchKernelGGL((raster_large_kernel<IMPLICIT>), dim3(cu * 8), dim3(256), 0, st, m->vert, m->ind,
+                               (long long)m->grid_w, v, m->vis, m->queue, items, m->qcap);
+            ALP_HIP(hipGetLastError());
+            if constexpr (IMPLICIT) {          // the triangles the grid kernel parked
+                hipLaunchKernelGGL(raster_coop4_kernel, dim3(cu * 8), dim3(256), 0, st, v, m->vis, m->park_small, items + 2,
+                                   m->park_cap[0]);
+                ALP_HIP(hipGetLastError());
+                hipLaunchKernelGGL(raster_coop_kernel, dim3(cu * 8), dim3(256), 0, st, v, m->vis, m->park_large, items + 3,
+                                   m->park_cap[1]);
+                ALP_HIP(hipGetLastError());
+            }
+            return ALP_OK;
+        };
         if constexpr (IMPLICIT) {
-            const long long tiles = ((m->grid_w - 1 + GT_W - 1) / GT_W) * ((m->grid_h - 1 + GT_H - 1) / GT_H);
+            if (!m->park_small) {
+                // ~1.2 M small and ~0.2 M large parked triangles per 5616 x 3744 frame of the 100 M-vertex DSM
+                const unsigned cap = initial_queue_cap();
+                const bool dflt = cap == (1u << 20);
+                if (int e = ensure_park(m, dflt ? 4u << 20 : cap, cap)) return e;
+            }
+            const int tiles_x = (int)((m->grid_w - 1 + GT_W - 1) / GT_W);
+            const long long tiles = (long long)tiles_x * ((m->grid_h - 1 + GT_H - 1) / GT_H);
+            if (!m->tile_bounds) {      // once per mesh: the vertices never change
+                ALP_HIP(hipMalloc((void **)&m->tile_bounds, (size_t)tiles * 6 * sizeof(float)));
+                // three tile lists (near, far, far survivors) + their three counters
+                ALP_HIP(hipMalloc((void **)&m->tile_lists, (size_t)(3 * tiles + 4) * sizeof(unsigned)));
+                hipLaunchKernelGGL(tile_bounds_kernel, dim3((unsigned)tiles), dim3(256), 0, st, m->vert, (int)m->grid_h,
+                                   (int)m->grid_w, tiles_x, m->tile_bounds);
+                ALP_HIP(hipGetLastError());
+            }
+            unsigned *near_list = m->tile_lists, *far_list = near_list + tiles, *second_list = far_list + tiles,
+                     *counts = second_list + tiles;      // [0] near, [1] far, [2] far survivors
+            ALP_HIP(hipMemsetAsync(counts, 0, 4 * sizeof(unsigned), st));
+            TileCull cull;
+            make_tile_cull(v, &cull);
+            if (getenv("ALP_NO_TILE_CULL")) cull.enabled = 0;     // development: measure / cross-check the exact path alone
+            if (getenv("ALP_NO_OCCLUSION")) cull.occlusion = 0;   // development: frustum culling only, one round
             // vertices are X, Z, Y: columns step X (R[0][0] on screen x), rows step Y (R[0][2])
             int along_rows = std::fabs(v.R[0][2]) > std::fabs(v.R[0][0]);
             if (const char *e = getenv("ALP_GRID_LANES")) along_rows = e[0] == 'r';   // development override
-            hipLaunchKernelGGL(raster_grid_kernel, dim3((unsigned)tiles), dim3(256), 0, st, m->vert, m->valid,
+            const unsigned plan_grid = (unsigned)((tiles + 255) / 256);
+            const unsigned grid_wgs = (unsigned)((tiles + 7) / 8 * 8);     // whole turns of the 8 XCDs (see the kernel's phase 0)
+            hipLaunchKernelGGL(tile_plan_kernel, dim3(plan_grid), dim3(256), 0, st, m->tile_bounds, (unsigned)tiles, cull,
+                               near_list, far_list, counts);
+            ALP_HIP(hipGetLastError());
+            // first round: the near tiles (the occluders).  One workgroup per possible list entry; the
+            // ones beyond the list's length leave at once.
+            hipLaunchKernelGGL(raster_grid_kernel, dim3(grid_wgs), dim3(256), 0, st, m->vert, m->valid,
                                (int)m->grid_h, (int)m->grid_w, v, m->vis, m->gqueue, m->qcount_dev + 1, m->gcap,
-                               along_rows);
+                               along_rows, near_list, counts + 0, m->park_small, m->park_large, m->qcount_dev + 2,
+                               m->park_cap[0], m->park_cap[1]);
+            ALP_HIP(hipGetLastError());
+#ifdef ALP_WG_TIMING
+            {   // duration of every workgroup of the first round
+                ALP_HIP(hipStreamSynchronize(st));
+                unsigned hc[4];
+                ALP_HIP(hipMemcpy(hc, counts, sizeof(hc), hipMemcpyDeviceToHost));
+                std::vector<unsigned long long> tt(8 * (size_t)hc[0]);
+                ALP_HIP(hipMemcpyFromSymbol(tt.data(), HIP_SYMBOL(g_wgtime), tt.size() * 8));
+                unsigned long long t0 = ~0ull, t1 = 0;
+                std::vector<double> dur;
+                double phase[4] = {0, 0, 0, 0};
+                for (unsigned i = 0; i < hc[0] && i < 131072; ++i) {
+                    t0 = std::min(t0, tt[8 * i]);
+                    t1 = std::max(t1, tt[8 * i + 4]);
+                    dur.push_back((tt[8 * i + 4] - tt[8 * i]) / 100.0);
+                    for (int k = 0; k < 4; ++k) phase[k] += (tt[8 * i + k + 1] - tt[8 * i + k]) / 100.0;
+                }
+                std::vector<double> sorted = dur;
+                std::sort(sorted.begin(), sorted.end());
+                double sum = 0;
+                for (double d : dur) sum += d;
+                fprintf(stderr, "[wg timing] first round: %u workgroups, span %.1f us, sum of durations %.0f us (vertices %.0f, classify %.0f, fast %.0f, slow %.0f), "
+                                "median %.1f, p90 %.1f, p99 %.1f, max %.1f us\n", hc[0], (t1 - t0) / 100.0, sum, phase[0], phase[1], phase[2], phase[3],
+                        sorted[sorted.size() / 2], sorted[sorted.size() * 9 / 10], sorted[sorted.size() * 99 / 100], sorted.back());
+                std::vector<unsigned> idx(dur.size());
+                for (unsigned i = 0; i < idx.size(); ++i) idx[i] = i;
+                std::partial_sort(idx.begin(), idx.begin() + std::min<size_t>(8, idx.size()), idx.end(), [&](unsigned a, unsigned b) { return dur[a] > dur[b]; });
+                for (size_t k = 0; k < std::min<size_t>(8, idx.size()); ++k) {
+                    const unsigned i = idx[k];
+                    fprintf(stderr, "   wg %u: start +%.1f us, duration %.1f us = vertices %.1f + classify %.1f + fast %.1f + slow %.1f\n", i,
+                            (tt[8 * i] - t0) / 100.0, dur[i], (tt[8 * i + 1] - tt[8 * i]) / 100.0, (tt[8 * i + 2] - tt[8 * i + 1]) / 100.0,
+                            (tt[8 * i + 3] - tt[8 * i + 2]) / 100.0, (tt[8 * i + 4] - tt[8 * i + 3]) / 100.0);
+                }
+            }
+#endif
+            if (int e = drain_round(0)) return e;
+            if (cull.enabled && cull.occlusion) {
+                // depth pyramid of what the first round drew, occlusion test of the far tiles, second round
+                const HizDims dm = hiz_dims(v.w, v.h);
+                hipLaunchKernelGGL(hiz_build_kernel, dim3((unsigned)dm.w[3], (unsigned)dm.h[3]), dim3(256), 0, st, m->vis, v.w,
+                                   v.h, dm, m->hiz);
+                ALP_HIP(hipGetLastError());
+                hipLaunchKernelGGL(hiz_top_kernel, dim3((unsigned)((dm.w[5] * dm.h[5] + 255) / 256)), dim3(256), 0, st, dm, m->hiz);
+                ALP_HIP(hipGetLastError());
+                hipLaunchKernelGGL(tile_occlusion_kernel, dim3(plan_grid), dim3(256), 0, st, m->tile_bounds, cull, far_list,
+                                   counts, dm, m->hiz, second_list, counts + 2);
+                ALP_HIP(hipGetLastError());
+                hipLaunchKernelGGL(raster_grid_kernel, dim3(grid_wgs), dim3(256), 0, st, m->vert, m->valid,
+                                   (int)m->grid_h, (int)m->grid_w, v, m->vis, m->gqueue, m->qcount_dev + 5, m->gcap,
+                                   along_rows, second_list, counts + 2, m->park_small, m->park_large, m->qcount_dev + 6,
+                                   m->park_cap[0], m->park_cap[1]);
+                ALP_HIP(hipGetLastError());
+                if (int e = drain_round(1)) return e;
+            }
+#ifdef ALP_RASTER_STATS
+            {
+                unsigned hc[4];
+                ALP_HIP(hipMemcpyAsync(hc, counts, sizeof(hc), hipMemcpyDeviceToHost, st));
+                ALP_HIP(hipStreamSynchronize(st));
+                fprintf(stderr, "[frame plan] tiles %lld: near %u, far %u of which %u survive the occlusion test\n", tiles, hc[0],
+                        hc[1], hc[2]);
+            }
+#endif
         } else {
             const long long want = (m->n_tri + 255) / 256;
 #ifndef RASTER_BLOCKS_PER_CU
@@ -1161,16 +1872,10 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
             hipLaunchKernelGGL((raster_kernel<IMPLICIT>), dim3(grid), dim3(256), 0, st, m->vert, m->ind, m->valid,
                                (long long)m->n_tri, (long long)m->grid_w, v, m->vis, m->gqueue, m->qcount_dev + 1,
                                m->gcap);
+            ALP_HIP(hipGetLastError());
+            if (int e = drain_round(0)) return e;
         }
-        ALP_HIP(hipGetLastError());
-        hipLaunchKernelGGL((raster_general_kernel<IMPLICIT>), dim3(cu * 2), dim3(256), 0, st, m->vert, m->ind,
-                           (long long)m->grid_w, v, m->vis, m->gqueue, m->qcount_dev + 1, m->gcap, m->queue,
-                           m->qcount_dev, m->qcap);
-        ALP_HIP(hipGetLastError());
-        hipLaunchKernelGGL((raster_large_kernel<IMPLICIT>), dim3(cu * 8), dim3(256), 0, st, m->vert, m->ind,
-                           (long long)m->grid_w, v, m->vis, m->queue, m->qcount_dev, m->qcap);
-        ALP_HIP(hipGetLastError());
-        ALP_HIP(hipMemcpyAsync(m->qcount_host, m->qcount_dev, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        ALP_HIP(hipMemcpyAsync(m->qcount_host, m->qcount_dev, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     }
     const long long npix = (long long)v.w * v.h;
     const long long want = (npix + 255) / 256;
@@ -1191,12 +1896,14 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
     m->unchecked = m->n_tri > 0;
 #ifdef ALP_RASTER_STATS
     {
-        unsigned long long hs[16], zero[16] = {0};
+        unsigned long long hs[24], zero[24] = {0};
         ALP_HIP(hipStreamSynchronize(st));
         ALP_HIP(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_rstat), sizeof(hs)));
         ALP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rstat), zero, sizeof(zero)));
         fprintf(stderr, "[raster stats] inline tris %llu | inline fragments by bbox width: 1px %llu, 2-3 %llu, 4-7 %llu, "
                         ">=8 %llu | coop tris %llu fragments %llu\n", hs[2], hs[3], hs[4], hs[5], hs[6], hs[8], hs[7]);
+        fprintf(stderr, "[grid stats] (unused %llu) tiles drawn %llu | FAST cells %llu (wave rounds %llu) SLOW cells %llu (wave "
+                        "rounds %llu)\n", hs[9], hs[10], hs[11], hs[13], hs[12], hs[14]);
     }
 #endif
     m->rendered = true;
@@ -1210,8 +1917,16 @@ int finish_frame(alp_mesh *m) {
     while (m->unchecked) {
         ALP_HIP(hipStreamSynchronize(ctx().stream));
         m->unchecked = false;
-        const unsigned items = m->qcount_host[0], general = m->qcount_host[1];
-        if (items <= m->qcap && general <= m->gcap) break;
+        const unsigned items = std::max(m->qcount_host[0], m->qcount_host[4]),
+                       general = std::max(m->qcount_host[1], m->qcount_host[5]),
+                       psmall = std::max(m->qcount_host[2], m->qcount_host[6]),
+                       plarge = std::max(m->qcount_host[3], m->qcount_host[7]);
+        const bool park_ok = !m->park_small || (psmall <= m->park_cap[0] && plarge <= m->park_cap[1]);
+        if (items <= m->qcap && general <= m->gcap && park_ok) break;
+        if (!park_ok)
+            if (int e = ensure_park(m, std::max(m->park_cap[0], psmall + psmall / 4 + 1024),
+                                    std::max(m->park_cap[1], plarge + plarge / 4 + 1024)))
+                return e;
         if (items > m->qcap)
             if (int e = ensure_queue(m, items + items / 4 + 1024)) return e;
         if (general > m->gcap)
@@ -1287,8 +2002,8 @@ int alp_mesh_create(const float *vert, const float *value, int64_t n_vert, const
             if (rc) return bail(rc);
         }
     }
-    if (hipMalloc((void **)&m->qcount_dev, 2 * sizeof(unsigned)) != hipSuccess ||
-        hipHostMalloc((void **)&m->qcount_host, 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess)
+    if (hipMalloc((void **)&m->qcount_dev, 8 * sizeof(unsigned)) != hipSuccess ||
+        hipHostMalloc((void **)&m->qcount_host, 8 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess)
         return bail(fail(ALP_EHIP, "hipMalloc queue counter"));
     if ((rc = ensure_queue(m, initial_queue_cap()))) return bail(rc);
     if ((rc = ensure_gqueue(m, initial_queue_cap()))) return bail(rc);
@@ -1329,7 +2044,8 @@ int alp_mesh_destroy(alp_mesh_t *m) {
     if (!m) return ALP_OK;
     if (ctx().ready) hipStreamSynchronize(ctx().stream);
     for (void *p : {(void *)m->vert, (void *)m->value, (void *)m->ind, (void *)m->valid, (void *)m->vis, (void *)m->image,
-                    (void *)m->queue, (void *)m->gqueue, (void *)m->qcount_dev, (void *)m->compact_counts, (void *)m->compact_offsets})
+                    (void *)m->queue, (void *)m->gqueue, (void *)m->qcount_dev, (void *)m->compact_counts, (void *)m->compact_offsets,
+                    (void *)m->tile_bounds, (void *)m->tile_lists, (void *)m->hiz, (void *)m->park_small})
         if (p) hipFree(p);
     if (m->qcount_host) hipHostFree(m->qcount_host);
     delete m;

@@ -21,6 +21,15 @@ struct RemapCoef {     // inverted coefficients of project.py:136-137, float64
 
 struct WorkItem { unsigned tri; unsigned short sub, tx, ty, pad; };   // sub: fan triangle 0/1
 
+// A snapped window-space triangle set aside ("parked") for a cooperative rasterisation: by the rest of its
+// wave (raster_kernel: coop_drain) or, from raster_grid_kernel, through the device queues of
+// raster_coop4_kernel / raster_coop_kernel.
+struct Deferred {
+    int X[3], Y[3];
+    float iw[3];
+    unsigned t;
+};
+
 }  // namespace alp
 
 struct alp_mesh {
@@ -29,6 +38,9 @@ struct alp_mesh {
     float *vert = nullptr, *value = nullptr;
     int *ind = nullptr;
     unsigned char *valid = nullptr;    // optional, per vertex: 0 = nodata, its triangles are not drawn
+    float *tile_bounds = nullptr;      // implicit grid: bounding box (centre, half extent) per raster_grid_kernel tile
+    unsigned *tile_lists = nullptr;    // implicit grid: near / far / surviving-far tile ids of the current frame + counters
+    unsigned *hiz = nullptr;           // depth pyramid of the current frame size (levels 8 .. 256 px)
     bool coords_as_value = false;      // render the vertices themselves (reverse_proj) although values are stored
     // per-render state (sized on first use)
     int w = 0, h = 0;
@@ -38,8 +50,10 @@ struct alp_mesh {
     unsigned qcap = 0;
     unsigned *gqueue = nullptr;        // general queue: triangle ids set aside by raster_grid_kernel
     unsigned gcap = 0;
-    unsigned *qcount_dev = nullptr;    // [0] work items, [1] general-queue entries
-    unsigned *qcount_host = nullptr;   // pinned copy of the two counters of the last frame
+    alp::Deferred *park_small = nullptr, *park_large = nullptr;   // implicit grid: parked triangles (one allocation)
+    unsigned park_cap[2] = {0, 0};
+    unsigned *qcount_dev = nullptr;    // per round (2 rounds) [0] work items, [1] general entries, [2] small parked, [3] large parked
+    unsigned *qcount_host = nullptr;   // pinned copy of the eight counters of the last frame
     bool unchecked = false;            // last frame enqueued, its queue counters not yet checked (finish_frame)
     alp::View last_v;
     alp::RemapCoef last_rc;
@@ -57,5 +71,6 @@ namespace alp {
 int upload_chunked(void *dst, const void *src, size_t bytes);
 int ensure_queue(alp_mesh *m, unsigned cap);
 int ensure_gqueue(alp_mesh *m, unsigned cap);
+int ensure_park(alp_mesh *m, unsigned cap_small, unsigned cap_large);
 unsigned initial_queue_cap();
 }  // namespace alp

@@ -63,30 +63,40 @@ def test_g13_distort_map_on_the_device(L, name, size):
     np.testing.assert_array_equal(got, orc.remap_nearest(index_img, g[f"mapx_{name}_{size}"], g[f"mapy_{name}_{size}"]))
 
 
-@pytest.mark.parametrize("case", ["trf_linear_d7", "trf_huber_d9", "dogbox_softl1_d4", "lm_d4"])
+LSQ_KW = {"trf_linear_d7": dict(method="trf"),
+          "trf_huber_d7": dict(method="trf", loss="huber", f_scale=5.0),
+          "dogbox_softl1_d4": dict(method="dogbox", loss="soft_l1", f_scale=3.0,
+                                   bound_widths={"fov": 10, "pan": 10, "tilt": 10, "roll": 10}),
+          "trf_cauchy_d4": dict(method="trf", loss="cauchy", f_scale=2.0),
+          "lm_d4": dict(method="lm"),
+          "trf_linear_dist_d6": dict(method="trf")}
+
+
+@pytest.mark.parametrize("case", list(LSQ_KW))
 def test_g14_lsq_optimizer_matches_the_reference_run(L, case):
-    """LsqOptimizer.optimize of the reference (optimize.py:467-539, scipy least_squares) on a seeded GCP
-    set: same optimum and error from the device residuals.  jac='2-point' = scipy's own sequential
-    differences (the reference's call), and the batched Jacobian (one launch for D+1 poses)."""
+    """LsqOptimizer.optimize of the reference (optimize.py:467-539, scipy least_squares) on seeded,
+    well-posed GCP problems: same optimum and error from the device residuals.  jac='2-point' =
+    scipy's own sequential differences (the reference's call); 'batched' = the D+1 poses of the same
+    scheme in one launch.  Tolerance: the reference's own optimum moves when its residuals are
+    perturbed by 1e-13 (finite differences with a 1.5e-8 step amplify them; least_squares stops at
+    ftol = 1e-8), see below."""
     from alproj_amd import optimize as aopt
     g = load("g14_lsq.npz")
     keys = [str(k) for k in g["param_keys"]]
-    init = dict(zip(keys, g["params_init"]))
+    init = dict(zip(keys, g[f"{case}_init"]))
     dfx = pd.DataFrame(g["xyz"], columns=["x", "y", "z"])
-    dfu = pd.DataFrame(g["uv"], columns=["u", "v"])
-    kw = {"trf_linear_d7": dict(method="trf"),
-          "trf_huber_d9": dict(method="trf", loss="huber", f_scale=5.0),
-          "dogbox_softl1_d4": dict(method="dogbox", loss="soft_l1", f_scale=3.0,
-                                   bound_widths={"fov": 10, "pan": 10, "tilt": 10, "roll": 10}),
-          "lm_d4": dict(method="lm")}[case]
+    dfu = pd.DataFrame(g["uv_" + str(g[f"{case}_uv"])], columns=["u", "v"])
     targets = [str(t) for t in g[f"{case}_targets"]]
     want = dict(zip(keys, g[f"{case}_params"]))
     for jac in ("2-point", "batched"):
         o = aopt.LsqOptimizer(dfx, dfu, dict(init))
         o.set_target(targets)
-        params, err = o.optimize(jac=jac, **kw)
+        params, err = o.optimize(jac=jac, **LSQ_KW[case])
         assert set(params) == set(want)
-        tol = 1e-7 if jac == "2-point" else 1e-5
+        # measured on the reference itself (1e-13 .. 1e-12 residual perturbations): pose parameters move
+        # by up to 2e-5 (metres / degrees), distortion coefficients by 2e-7, the error by 1e-5 relative
         for k in targets:
-            assert params[k] == pytest.approx(want[k], rel=tol, abs=tol * 1e-2), (jac, k)
-        assert err == pytest.approx(float(g[f"{case}_error"]), rel=1e-8 if jac == "2-point" else 1e-6)
+            tol = 2e-4 if k in ("x", "y", "z", "fov", "pan", "tilt", "roll") else 2e-6
+            assert abs(params[k] - want[k]) <= tol, (jac, k, params[k], want[k])
+        assert err == pytest.approx(float(g[f"{case}_error"]), rel=5e-5)
+        assert err < 2.5

@@ -124,7 +124,9 @@ def test_project_c1_dsm_316(L):
     for cam in (syn.standoff_params(n), syn.perturbed(syn.standoff_params(n))):
         ref = orc.project_points(xyz, cam)
         got64 = _project(L, xyz, cam, L.params_vector(cam), "f64")
-        np.testing.assert_allclose(got64, ref, rtol=1e-9, atol=1e-9)
+        # part of this DSM lies far outside the image (v up to 1.4e4 px), where the distortion
+        # polynomial cancels: the reference's own rounding there is ~1e-8 px (cf. test_project_f64_golden)
+        np.testing.assert_allclose(got64, ref, rtol=1e-9, atol=1e-7)
         got32 = _project(L, xyz, cam, L.params_vector(cam), "f32")
         rep = assert_f32_close(got32, ref, cam["w"], label="c1 316x316 DSM")
         assert rep["strict_rel_pass_fraction"] > 0.99
