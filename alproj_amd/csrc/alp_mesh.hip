@@ -187,8 +187,8 @@ int alp_mesh_from_rasters(const void *dsm, int dsm_dtype, int64_t rows, int64_t 
     dsm_dev = aer_dev = nullptr;
     nod_dev = nullptr;
     zmin_dev = nullptr;
-    if (hipMalloc((void **)&m->qcount_dev, 8 * sizeof(unsigned)) != hipSuccess ||
-        hipHostMalloc((void **)&m->qcount_host, 8 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess)
+    if (hipMalloc((void **)&m->qcount_dev, QC_TOTAL * sizeof(unsigned)) != hipSuccess ||
+        hipHostMalloc((void **)&m->qcount_host, QC_TOTAL * sizeof(unsigned), hipHostMallocDefault) != hipSuccess)
         return bail(fail(ALP_EHIP, "hipMalloc queue counter"));
     if ((rc = ensure_queue(m, initial_queue_cap()))) return bail(rc);
     if ((rc = ensure_gqueue(m, initial_queue_cap()))) return bail(rc);

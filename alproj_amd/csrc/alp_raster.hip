@@ -124,8 +124,22 @@ __device__ __forceinline__ void to_view(const View &v, float px, float py, float
         out[i] = __builtin_fmaf(v.R[i][0], dx, __builtin_fmaf(v.R[i][1], dy, v.R[i][2] * dz));
 }
 
+// The correctly rounded float32 reciprocal 1.0f / x in three instructions: v_rcp_f32 and one Newton step
+// with fused multiply-adds.  On gfx950 this equals the IEEE division for EVERY mantissa (exhaustive check:
+// tools/rcp_exact.hip, all 2^23 mantissas for exponents 0 .. 60; scaling by a power of two is exact in
+// that range), so the specification's "IEEE division"  is met bit for bit at a
+// third of the ~11 instructions of the generic expansion.  Outside [1, 2^60) the generic division runs.
+__device__ __forceinline__ float exact_rcp_unchecked(float x) {       // x in [1, 2^60) -- or the result is not used
+    const float y = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(y, __builtin_fmaf(-x, y, 1.0f), y);
+}
+__device__ __forceinline__ float exact_rcp(float x) {
+    if (__builtin_expect(!(x >= 1.0f && x < 1.0e18f), 0)) return 1.0f / x;
+    return exact_rcp_unchecked(x);
+}
+
 __device__ __forceinline__ void to_window(const View &v, const float q[3], float &xw, float &yw, float &iw) {
-    const float i = 1.0f / q[2];
+    const float i = exact_rcp(q[2]);
     iw = i;
     xw = __builtin_fmaf((v.fx * q[0]) * i, v.sx, v.sx);
     yw = __builtin_fmaf((v.fy * q[1]) * i, v.sy, v.sy);
@@ -414,7 +428,7 @@ __device__ __forceinline__ void coop_raster(const View &v, const int X[3], const
         ya[k] = Y[a];
         bias[k] = (dy[k] < 0 || (dy[k] == 0 && dx[k] > 0)) ? 0 : 1;
     }
-    const float inv_area = 1.0f / (float)area2;
+    const float inv_area = exact_rcp_unchecked((float)area2);
     const unsigned long long lo = (unsigned long long)(0xFFFFFFFFu - t);
     const int lx = lane & 7, ly = lane >> 3;
     for (int by = cj0; by <= cj1; by += 8)
@@ -501,7 +515,7 @@ __device__ __forceinline__ int emit_small(const View &v, const int X[3], const i
         bias[k] = (dy[k] < 0 || (dy[k] == 0 && dx[k] > 0)) ? 0 : 1;
         row[k] = mul24(dx[k], py0 - Y[a]) - mul24(dy[k], px0 - X[a]) - bias[k];
     }
-    const float inv_area = 1.0f / (float)area2;
+    const float inv_area = exact_rcp_unchecked((float)area2);
     const unsigned long long lo = (unsigned long long)(0xFFFFFFFFu - t);
     RSTAT(2, 1);
     for (int j = cj0; j <= cj1; ++j) {
@@ -603,10 +617,16 @@ __global__ __launch_bounds__(256) void raster_coop_kernel(View v, unsigned long 
                                                           const unsigned *__restrict__ count, unsigned cap) {
     const unsigned n = min(*count, cap);
     const int lane = (int)(threadIdx.x & 63);
-    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-    const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (unsigned it = wave; it < n; it += nwaves) {
-        const Deferred d = queue[it];          // wave-uniform address
+    // workgroups go to the 8 XCDs round-robin: XCD x takes the x-th contiguous eighth of the queue
+    // (neighbouring entries are neighbouring triangles: their pixels meet in one L2)
+    const unsigned chunk = (n + 7u) >> 3, xcd = blockIdx.x & 7u, lo = xcd * chunk, hi = min(lo + chunk, n);
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(((blockIdx.x >> 3) * blockDim.x + threadIdx.x) >> 6));
+    const unsigned nwaves = ((gridDim.x >> 3) * blockDim.x) >> 6;
+    if (lo + wave >= hi) return;
+    Deferred nextd = queue[lo + wave];         // wave-uniform address
+    for (unsigned it = lo + wave; it < hi; it += nwaves) {
+        const Deferred d = nextd;
+        if (it + nwaves < hi) nextd = queue[it + nwaves];        // requested before this one is rasterised
         int X[3], Y[3];
         float iw3[3];
 #pragma unroll
@@ -623,10 +643,14 @@ __global__ __launch_bounds__(256) void raster_coop4_kernel(View v, unsigned long
                                                            const Deferred *__restrict__ queue,
                                                            const unsigned *__restrict__ count, unsigned cap) {
     const unsigned n = min(*count, cap);
-    const unsigned group = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, ngroups = (gridDim.x * blockDim.x) >> 4;
+    const unsigned chunk = (n + 7u) >> 3, xcd = blockIdx.x & 7u, lo = xcd * chunk, hi = min(lo + chunk, n);   // as in raster_coop_kernel
+    const unsigned group = ((blockIdx.x >> 3) * blockDim.x + threadIdx.x) >> 4, ngroups = ((gridDim.x >> 3) * blockDim.x) >> 4;
     const int lx = (int)(threadIdx.x & 3), ly = (int)((threadIdx.x >> 2) & 3);
-    for (unsigned it = group; it < n; it += ngroups) {
-        const Deferred d = queue[it];          // the 16 lanes of a group read the same entry
+    if (lo + group >= hi) return;
+    Deferred nextd = queue[lo + group];        // the 16 lanes of a group read the same entry
+    for (unsigned it = lo + group; it < hi; it += ngroups) {
+        const Deferred d = nextd;
+        if (it + ngroups < hi) nextd = queue[it + ngroups];      // requested before this one is rasterised
         const int minx = min(d.X[0], min(d.X[1], d.X[2])), maxx = max(d.X[0], max(d.X[1], d.X[2]));
         const int miny = min(d.Y[0], min(d.Y[1], d.Y[2])), maxy = max(d.Y[0], max(d.Y[1], d.Y[2]));
         const int ci0 = max((minx + SUB / 2 - 1) >> 8, 0), ci1 = min((maxx - SUB / 2) >> 8, v.w - 1);
@@ -640,7 +664,7 @@ __global__ __launch_bounds__(256) void raster_coop4_kernel(View v, unsigned long
             dy[k] = d.Y[b] - d.Y[a];
             bias[k] = (dy[k] < 0 || (dy[k] == 0 && dx[k] > 0)) ? 0 : 1;
         }
-        const float inv_area = 1.0f / (float)area2;
+        const float inv_area = exact_rcp_unchecked((float)area2);
         const unsigned long long lo = (unsigned long long)(0xFFFFFFFFu - d.t);
         for (int by = cj0; by <= cj1; by += 4)
             for (int bx = ci0 & ~3; bx <= ci1; bx += 4) {
@@ -657,6 +681,66 @@ __global__ __launch_bounds__(256) void raster_coop4_kernel(View v, unsigned long
                     vis_max(vis, v, i, j, ((unsigned long long)__float_as_uint(q) << 32) | lo);
                 }
             }
+    }
+}
+
+// Parked CELLS (box of at most 8 x 8 pixel centres, at least 3 columns and 9 centres): one cell per wave,
+// lane = one pixel of the 8 x 8 window anchored at the box's first centre, so the whole cell is decided in
+// ONE step; the cell's data are wave-uniform (scalar registers, scalar set-up).  Both triangles are
+// decided per pixel from five shared edge functions -- the arithmetic of the FAST path of
+// raster_grid_kernel, evaluated directly at the pixel instead of stepped -- and a pixel sends ONE atomic
+// with the larger of its (at most two) keys: the row segments of both triangles of a cell travel in the
+// same 64-byte line-requests (the chip serves ~23 G atomic line-requests/s; 16-lane groups stepping
+// 8 x 2 blocks measured 130 M vector instructions for this stage, a wave per cell needs half).
+__global__ __launch_bounds__(256) void raster_cell_kernel(View v, unsigned long long *__restrict__ vis,
+                                                          const ParkedCell *__restrict__ queue,
+                                                          const unsigned *__restrict__ count, unsigned cap) {
+    const unsigned n = min(*count, cap);
+    const int lane = (int)(threadIdx.x & 63), lx = lane & 7, ly = lane >> 3;
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (unsigned it = wave; it < n; it += nwaves) {
+        const ParkedCell *e = queue + it;          // wave-uniform address: scalar loads
+        const int ax = e->X[0], bx_ = e->X[1], cx = e->X[2], dx_ = e->X[3];
+        const int ay = e->Y[0], by_ = e->Y[1], cy = e->Y[2], dy_ = e->Y[3];
+        const float iwa = e->iw[0], iwb = e->iw[1], iwc = e->iw[2], iwd = e->iw[3];
+        const unsigned cell = e->cell;
+        const int minx = min(min(ax, bx_), min(cx, dx_)), maxx = max(max(ax, bx_), max(cx, dx_));
+        const int miny = min(min(ay, by_), min(cy, dy_)), maxy = max(max(ay, by_), max(cy, dy_));
+        const int ci0 = max((minx + SUB / 2 - 1) >> 8, 0), ci1 = min((maxx - SUB / 2) >> 8, v.w - 1);
+        const int cj0 = max((miny + SUB / 2 - 1) >> 8, 0), cj1 = min((maxy - SUB / 2) >> 8, v.h - 1);
+        // directed edges: 0 b->c, 1 c->a, 2 a->b (triangle 0); 3 c->d, 4 d->a, 5 a->c (triangle 1)
+        const int ex0 = cx - bx_, ex1 = ax - cx, ex2 = bx_ - ax, ex3 = dx_ - cx, ex4 = ax - dx_, ex5 = -ex1;
+        const int ey0 = cy - by_, ey1 = ay - cy, ey2 = by_ - ay, ey3 = dy_ - cy, ey4 = ay - dy_, ey5 = -ey1;
+        // the edge owns its boundary iff dy < 0 or (dy == 0 and dx > 0) iff (dy << 12) - dx < 0 (|dx| < 2^12)
+        const int bs0 = 1 + (((ey0 << 12) - ex0) >> 31), bs1 = 1 + (((ey1 << 12) - ex1) >> 31), bs2 = 1 + (((ey2 << 12) - ex2) >> 31);
+        const int bs3 = 1 + (((ey3 << 12) - ex3) >> 31), bs4 = 1 + (((ey4 << 12) - ex4) >> 31), bs5 = 1 + (((ey5 << 12) - ex5) >> 31);
+        // doubled areas = sum of a triangle's three edge functions at any point (here: at b, resp. at c, where
+        // two of the three vanish); every product has factors below 2^12
+        const int area0 = ex1 * (by_ - cy) - ey1 * (bx_ - cx) + ex2 * (by_ - ay) - ey2 * (bx_ - ax);
+        const int area1 = ex4 * (cy - dy_) - ey4 * (cx - dx_);
+        const float inv0 = exact_rcp_unchecked((float)area0), inv1 = exact_rcp_unchecked((float)area1);   // used only where area > 0
+        const unsigned long long lo0 = 0xFFFFFFFFu - 2u * cell, lo1 = lo0 - 1u;
+        const int i = ci0 + lx, j = cj0 + ly;
+        if (i > ci1 || j > cj1) continue;
+        const int px = i * SUB + SUB / 2, py = j * SUB + SUB / 2;
+        const int r0 = mul24(ex0, py - by_) - mul24(ey0, px - bx_);       // unbiased edge values
+        const int r1 = mul24(ex1, py - cy) - mul24(ey1, px - cx);
+        const int r2 = mul24(ex2, py - ay) - mul24(ey2, px - ax);
+        const int r3 = mul24(ex3, py - cy) - mul24(ey3, px - cx);
+        const int r4 = mul24(ex4, py - dy_) - mul24(ey4, px - dx_);
+        const int r5 = -r1;
+        unsigned long long key = 0;
+        if (((r0 - bs0) | (r1 - bs1) | (r2 - bs2)) >= 0) {      // weights: edge k is opposite vertex k of (a, b, c)
+            const float q = __builtin_fmaf((float)r2, iwc, __builtin_fmaf((float)r1, iwb, (float)r0 * iwa)) * inv0;
+            key = ((unsigned long long)__float_as_uint(q) << 32) | lo0;
+        }
+        if (((r3 - bs3) | (r4 - bs4) | (r5 - bs5)) >= 0) {      // (a, c, d)
+            const float q = __builtin_fmaf((float)r5, iwd, __builtin_fmaf((float)r4, iwc, (float)r3 * iwa)) * inv1;
+            const unsigned long long k1 = ((unsigned long long)__float_as_uint(q) << 32) | lo1;
+            key = k1 > key ? k1 : key;
+        }
+        if (key) vis_max(vis, v, i, j, key);
     }
 }
 
@@ -858,7 +942,7 @@ static void make_tile_cull(const View &v, TileCull *c) {
     c->w = v.w; c->h = v.h;
     // cells that project to about a pixel or more: vz < focal length in pixels x cell size
     const double focal_px = std::fmax((double)v.fx * v.sx, (double)v.fy * v.sy);
-    double near_px = 1.0;
+    double near_px = 0.75;     // measured on the 100 M-vertex frame: 0.5 1.17 ms, 0.75 1.11, 1.0 1.20, 1.5 1.22, 2.5 1.36
     if (const char *e = getenv("ALP_NEAR_PX")) near_px = atof(e);      // development: where the first round ends
     c->near_limit = (float)(focal_px * near_px);
     c->enabled = 1;
@@ -1081,15 +1165,19 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
                         unsigned *__restrict__ gcount, unsigned gcap, int lanes_along_rows,
                         const unsigned *__restrict__ tile_list, const unsigned *__restrict__ tile_count,
                         Deferred *__restrict__ park_small, Deferred *__restrict__ park_large,
-                        unsigned *__restrict__ park_counts, unsigned park_cap_small, unsigned park_cap_large) {
+                        ParkedCell *__restrict__ park_cell, unsigned *__restrict__ park_counts, unsigned park_cap_small,
+                        unsigned park_cap_large, unsigned park_cap_cell) {
     // s_xy[].x of a vertex without window coordinates: behind the near plane / outside the
     // fixed-point range / masked out (nodata: its triangles do not exist, surface.py:203-205)
     constexpr int BEHIND = INT_MIN, RANGE = INT_MIN + 1, NODATA = INT_MIN + 2;
     __shared__ int2 s_xy[GT_NV];          // snapped window coordinates
     __shared__ float s_iw[GT_NV];
     __shared__ unsigned short s_q[GT_NC]; // FAST cell ids from the front, SLOW cell ids from the back
-    __shared__ unsigned short s_park[2 * GT_NC];   // parked triangles (2 * cell id + half): small boxes from the front, large from the back
-    __shared__ unsigned s_nfast, s_nslow, s_npark[2], s_park_base[2];
+    // parked work: cell ids [0, ncell), then triangles (2 * cell id + half) with small boxes upwards from
+    // ncell and with large boxes downwards from the end (a cell is parked whole or contributes at most two
+    // triangles, so 2 * GT_NC entries always suffice)
+    __shared__ unsigned short s_park[2 * GT_NC];
+    __shared__ unsigned s_nfast, s_nslow, s_npark[3], s_park_base[3];
     // ---- phase 0: this workgroup's tile (the frame plan dropped, deferred or culled the others)
     // Workgroups are handed to the 8 XCDs round-robin; each XCD has its own L2.  List position =
     // (XCD) * chunk + (turn): one XCD walks a CONTIGUOUS eighth of the list, i.e. neighbouring tiles,
@@ -1113,6 +1201,7 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
         s_nslow = 0;
         s_npark[0] = 0;
         s_npark[1] = 0;
+        s_npark[2] = 0;
     }
     // ---- phase 1: vertices.  Every load of the thread's (up to) GT_VPT vertices is issued before the
     // first one is used: ONE memory round trip per tile instead of one per vertex (the round trip is what
@@ -1189,6 +1278,12 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
                     // into the viewport has edge vectors far beyond the 24-bit products and the 2^12 tie
                     // key; i1 - i0 < 8 bounds its extent by 10 px = 2560 sub-pixel units
                     kind = (nx < FAST_MAX && ny < FAST_MAX && ((i1 - i0) | (j1 - j0)) < 8) ? 1 : 2;
+                    // a larger box of at most 8 x 8 centres (at least COOP_MIN_W columns and COOP_MIN_PIX
+                    // centres; unclamped extent under 14 px = 3584 sub-pixel units for the same reasons):
+                    // the whole cell goes to raster_cell_kernel
+                    if (kind == 2 && nx < 8 && ny < 8 && nx + 1 >= COOP_MIN_W && mul24(nx + 1, ny + 1) >= COOP_MIN_PIX &&
+                        i1 - i0 < 12 && j1 - j0 < 12)
+                        kind = 3;
                 }
             } else if (!(P0.x == BEHIND && P1.x == BEHIND && P2.x == BEHIND && P3.x == BEHIND)) {
                 kind = 2;                  // sentinels among the corners: sorted out per triangle
@@ -1207,10 +1302,18 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
             base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
             if (kind == 2) s_q[GT_NC - 1 - (base + __popcll(ms & ((1ull << lane) - 1ull)))] = (unsigned short)id;
         }
+        const unsigned long long mc = __ballot(kind == 3);
+        if (mc) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&s_npark[2], (unsigned)__popcll(mc));
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if (kind == 3) s_park[base + __popcll(mc & ((1ull << lane) - 1ull))] = (unsigned short)id;
+        }
     }
     __syncthreads();
     WGT(2);
     const int nfast = (int)s_nfast, nslow = (int)s_nslow;
+    const unsigned ncell = s_npark[2];
 #if defined(GRID_STOP_AFTER) && GRID_STOP_AFTER == 2
     if (nfast + nslow == 123456) vis[0] = s_q[threadIdx.x];
     return;
@@ -1264,7 +1367,7 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
             row[k] -= bs[k];
         }
         const float iwa = s_iw[ia], iwb = s_iw[ib], iwc = s_iw[ic], iwd = s_iw[idd];
-        const float inv0 = 1.0f / (float)area0, inv1 = 1.0f / (float)area1;      // used only where area > 0
+        const float inv0 = exact_rcp_unchecked((float)area0), inv1 = exact_rcp_unchecked((float)area1);      // used only where area > 0
         const unsigned long long lo0 = 0xFFFFFFFFu - 2u * cell, lo1 = lo0 - 1u;
         for (int j = cj0; j <= cj1; ++j) {
             int u[6];
@@ -1335,7 +1438,7 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
                 unsigned base = 0;
                 if (lane == 0) base = atomicAdd(&s_npark[0], (unsigned)__popcll(ms));
                 base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-                if (code == EMIT_PARKED_SMALL) s_park[base + __popcll(ms & ((1ull << lane) - 1ull))] = (unsigned short)(2 * id + half);
+                if (code == EMIT_PARKED_SMALL) s_park[ncell + base + __popcll(ms & ((1ull << lane) - 1ull))] = (unsigned short)(2 * id + half);
             }
             if (ml) {
                 unsigned base = 0;
@@ -1350,16 +1453,31 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
     // near tiles: 0.5 ms of same-address atomics), then every thread writes whole entries.
     __syncthreads();
     const unsigned np_small = s_npark[0], np_large = s_npark[1];
-    if (np_small + np_large == 0) return;
-    if (threadIdx.x < 2) {
-        const unsigned cnt = threadIdx.x ? np_large : np_small;
+    if (np_small + np_large + ncell == 0) return;
+    if (threadIdx.x < 3) {
+        const unsigned cnt = threadIdx.x == 0 ? np_small : (threadIdx.x == 1 ? np_large : ncell);
         s_park_base[threadIdx.x] = cnt ? atomicAdd(park_counts + threadIdx.x, cnt) : 0u;
     }
     __syncthreads();
+    for (unsigned e = threadIdx.x; e < ncell; e += 256) {
+        const int id = (int)s_park[e];
+        int lr, lc;
+        cell_rc(id, lr, lc);
+        const int ia = lr * GT_VW + lc, ib = ia + GT_VW, ic = ib + 1, idd = ia + 1;
+        const int2 A = s_xy[ia], B = s_xy[ib], C = s_xy[ic], D = s_xy[idd];
+        ParkedCell pc;
+        pc.X[0] = A.x; pc.X[1] = B.x; pc.X[2] = C.x; pc.X[3] = D.x;
+        pc.Y[0] = A.y; pc.Y[1] = B.y; pc.Y[2] = C.y; pc.Y[3] = D.y;
+        pc.iw[0] = s_iw[ia]; pc.iw[1] = s_iw[ib]; pc.iw[2] = s_iw[ic]; pc.iw[3] = s_iw[idd];
+        pc.cell = (unsigned)(r0 + lr) * (unsigned)(gw - 1) + (unsigned)(c0 + lc);
+        pc.pad[0] = pc.pad[1] = pc.pad[2] = 0;
+        const unsigned slot = s_park_base[2] + e;
+        if (slot < park_cap_cell) park_cell[slot] = pc;           // an overflow is noticed by finish_frame
+    }
     for (unsigned e = threadIdx.x; e < np_small + np_large; e += 256) {
         const bool large = e >= np_small;
         const unsigned k = large ? e - np_small : e;
-        const unsigned code = large ? s_park[2 * GT_NC - 1 - k] : s_park[k];
+        const unsigned code = large ? s_park[2 * GT_NC - 1 - k] : s_park[ncell + k];
         const int id = (int)(code >> 1), half = (int)(code & 1u);
         int lr, lc;
         cell_rc(id, lr, lc);
@@ -1691,15 +1809,19 @@ unsigned initial_queue_cap() {
     return 1u << 20;
 }
 
-int ensure_park(alp_mesh *m, unsigned cap_small, unsigned cap_large) {
-    if (m->park_small && m->park_cap[0] >= cap_small && m->park_cap[1] >= cap_large) return ALP_OK;
+int ensure_park(alp_mesh *m, unsigned cap_small, unsigned cap_large, unsigned cap_cell) {
+    if (m->park_small && m->park_cap[0] >= cap_small && m->park_cap[1] >= cap_large && m->park_cap[2] >= cap_cell) return ALP_OK;
     if (m->park_small) hipFree(m->park_small);
+    if (m->park_cell) hipFree(m->park_cell);
     m->park_small = nullptr;
     m->park_large = nullptr;
+    m->park_cell = nullptr;
     ALP_HIP(hipMalloc((void **)&m->park_small, ((size_t)cap_small + cap_large) * sizeof(Deferred)));
+    ALP_HIP(hipMalloc((void **)&m->park_cell, (size_t)cap_cell * sizeof(ParkedCell)));
     m->park_large = (Deferred *)m->park_small + cap_small;
     m->park_cap[0] = cap_small;
     m->park_cap[1] = cap_large;
+    m->park_cap[2] = cap_cell;
     return ALP_OK;
 }
 
@@ -1742,10 +1864,10 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
     ALP_HIP(hipMemsetAsync(m->vis, 0, (size_t)v.w * v.h * sizeof(unsigned long long), st));
     if (m->n_tri > 0) {
         // queue counters, four per round: [0] work items, [1] general entries, [2] small parked, [3] large parked
-        ALP_HIP(hipMemsetAsync(m->qcount_dev, 0, 8 * sizeof(unsigned), st));
+        ALP_HIP(hipMemsetAsync(m->qcount_dev, 0, QC_TOTAL * sizeof(unsigned), st));
         // the consumers of the rare cases (near-plane crossings, 64 px and more) of one round
         auto drain_round = [&](int round) -> int {
-            unsigned *items = m->qcount_dev + 4 * round, *general = items + 1;
+            unsigned *items = m->qcount_dev + QC_STRIDE * round, *general = items + 1;
             hipLaunchKernelGGL((raster_general_kernel<IMPLICIT>), dim3(cu * 2), dim3(256), 0, st, m->vert, m->ind,
                                (long long)m->grid_w, v, m->vis, m->gqueue, general, m->gcap, m->queue, items, m->qcap);
             ALP_HIP(hipGetLastError());
@@ -1759,29 +1881,31 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
                 hipLaunchKernelGGL(raster_coop_kernel, dim3(cu * 8), dim3(256), 0, st, v, m->vis, m->park_large, items + 3,
                                    m->park_cap[1]);
                 ALP_HIP(hipGetLastError());
+                hipLaunchKernelGGL(raster_cell_kernel, dim3(cu * 8), dim3(256), 0, st, v, m->vis, m->park_cell, items + 4,
+                                   m->park_cap[2]);
+                ALP_HIP(hipGetLastError());
             }
             return ALP_OK;
         };
         if constexpr (IMPLICIT) {
             if (!m->park_small) {
-                // ~1.2 M small and ~0.2 M large parked triangles per 5616 x 3744 frame of the 100 M-vertex DSM
+                // ~0.7 M parked cells and a few 100 k parked triangles per 5616 x 3744 frame of the 100 M-vertex DSM
                 const unsigned cap = initial_queue_cap();
                 const bool dflt = cap == (1u << 20);
-                if (int e = ensure_park(m, dflt ? 4u << 20 : cap, cap)) return e;
+                if (int e = ensure_park(m, cap, cap, dflt ? 2u << 20 : cap)) return e;
             }
             const int tiles_x = (int)((m->grid_w - 1 + GT_W - 1) / GT_W);
             const long long tiles = (long long)tiles_x * ((m->grid_h - 1 + GT_H - 1) / GT_H);
             if (!m->tile_bounds) {      // once per mesh: the vertices never change
                 ALP_HIP(hipMalloc((void **)&m->tile_bounds, (size_t)tiles * 6 * sizeof(float)));
                 // three tile lists (near, far, far survivors) + their three counters
-                ALP_HIP(hipMalloc((void **)&m->tile_lists, (size_t)(3 * tiles + 4) * sizeof(unsigned)));
+                ALP_HIP(hipMalloc((void **)&m->tile_lists, (size_t)(3 * tiles) * sizeof(unsigned)));
                 hipLaunchKernelGGL(tile_bounds_kernel, dim3((unsigned)tiles), dim3(256), 0, st, m->vert, (int)m->grid_h,
                                    (int)m->grid_w, tiles_x, m->tile_bounds);
                 ALP_HIP(hipGetLastError());
             }
             unsigned *near_list = m->tile_lists, *far_list = near_list + tiles, *second_list = far_list + tiles,
-                     *counts = second_list + tiles;      // [0] near, [1] far, [2] far survivors
-            ALP_HIP(hipMemsetAsync(counts, 0, 4 * sizeof(unsigned), st));
+                     *counts = m->qcount_dev + 2 * QC_STRIDE;   // [0] near, [1] far, [2] far survivors (cleared with the queue counters)
             TileCull cull;
             make_tile_cull(v, &cull);
             if (getenv("ALP_NO_TILE_CULL")) cull.enabled = 0;     // development: measure / cross-check the exact path alone
@@ -1798,8 +1922,8 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
             // ones beyond the list's length leave at once.
             hipLaunchKernelGGL(raster_grid_kernel, dim3(grid_wgs), dim3(256), 0, st, m->vert, m->valid,
                                (int)m->grid_h, (int)m->grid_w, v, m->vis, m->gqueue, m->qcount_dev + 1, m->gcap,
-                               along_rows, near_list, counts + 0, m->park_small, m->park_large, m->qcount_dev + 2,
-                               m->park_cap[0], m->park_cap[1]);
+                               along_rows, near_list, counts + 0, m->park_small, m->park_large, m->park_cell,
+                               m->qcount_dev + 2, m->park_cap[0], m->park_cap[1], m->park_cap[2]);
             ALP_HIP(hipGetLastError());
 #ifdef ALP_WG_TIMING
             {   // duration of every workgroup of the first round
@@ -1848,9 +1972,9 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
                                    counts, dm, m->hiz, second_list, counts + 2);
                 ALP_HIP(hipGetLastError());
                 hipLaunchKernelGGL(raster_grid_kernel, dim3(grid_wgs), dim3(256), 0, st, m->vert, m->valid,
-                                   (int)m->grid_h, (int)m->grid_w, v, m->vis, m->gqueue, m->qcount_dev + 5, m->gcap,
-                                   along_rows, second_list, counts + 2, m->park_small, m->park_large, m->qcount_dev + 6,
-                                   m->park_cap[0], m->park_cap[1]);
+                                   (int)m->grid_h, (int)m->grid_w, v, m->vis, m->gqueue, m->qcount_dev + QC_STRIDE + 1, m->gcap,
+                                   along_rows, second_list, counts + 2, m->park_small, m->park_large, m->park_cell,
+                                   m->qcount_dev + QC_STRIDE + 2, m->park_cap[0], m->park_cap[1], m->park_cap[2]);
                 ALP_HIP(hipGetLastError());
                 if (int e = drain_round(1)) return e;
             }
@@ -1875,7 +1999,7 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
             ALP_HIP(hipGetLastError());
             if (int e = drain_round(0)) return e;
         }
-        ALP_HIP(hipMemcpyAsync(m->qcount_host, m->qcount_dev, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        ALP_HIP(hipMemcpyAsync(m->qcount_host, m->qcount_dev, 2 * QC_STRIDE * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     }
     const long long npix = (long long)v.w * v.h;
     const long long want = (npix + 255) / 256;
@@ -1917,15 +2041,16 @@ int finish_frame(alp_mesh *m) {
     while (m->unchecked) {
         ALP_HIP(hipStreamSynchronize(ctx().stream));
         m->unchecked = false;
-        const unsigned items = std::max(m->qcount_host[0], m->qcount_host[4]),
-                       general = std::max(m->qcount_host[1], m->qcount_host[5]),
-                       psmall = std::max(m->qcount_host[2], m->qcount_host[6]),
-                       plarge = std::max(m->qcount_host[3], m->qcount_host[7]);
-        const bool park_ok = !m->park_small || (psmall <= m->park_cap[0] && plarge <= m->park_cap[1]);
+        const unsigned *h = m->qcount_host;
+        const unsigned items = std::max(h[0], h[QC_STRIDE]), general = std::max(h[1], h[QC_STRIDE + 1]),
+                       psmall = std::max(h[2], h[QC_STRIDE + 2]), plarge = std::max(h[3], h[QC_STRIDE + 3]),
+                       pcell = std::max(h[4], h[QC_STRIDE + 4]);
+        const bool park_ok = !m->park_small || (psmall <= m->park_cap[0] && plarge <= m->park_cap[1] && pcell <= m->park_cap[2]);
         if (items <= m->qcap && general <= m->gcap && park_ok) break;
         if (!park_ok)
             if (int e = ensure_park(m, std::max(m->park_cap[0], psmall + psmall / 4 + 1024),
-                                    std::max(m->park_cap[1], plarge + plarge / 4 + 1024)))
+                                    std::max(m->park_cap[1], plarge + plarge / 4 + 1024),
+                                    std::max(m->park_cap[2], pcell + pcell / 4 + 1024)))
                 return e;
         if (items > m->qcap)
             if (int e = ensure_queue(m, items + items / 4 + 1024)) return e;
@@ -2002,8 +2127,8 @@ int alp_mesh_create(const float *vert, const float *value, int64_t n_vert, const
             if (rc) return bail(rc);
         }
     }
-    if (hipMalloc((void **)&m->qcount_dev, 8 * sizeof(unsigned)) != hipSuccess ||
-        hipHostMalloc((void **)&m->qcount_host, 8 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess)
+    if (hipMalloc((void **)&m->qcount_dev, QC_TOTAL * sizeof(unsigned)) != hipSuccess ||
+        hipHostMalloc((void **)&m->qcount_host, QC_TOTAL * sizeof(unsigned), hipHostMallocDefault) != hipSuccess)
         return bail(fail(ALP_EHIP, "hipMalloc queue counter"));
     if ((rc = ensure_queue(m, initial_queue_cap()))) return bail(rc);
     if ((rc = ensure_gqueue(m, initial_queue_cap()))) return bail(rc);
@@ -2045,7 +2170,7 @@ int alp_mesh_destroy(alp_mesh_t *m) {
     if (ctx().ready) hipStreamSynchronize(ctx().stream);
     for (void *p : {(void *)m->vert, (void *)m->value, (void *)m->ind, (void *)m->valid, (void *)m->vis, (void *)m->image,
                     (void *)m->queue, (void *)m->gqueue, (void *)m->qcount_dev, (void *)m->compact_counts, (void *)m->compact_offsets,
-                    (void *)m->tile_bounds, (void *)m->tile_lists, (void *)m->hiz, (void *)m->park_small})
+                    (void *)m->tile_bounds, (void *)m->tile_lists, (void *)m->hiz, (void *)m->park_small, (void *)m->park_cell})
         if (p) hipFree(p);
     if (m->qcount_host) hipHostFree(m->qcount_host);
     delete m;

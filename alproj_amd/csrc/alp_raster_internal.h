@@ -30,6 +30,15 @@ struct Deferred {
     unsigned t;
 };
 
+// A whole grid cell parked by raster_grid_kernel for raster_cell_kernel: the snapped corners a, b, c, d
+// (vertex ids a, a + gw, a + gw + 1, a + 1: triangles (a, b, c) and (a, c, d), surface.py:194-201).
+struct alignas(16) ParkedCell {
+    int X[4], Y[4];
+    float iw[4];
+    unsigned cell;
+    unsigned pad[3];
+};
+
 }  // namespace alp
 
 struct alp_mesh {
@@ -51,9 +60,12 @@ struct alp_mesh {
     unsigned *gqueue = nullptr;        // general queue: triangle ids set aside by raster_grid_kernel
     unsigned gcap = 0;
     alp::Deferred *park_small = nullptr, *park_large = nullptr;   // implicit grid: parked triangles (one allocation)
-    unsigned park_cap[2] = {0, 0};
-    unsigned *qcount_dev = nullptr;    // per round (2 rounds) [0] work items, [1] general entries, [2] small parked, [3] large parked
-    unsigned *qcount_host = nullptr;   // pinned copy of the eight counters of the last frame
+    alp::ParkedCell *park_cell = nullptr;                         // implicit grid: parked cells
+    unsigned park_cap[3] = {0, 0, 0};                             // small, large, cells
+    // per round (2 rounds x QC_STRIDE) [0] work items, [1] general entries, [2] small parked, [3] large parked,
+    // [4] parked cells; then the three tile-list lengths of the frame plan
+    unsigned *qcount_dev = nullptr;
+    unsigned *qcount_host = nullptr;   // pinned copy of the queue counters of the last frame
     bool unchecked = false;            // last frame enqueued, its queue counters not yet checked (finish_frame)
     alp::View last_v;
     alp::RemapCoef last_rc;
@@ -71,6 +83,8 @@ namespace alp {
 int upload_chunked(void *dst, const void *src, size_t bytes);
 int ensure_queue(alp_mesh *m, unsigned cap);
 int ensure_gqueue(alp_mesh *m, unsigned cap);
-int ensure_park(alp_mesh *m, unsigned cap_small, unsigned cap_large);
+int ensure_park(alp_mesh *m, unsigned cap_small, unsigned cap_large, unsigned cap_cell);
+constexpr int QC_STRIDE = 8;           // counters per round
+constexpr int QC_TOTAL = 2 * QC_STRIDE + 4;
 unsigned initial_queue_cap();
 }  // namespace alp
