@@ -64,6 +64,7 @@ _SIGNATURES = {
     "alp_eval_population": [_c_void_p, _c_dp, _c_i64, _c_int, _c_double, _c_dp, ctypes.POINTER(_c_i64)],
     "alp_eval_population_enqueue": [_c_void_p, _c_dp, _c_i64, _c_int, _c_double],
     "alp_eval_population_wait": [_c_void_p, _c_dp, ctypes.POINTER(_c_i64)],
+    "alp_eval_population_timing": [_c_void_p, _c_fp, _c_fp],
     "alp_loss_uv": [_c_dp, _c_dp, _c_i64, _c_int, _c_double, _c_dp],
     "alp_mesh_create": [_c_fp, _c_fp, _c_i64, _c_void_p, _c_int, _c_i64, _c_i64, _c_i64,
                         ctypes.POINTER(_c_void_p)],
@@ -260,6 +261,12 @@ class Points:
         check(self._lib.alp_eval_population_enqueue(self._h, as_dp(cand), cand.shape[0],
                                                     int(loss_kind), float(f_scale)))
         return cand.shape[0]
+
+    def eval_population_timing(self):
+        """(kernel_ms, allreduce_ms) of the last completed population evaluation (HIP events)."""
+        k, a = ctypes.c_float(), ctypes.c_float()
+        check(self._lib.alp_eval_population_timing(self._h, ctypes.byref(k), ctypes.byref(a)))
+        return float(k.value), float(a.value)
 
     def eval_population_wait(self, P):
         losses = np.empty(P, dtype=np.float64)

@@ -48,6 +48,8 @@ struct alp_points {
     double pending_f_scale = 0;
     std::vector<double> cand_copy;   // the P x 25 parameter vectors of the pending call (argmin confirmation)
     // argmin confirmation (float32 sets): float64 records, partial sums and sums of up to CONFIRM_MAX candidates
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // last population evaluation: before the kernels, after them, after the all-reduce
+    bool timed = false;
     void *conf_dev = nullptr;
     int conf_nblk = 0;
     double *conf_host = nullptr;   // pinned, CONFIRM_MAX + 1
@@ -195,6 +197,9 @@ int enqueue_popeval(alp_points *p, const double *cand, int64_t P, int loss_kind,
     const int64_t rows = (p->n + 255) / 256;
     if (rows < nblk) nblk = (int)(rows > 0 ? rows : 1);
     if (int rc = ensure_pop_scratch(p, P, nblk)) return rc;
+    if (!p->ev[0])
+        for (auto &e : p->ev) ALP_HIP(hipEventCreate(&e));
+    ALP_HIP(hipEventRecord(p->ev[0], ctx().stream));
     hipLaunchKernelGGL(kernels[which], dim3(nblk), dim3(256), 0, ctx().stream, (const T *)p->x, (const T *)p->y,
                        (const T *)p->z, (const T *)p->uo, (const T *)p->vo, p->n, (const PoseRec<T> *)p->cand_dev,
                        (int)P, (T)f_scale, p->partials);
@@ -202,7 +207,10 @@ int enqueue_popeval(alp_points *p, const double *cand, int64_t P, int loss_kind,
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((P + 31) / 32)), dim3(256), 0, ctx().stream,
                        p->partials, nblk, (int)P, (double)p->n, p->sums_dev);
     ALP_HIP(hipGetLastError());
+    ALP_HIP(hipEventRecord(p->ev[1], ctx().stream));
     if (int rc = comm_allreduce_sum_f64(p->sums_dev, P + 1)) return rc;
+    ALP_HIP(hipEventRecord(p->ev[2], ctx().stream));
+    p->timed = true;
     ALP_HIP(hipMemcpyAsync(p->sums_host, p->sums_dev, (size_t)(P + 1) * sizeof(double),
                            hipMemcpyDeviceToHost, ctx().stream));
     p->pending_P = P;
@@ -330,6 +338,8 @@ int alp_points_destroy(alp_points_t *p) {
     if (p->sums_host) hipHostFree(p->sums_host);
     if (p->conf_dev) hipFree(p->conf_dev);
     if (p->conf_host) hipHostFree(p->conf_host);
+    for (auto &e : p->ev)
+        if (e) hipEventDestroy(e);
     delete p;
     return ALP_OK;
 }
@@ -554,6 +564,19 @@ int alp_eval_population_wait(alp_points_t *p, double *loss_out, int64_t *argmin_
         }
     }
     if (argmin_out) *argmin_out = best < 0 ? 0 : best;
+    return ALP_OK;
+}
+
+int alp_eval_population_timing(alp_points_t *p, float *kernel_ms, float *allreduce_ms) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(p, "points handle is NULL");
+    if (!p->timed) return fail(ALP_ESTATE, "alp_eval_population_timing: no population evaluation yet");
+    if (p->pending_P > 0) return fail(ALP_ESTATE, "alp_eval_population_timing: wait for the pending evaluation first");
+    float a = 0, b = 0;
+    ALP_HIP(hipEventElapsedTime(&a, p->ev[0], p->ev[1]));
+    ALP_HIP(hipEventElapsedTime(&b, p->ev[1], p->ev[2]));
+    if (kernel_ms) *kernel_ms = a;
+    if (allreduce_ms) *allreduce_ms = b;
     return ALP_OK;
 }
 

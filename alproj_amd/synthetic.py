@@ -29,25 +29,37 @@ def _elevation(X, Y):
     return 300.0 * np.sin(X / 700.0) * np.cos(Y / 500.0) + 40.0 * np.sin(X / 37.0) * np.sin(Y / 53.0)
 
 
-def dsm_rows(n_side, row0, row1, res=1.0, seed=SEED, noise=None):
-    """Vertices of grid rows [row0, row1): float32 (count, 3) in X, Z, Y order relative to
-    the surface minimum being (0, zmin, 0) -- i.e. X = col*res, Y = (n-1-row)*res, Z raw.
+def row_noise(n_side, row, seed=SEED, out=None):
+    """The N(0, 0.5^2) elevation noise of ONE grid row (float32, n_side values): a counter-based
+    Philox stream keyed by (seed, row), so that any rank generates exactly its own rows -- the same
+    values whatever the sharding -- without drawing the other ranks' share of the field."""
+    bits = np.random.Philox(key=[seed, 0], counter=[0, int(row), 0, 0])
+    out = np.random.Generator(bits).standard_normal(n_side, dtype=np.float32, out=out)
+    out *= np.float32(0.5)
+    return out
 
-    ``noise`` (full-grid N(0, 0.5^2) field, flat) may be passed to avoid regenerating it.
-    """
-    if noise is None:
-        noise = np.random.default_rng(seed).normal(0.0, 0.5, n_side * n_side).astype(np.float32)
+
+def dsm_rows(n_side, row0, row1, res=1.0, seed=SEED):
+    """Vertices of grid rows [row0, row1): float32 (count, 3) in X, Z, Y order relative to
+    the surface minimum being (0, zmin, 0) -- i.e. X = col*res, Y = (n-1-row)*res, Z raw."""
     cols = np.arange(n_side, dtype=np.float64) * res
+    cols32 = cols.astype(np.float32)
     out = np.empty(((row1 - row0) * n_side, 3), dtype=np.float32)
     step = max(1, (1 << 22) // n_side)
+    noise = np.empty((step, n_side), dtype=np.float32)
     for r in range(row0, row1, step):
         r2 = min(row1, r + step)
         Y = ((n_side - 1 - np.arange(r, r2, dtype=np.float64)) * res)[:, None]
-        Z = _elevation(cols[None, :], Y) + noise[r * n_side:r2 * n_side].reshape(r2 - r, n_side)
-        sl = slice((r - row0) * n_side, (r2 - row0) * n_side)
-        out[sl, 0] = np.broadcast_to(cols[None, :], Z.shape).ravel()
-        out[sl, 1] = Z.ravel()
-        out[sl, 2] = np.broadcast_to(Y, Z.shape).ravel()
+        for k, rr in enumerate(range(r, r2)):
+            row_noise(n_side, rr, seed, out=noise[k])
+        # _elevation(cols, Y), separably: the same floating-point operations in the same order, with the
+        # sines / cosines evaluated once per column and row instead of once per vertex
+        Z = (300.0 * np.sin(cols / 700.0))[None, :] * np.cos(Y / 500.0) + (40.0 * np.sin(cols / 37.0))[None, :] * np.sin(Y / 53.0)
+        Z += noise[:r2 - r]
+        blk = out[(r - row0) * n_side:(r2 - row0) * n_side].reshape(r2 - r, n_side, 3)
+        blk[:, :, 0] = cols32[None, :]
+        blk[:, :, 1] = Z
+        blk[:, :, 2] = Y
     return out
 
 
@@ -68,10 +80,19 @@ def surface(n_side, res=1.0, seed=SEED, rows=None):
 
 
 def grid_indices(n_side, dtype=np.int64):
-    """Triangle index array of the full regular grid (surface.py:194-201 on a square grid)."""
-    a = (np.arange(n_side - 1)[None, :] + np.arange(n_side - 1)[:, None] * n_side).ravel()
-    ind = np.stack([a, a + n_side, a + n_side + 1, a, a + n_side + 1, a + 1], axis=1)
-    return ind.reshape(-1, 3).astype(dtype)
+    """Triangle index array of the full regular grid (surface.py:194-201 on a square grid), built in
+    `dtype` band by band (the int64 form of a 10000 x 10000 grid is 4.8 GB)."""
+    m = n_side - 1
+    out = np.empty((2 * m * m, 3), dtype=dtype)
+    view = out.reshape(m, m, 6)
+    cols = np.arange(m, dtype=dtype)
+    band = max(1, (1 << 22) // max(m, 1))
+    offs = np.array([0, n_side, n_side + 1, 0, n_side + 1, 1], dtype=dtype)
+    for r in range(0, m, band):
+        r2 = min(m, r + band)
+        a = cols[None, :] + (np.arange(r, r2, dtype=dtype) * dtype(n_side))[:, None]
+        view[r:r2] = a[:, :, None] + offs[None, None, :]
+    return out
 
 
 def colors(n_vertices, seed=SEED):

@@ -11,10 +11,15 @@ float32 planes, row-sharded over the ranks (strong scaling: the total is fixed).
 
   leg 1 (the timed "steps" -> `value`): one step = one single-pose forward projection of the
         whole DSM (every rank projects its shard, no collective).  Gpoints/s = vertices / t.
-  leg 2 (`cma`): CMA-ES generations = ask -> population evaluation on the GPU(s) with ONE RCCL
-        all-reduce of the P+1 partial sums -> tell; pop = 2048, D = 21 (BASELINE config 5).
-  leg 3 (`raster`, 1 GPU only -- the render does not shard: "replicas only"): depth-buffered
-        render of the same DSM as a triangle mesh onto the 5616x3744 frame (BASELINE config 4).
+  `cma`: CMA-ES generations = ask -> population evaluation on the GPU(s) with ONE RCCL all-reduce of
+        the P+1 partial sums -> tell; pop = 2048, D = 21 (BASELINE config 5); kernel / all-reduce
+        split from HIP events inside the library.
+  `f64` (1 GPU): the same projection and population evaluation in the float64 parity mode.
+  `c2_c3_10m` (1 GPU): BASELINE configs 2 and 3: 10 M vertices, single-pose projection and CMA-ES
+        pop 256 / D 9 (Huber f = 10 and mean distance).
+  `raster` (1 GPU only -- the render does not shard: "replicas only"): depth-buffered render of the
+        100 M-vertex DSM as a triangle mesh onto the 5616x3744 frame (BASELINE config 4): implicit
+        grid, int32 index array, distorted pose, and upload-inclusive.
   `cpu_baseline` (rank 0, N=1 only): the numpy float64 restatement of the reference
         (oracle/ref_numpy.py) timed on this host on a bounded sample.
 
@@ -33,8 +38,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 measured copy)
 VALU_PEAK = 157.3e12       # flop/s fp32 vector (MI355X_MICROARCH.md)
+VALU_PEAK_F64 = 78.6e12    # flop/s fp64 vector (MI355X_MICROARCH.md)
 BYTES_PER_VERTEX = {"f32": 20, "f64": 40}     # 3 coordinates in + 2 pixel coordinates out
 EVAL_FLOPS = 77            # flop per point-candidate evaluation (Huber): 30 fma + 13 + 4 transcendental, DESIGN.md section 4 (K2)
+PROFILES = os.path.join(ROOT, "profiles")
 
 
 def parse():
@@ -49,7 +56,9 @@ def parse():
     ap.add_argument("--cma-steps", type=int, default=None, help="generations timed (default min(steps, 10))")
     ap.add_argument("--no-cma", action="store_true")
     ap.add_argument("--no-raster", action="store_true")
-    ap.add_argument("--raster-explicit", action="store_true", help="also time the int32 index-array mesh")
+    ap.add_argument("--no-raster-explicit", action="store_true", help="skip the int32 index-array mesh (2.4 GB of indices)")
+    ap.add_argument("--no-f64", action="store_true")
+    ap.add_argument("--no-10m", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -138,6 +147,60 @@ def cpu_baseline(orc, truth, xyz_sample, obs_sample):
     return best_p, best_l
 
 
+def parity_report(got, ref, w):
+    """float32 (or float64) projection against the float64 oracle: the bound the mode is held to
+    (1e-5 of max(|ref|, image width): float32 COORDINATES at distance D are uncertain by D * 2^-24, which
+    moves a pixel by up to fx * 2^-24 ~ 2e-4 px whatever the arithmetic), plus what the strict
+    north-star reading (1e-5 of |ref|) gives."""
+    d = np.abs(got - ref)
+    fin = np.isfinite(ref) & np.isfinite(got)
+    return {"checked_values": int(fin.sum()),
+            "max_err_rel_to_max(|ref|,w)_vs_f64_oracle": float((d[fin] / np.maximum(np.abs(ref[fin]), w)).max()),
+            "tolerance": 1e-5,
+            "max_abs_err_px": float(d[fin].max()),
+            "strict_1e-5_relative_pass_fraction": float((d[fin] <= 1e-5 * np.abs(ref[fin])).mean())}
+
+
+def pmc_traffic(name):
+    """HBM bytes per launch measured with rocprofv3 --pmc in separate passes (FETCH_SIZE x2 on gfx950 +
+    WRITE_SIZE, as MI355X_MICROARCH.md prescribes); the newest committed round wins."""
+    for rnd in ("r02", "r01"):
+        f = os.path.join(PROFILES, f"{rnd}_{name}_pmc_traffic.json")
+        if os.path.exists(f):
+            return json.load(open(f)), os.path.relpath(f, ROOT)
+    return None, None
+
+
+def cma_loop(L, CMA, pts, base, targets, bounds_fn, pop, loss_kind, f_scale, seed=1234):
+    """One CMA-ES optimiser over the resident point set: returns (generation closure, state dict)."""
+    bounds = bounds_fn(base, targets)
+    lower, upper = bounds[:, 0], bounds[:, 1]
+    cols = [L.PARAM_KEYS.index(t) for t in targets]
+    basev = L.params_vector(base)
+    opt = CMA(mean=np.full(len(targets), 0.5), sigma=1.0,
+              bounds=np.column_stack([np.zeros(len(targets)), np.ones(len(targets))]),
+              population_size=pop, n_max_resampling=100, seed=seed)
+    state = {"t_ask": 0.0, "t_eval": 0.0, "t_tell": 0.0}
+
+    def generation():
+        t0 = time.perf_counter()
+        X = opt.ask_population()
+        cand = np.tile(basev, (pop, 1))
+        cand[:, cols] = X * (upper - lower) + lower
+        t1 = time.perf_counter()
+        losses, amin = pts.eval_population(cand, loss_kind, f_scale)
+        t2 = time.perf_counter()
+        opt.tell_population(X, losses)
+        t3 = time.perf_counter()
+        state["best"] = float(losses[amin])
+        state["t_ask"] += t1 - t0
+        state["t_eval"] += t2 - t1
+        state["t_tell"] += t3 - t2
+        state["n"] = state.get("n", 0) + 1
+
+    return generation, state
+
+
 def main():
     args = parse()
     ctl = Control()
@@ -158,16 +221,18 @@ def main():
     from alproj_amd import dist as adist
     from alproj_amd import synthetic as syn
     from alproj_amd.cma import CMA
+    from alproj_amd.optimize import bounds_to_array      # the product's own host logic
     from oracle import ref_numpy as orc       # checker (parity spot check) and cpu_baseline only
 
     adist.init_comm(ctl.rank, ctl.world, ctl.bcast_bytes, ctl.local_rank)
     info = L.device_info()
+    comm_rank, comm_world = L.comm_info()
 
     # ---------------------------------------------------------------- workload
     n_side = syn.grid_side(args.vertices)
     r0, r1 = adist.shard_rows(n_side, ctl.rank, ctl.world)
     t_gen = time.perf_counter()
-    surf = syn.surface(n_side, rows=(r0, r1))
+    surf = syn.surface(n_side, rows=(r0, r1))       # every rank generates its own rows only
     xyz_l = syn.vert_to_xyz_local(surf["vert"])
     n_local = xyz_l.shape[0]
     n_total = n_side * n_side
@@ -193,20 +258,18 @@ def main():
     t_fetch = time.perf_counter() - t_fetch
     del uu_all, vv_all
     # parity spot check on the bench workload itself (outside the timed region)
-    step = max(1, n_local // 4000)
+    step = max(1, n_local // 40000)
     cnt = (n_local - 1) // step
     u, v = pts.fetch_strided(0, step, cnt)
     sample = xyz_l[0:cnt * step:step].astype(np.float64)
     ref = orc.project_points(sample, truth)
-    rel = np.abs(np.stack([u, v], 1) - ref) / np.maximum(np.abs(ref), truth["w"])
-    parity_max_rel = float(rel.max())
+    parity = parity_report(np.stack([u, v], 1), ref, truth["w"])
 
-    # HBM traffic of the kernel: PMC passes (FETCH_SIZE / WRITE_SIZE, gfx950-corrected) cannot run
-    # inside this process; the committed rocprofv3 measurement gives bytes per vertex
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_project_pmc_traffic.json")
-    if args.precision == "f32" and os.path.exists(tfile):
-        traffic = json.load(open(tfile))["hbm_bytes_per_vertex"] * n_local
+    traffic, traffic_src = (None, None)
+    if args.precision == "f32":
+        t_json, traffic_src = pmc_traffic("project")
+        if t_json:
+            traffic = t_json["hbm_bytes_per_vertex"] * n_local
 
     out = {
         "metric": "Gpoints/s projected (pinhole + Brown-Conrady, single pose) over the 100M-vertex DSM; "
@@ -220,21 +283,22 @@ def main():
                    "precision": args.precision},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "traffic": traffic,
-                     "traffic_source": "profiles/r01_project_pmc_traffic.json (rocprofv3 --pmc, bytes/vertex x "
-                                       "vertices per launch)" if traffic else None,
+                     "traffic_source": f"{traffic_src} (rocprofv3 --pmc, bytes/vertex x vertices per launch)" if traffic else None,
                      "kernel": "project_kernel", "kernel_ms": kern_s * 1e3,
                      "bytes_per_vertex": bpv, "vertices_per_launch": n_local},
-        "parity": {"checked_vertices": int(cnt), "max_err_rel_to_max(|ref|,w)_vs_f64_oracle": parity_max_rel,
-                   "tolerance": 1e-5},
+        "parity": parity,
         "device": info, "setup_s": t_gen,
+        # the communicator the library itself reports (ncclCommInitRank succeeded on every rank)
+        "rccl": {"rank": comm_rank, "nranks": comm_world},
         # SURVEY 8(d) c2 asks for the end-to-end figure beside the kernel figure; it is never `value`
         "pcie_inclusive": {"upload_s": t_up, "fetch_uv_s": t_fetch,
                            "gpoints_per_s_one_pass_incl_upload_and_fetch":
                                n_local / (t_up + ms_per_step / 1e3 + t_fetch) / 1e9},
     }
 
-    # ---------------------------------------------------------------- leg 2: CMA-ES generations
+    # ---------------------------------------------------------------- CMA-ES generations (config 5)
     obs = None
+    targets = syn.TARGETS_D9 if args.dims == 9 else syn.TARGETS_D21
     if not args.no_cma:
         uu, vv = pts.fetch(np.float32)
         rng = np.random.default_rng(1 + ctl.rank)
@@ -243,43 +307,22 @@ def main():
         obs += rng.normal(0.0, 1.0, obs.shape).astype(np.float32)
         obs[~np.isfinite(obs)] = 0.0
         pts.set_observed(obs)
-        targets = syn.TARGETS_D9 if args.dims == 9 else syn.TARGETS_D21
-        from alproj_amd.optimize import bounds_to_array      # the product's own host logic
-        bounds = bounds_to_array(base, targets)
-        lower, upper = bounds[:, 0], bounds[:, 1]
-        cols = [L.PARAM_KEYS.index(t) for t in targets]
-        basev = L.params_vector(base)
-        opt = CMA(mean=np.full(len(targets), 0.5), sigma=1.0,
-                  bounds=np.column_stack([np.zeros(len(targets)), np.ones(len(targets))]),
-                  population_size=args.pop, n_max_resampling=100, seed=1234)
-        state = {}
-
-        def generation():
-            X = opt.ask_population()
-            cand = np.tile(basev, (args.pop, 1))
-            cand[:, cols] = X * (upper - lower) + lower
-            losses, amin = pts.eval_population(cand, L.LOSS_HUBER, 10.0)
-            opt.tell_population(X, losses)
-            state["best"] = float(losses[amin])
-
+        generation, state = cma_loop(L, CMA, pts, base, targets, bounds_to_array, args.pop, L.LOSS_HUBER, 10.0)
         k_cma = args.cma_steps or min(args.steps, 10)
         wall_c, _ = timed(ctl, L, generation, k_cma, min(args.warmup, 2))
-        # device time of one population evaluation (HIP events around the enqueue)
-        cand = np.tile(basev, (args.pop, 1))
-        cand[:, cols] = opt.ask_population() * (upper - lower) + lower
-        L.event_record(2)
-        pts.eval_population_enqueue(cand, L.LOSS_HUBER, 10.0)
-        L.event_record(3)
-        pts.eval_population_wait(args.pop)
-        eval_ms = L.event_elapsed_ms(2, 3)
+        eval_ms, ar_ms = pts.eval_population_timing()        # the last generation's kernels / all-reduce (HIP events)
         evals = n_local * args.pop
+        n_gen = state["n"]
         out["cma"] = {
             "iters_per_s": k_cma / wall_c, "ms_per_iter": wall_c / k_cma * 1e3, "generations_timed": k_cma,
             "population": args.pop, "dims": len(targets), "loss": "huber f_scale=10",
             "point_candidate_evals_per_s": n_total * args.pop * k_cma / wall_c,
             "best_loss_last_generation": state.get("best"),
             "collective": "ncclAllReduce(sum, f64, P+1) per generation" if ctl.world > 1 else "none (1 GPU)",
-            "roofline": {"bound": "valu_fp32", "kernel": "popeval_kernel (+ reduce, all-reduce, D2H)",
+            "all_reduce_ms": ar_ms, "all_reduce_share_of_generation": ar_ms / (wall_c / k_cma * 1e3),
+            "host_ms_per_generation": {"ask": state["t_ask"] / n_gen * 1e3, "eval_call": state["t_eval"] / n_gen * 1e3,
+                                       "tell": state["t_tell"] / n_gen * 1e3},
+            "roofline": {"bound": "valu_fp32", "kernel": "popeval_kernel (+ reduce_partials_kernel)",
                          "kernel_ms": eval_ms,
                          "achieved": evals * EVAL_FLOPS / (eval_ms / 1e3) / 1e12, "peak": VALU_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": evals * EVAL_FLOPS / (eval_ms / 1e3) / VALU_PEAK,
@@ -291,45 +334,112 @@ def main():
                          "hbm_frac": n_local * 20 * ((args.pop + 127) // 128) / (eval_ms / 1e3) / HBM_PEAK},
         }
 
-    # ---------------------------------------------------------------- leg 3: depth raster (1 GPU)
+    # ---------------------------------------------------------------- float64 parity mode (1 GPU)
+    if ctl.world == 1 and not args.no_f64 and args.precision == "f32":
+        p64 = L.Points(xyz_l, origin, "f64")
+        k64 = min(args.steps, 20)
+        wall64, dev64 = timed(ctl, L, lambda: p64.project(pv_truth), k64, 3)
+        u64, v64 = p64.fetch_strided(0, step, cnt)
+        par64 = parity_report(np.stack([u64, v64], 1), ref, truth["w"])
+        par64["tolerance"] = 1e-9
+        k64_s = dev64 / k64 / 1e3
+        out["f64"] = {"projection": {"gpoints_per_s": n_total / (wall64 / k64) / 1e9, "ms_per_step": wall64 / k64 * 1e3,
+                                     "steps": k64, "parity": par64,
+                                     "roofline": {"bound": "hbm", "achieved": n_local * 40 / k64_s / 1e9, "peak": HBM_PEAK / 1e9,
+                                                  "unit": "GB/s", "frac": n_local * 40 / k64_s / HBM_PEAK, "kernel_ms": k64_s * 1e3,
+                                                  "bytes_per_vertex": 40}}}
+        if not args.no_cma:
+            p64.set_observed(obs)
+            gen64, st64 = cma_loop(L, CMA, p64, base, targets, bounds_to_array, args.pop, L.LOSS_HUBER, 10.0)
+            wall_c64, _ = timed(ctl, L, gen64, 2, 1)
+            e64, _ = p64.eval_population_timing()
+            out["f64"]["cma"] = {"iters_per_s": 2 / wall_c64, "ms_per_iter": wall_c64 / 2 * 1e3, "generations_timed": 2,
+                                 "population": args.pop, "dims": len(targets), "kernel_ms": e64,
+                                 "point_candidate_evals_per_s": n_total * args.pop * 2 / wall_c64,
+                                 "roofline": {"bound": "valu_fp64", "achieved": n_local * args.pop * EVAL_FLOPS / (e64 / 1e3) / 1e12,
+                                              "peak": VALU_PEAK_F64 / 1e12, "unit": "TFLOP/s",
+                                              "frac": n_local * args.pop * EVAL_FLOPS / (e64 / 1e3) / VALU_PEAK_F64}}
+        p64.close()
+
+    # ---------------------------------------------------------------- BASELINE configs 2 and 3: 10 M vertices (1 GPU)
+    if ctl.world == 1 and not args.no_10m and n_total > 20_000_000:
+        n10 = syn.grid_side(10_000_000)
+        s10 = syn.surface(n10)
+        x10 = syn.vert_to_xyz_local(s10["vert"])
+        b10 = syn.local_params(syn.standoff_params(n10), s10["offsets"])
+        t10 = syn.local_params(syn.perturbed(syn.standoff_params(n10)), s10["offsets"])
+        with L.Points(x10, [b10["x"], b10["y"], b10["z"]], "f32") as p10:
+            pv10 = L.params_vector(t10)
+            w10, d10 = timed(ctl, L, lambda: p10.project(pv10), args.steps, args.warmup)
+            k10 = d10 / args.steps / 1e3
+            c2 = {"vertices": len(x10), "gpoints_per_s": len(x10) / (w10 / args.steps) / 1e9, "ms_per_step": w10 / args.steps * 1e3,
+                  "roofline": {"bound": "hbm", "achieved": len(x10) * 20 / k10 / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                               "frac": len(x10) * 20 / k10 / HBM_PEAK, "kernel_ms": k10 * 1e3}}
+            uu, vv = p10.fetch(np.float32)
+            o10 = np.stack([uu, vv], 1) + np.random.default_rng(1).normal(0, 1.0, (len(x10), 2)).astype(np.float32)
+            o10[~np.isfinite(o10)] = 0.0
+            p10.set_observed(o10)
+            c3 = {"vertices": len(x10), "population": 256, "dims": 9, "sigma": 1.0}
+            for tag, kind, fs in (("huber_f10", L.LOSS_HUBER, 10.0), ("mean_distance", L.LOSS_MEAN_DIST, 0.0)):
+                g10, st10 = cma_loop(L, CMA, p10, b10, syn.TARGETS_D9, bounds_to_array, 256, kind, fs)
+                k_g = 50
+                wc, _ = timed(ctl, L, g10, k_g, 3)
+                ek, _ = p10.eval_population_timing()
+                c3[tag] = {"iters_per_s": k_g / wc, "ms_per_iter": wc / k_g * 1e3, "generations_timed": k_g, "kernel_ms": ek,
+                           "point_candidate_evals_per_s": len(x10) * 256 * k_g / wc,
+                           "host_ms_per_generation": {"ask": st10["t_ask"] / st10["n"] * 1e3, "tell": st10["t_tell"] / st10["n"] * 1e3},
+                           "valu_frac": len(x10) * 256 * EVAL_FLOPS / (ek / 1e3) / VALU_PEAK}
+        out["c2_c3_10m"] = {"c2_projection": c2, "c3_cma": c3}
+        del s10, x10, o10
+
+    # ---------------------------------------------------------------- depth raster (1 GPU)
     if ctl.world == 1 and not args.no_raster:
         cam = syn.base_params(n_side)              # camera on the surface's west edge
         pv_cam = L.params_vector(cam)
         k_r = min(args.steps, 10)
-        variants = [("implicit_grid", None)]
-        if args.raster_explicit:
-            variants.append(("int32_indices", syn.grid_indices(n_side, np.int32)))
         n_tri = 2 * (n_side - 1) ** 2
         W, H = int(cam["w"]), int(cam["h"])
         out["raster"] = {"frame": f"{W}x{H}", "vertices": n_total, "triangles": n_tri,
                          "call": "persp_proj(vert, vert, ind, params, offsets) as used by reverse_proj"}
-        for name, ind in variants:
-            if ind is not None:     # time the index-array kernel itself (a full regular grid would be recognised)
+        variants = [("implicit_grid", False)]
+        if not args.no_raster_explicit:
+            variants.append(("int32_indices", True))
+        for name, explicit in variants:
+            ind = None
+            if explicit:     # time the index-array kernel itself (a full regular grid would be recognised)
                 os.environ["ALP_NO_GRID_DETECT"] = "1"
-            mesh = L.Mesh(surf["vert"], None, ind, grid=None if ind is not None else (n_side, n_side))
+                ind = syn.grid_indices(n_side, np.int32)
+            t_mesh = time.perf_counter()
+            mesh = L.Mesh(surf["vert"], None, ind, grid=None if explicit else (n_side, n_side))
+            mesh.render_enqueue(pv_cam, surf["offsets"])
+            L.synchronize()
+            t_mesh = time.perf_counter() - t_mesh        # upload of the mesh + the first frame (incl. one-off tile bounds)
             os.environ.pop("ALP_NO_GRID_DETECT", None)
             wall_r, dev_r = timed(ctl, L, lambda: mesh.render_enqueue(pv_cam, surf["offsets"]), k_r, 2)
             img = mesh.fetch()
             # algorithmic bytes per frame: vertices 12 B (value == vert), indices 12 B per
             # triangle when explicit, visibility 8 B written + 8 B read per pixel, 12 B per pixel out
-            alg = n_total * 12 + (n_tri * 12 if ind is not None else 0) + W * H * (16 + 12)
+            alg = n_total * 12 + (n_tri * 12 if explicit else 0) + W * H * (16 + 12)
+            tr, tr_src = pmc_traffic("raster_" + name)
             out["raster"][name] = {
                 "ms_per_frame": wall_r / k_r * 1e3, "device_ms_per_frame": dev_r / k_r,
                 "gvertices_per_s": n_total / (wall_r / k_r) / 1e9, "frames_timed": k_r,
                 "covered_fraction": float((img[:, :, 0] > 0).mean()),
+                "upload_inclusive_ms_first_frame": t_mesh * 1e3,
                 "roofline": {"bound": "hbm", "achieved": alg / (dev_r / k_r / 1e3) / 1e9, "peak": HBM_PEAK / 1e9,
                              "unit": "GB/s", "frac": alg / (dev_r / k_r / 1e3) / HBM_PEAK,
                              "algorithmic_bytes_per_frame": alg,
+                             "traffic": tr["hbm_bytes_per_frame"] if tr else None, "traffic_source": tr_src,
                              # SURVEY 8(d) also counts the reference's separate remap pass (12 B read +
                              # 12 B written per pixel), which is fused away here
                              "frac_with_survey_remap_bytes": (alg + W * H * 24) / (dev_r / k_r / 1e3) / HBM_PEAK},
             }
-            if ind is None:     # also with the distorted ground-truth pose (remap stage on)
+            if not explicit:     # also with the distorted ground-truth pose (remap stage on)
                 pv_dist = L.params_vector(syn.truth_params(n_side))
                 wall_d, dev_d = timed(ctl, L, lambda: mesh.render_enqueue(pv_dist, surf["offsets"]), k_r, 2)
                 out["raster"][name]["distorted_pose_ms_per_frame"] = wall_d / k_r * 1e3
             mesh.close()
-            del img
+            del img, ind
 
     # ---------------------------------------------------------------- GCP-scale optimiser (1 GPU)
     # the reference's own problem size: 1127 GCPs, pop 50, D = 9, 300 generations, Huber f = 10

@@ -158,6 +158,12 @@ int alp_eval_population(alp_points_t *pts, const double *cand, int64_t P, int lo
 int alp_eval_population_enqueue(alp_points_t *pts, const double *cand, int64_t P,
                                 int loss_kind, double f_scale);
 int alp_eval_population_wait(alp_points_t *pts, double *loss_out, int64_t *argmin_out);
+/* Device time of the last completed population evaluation of this handle, from HIP events on the
+ * library stream: kernel_ms = the evaluation and reduction kernels, allreduce_ms = the
+ * ncclAllReduce(sum, double, P+1) behind them (about 0 without a communicator).  What bench.py
+ * reports as the collective's share of a CMA-ES generation (src/alproj/optimize.py:418-424 has no
+ * counterpart: the reference is one process). */
+int alp_eval_population_timing(alp_points_t *pts, float *kernel_ms, float *allreduce_ms);
 
 /* Loss of two host arrays of pixel coordinates (n x 2 row-major doubles each): replaces the
  * stand-alone rmse(), src/alproj/optimize.py:157-178 (loss_kind ALP_LOSS_MEAN_DIST) and

@@ -29,7 +29,7 @@ def _hand_made():
 SCENES = {
     "grid_tilted": lambda: _grid_scene(120, 320, 200, tilt=-10.0),
     "grid_tilt_roll": lambda: _grid_scene(90, 240, 160, tilt=-12.0, roll=7.0, pan=80.0),
-    "grid_near_plane": lambda: _grid_scene(60, 200, 140, dz=-48.5, tilt=-20.0),       # triangles cross vz = 1
+    "grid_near_plane": lambda: _grid_scene(60, 200, 140, dz=-48.0, tilt=-20.0),       # triangles cross vz = 1
     "grid_wide_fov": lambda: _grid_scene(100, 256, 192, fov=88.0, tilt=-30.0, pan=120.0),
     "hand_made_indices": _hand_made,
 }
