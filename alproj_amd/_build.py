@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 BUILD = os.path.join(ROOT, "build")
 LIB = os.path.join(HERE, "libalproj_hip.so")
-SOURCES = ["alp_core.hip", "alp_points.hip", "alp_raster.hip", "alp_mesh.hip", "alp_rasterize.hip"]
+SOURCES = ["alp_core.hip", "alp_points.hip", "alp_raster.hip", "alp_mesh.hip", "alp_rasterize.hip", "alp_sampler.hip"]
 # the raster's coverage/visibility arithmetic is specified operation by operation (DESIGN.md
 # section 5): no implicit fused multiply-adds there
 EXTRA_FLAGS = {"alp_raster.hip": ["-ffp-contract=off"], "alp_mesh.hip": ["-ffp-contract=off"]}

@@ -66,6 +66,8 @@ _SIGNATURES = {
     "alp_eval_population_wait": [_c_void_p, _c_dp, ctypes.POINTER(_c_i64)],
     "alp_eval_population_timing": [_c_void_p, _c_fp, _c_fp],
     "alp_loss_uv": [_c_dp, _c_dp, _c_i64, _c_int, _c_double, _c_dp],
+    "alp_cma_sample": [_c_dp, _c_double, _c_dp, _c_dp, _c_dp, _c_int, _c_i64, _c_int, ctypes.c_uint64, ctypes.c_uint64, _c_dp,
+                       ctypes.POINTER(ctypes.c_int32)],
     "alp_mesh_create": [_c_fp, _c_fp, _c_i64, _c_void_p, _c_int, _c_i64, _c_i64, _c_i64,
                         ctypes.POINTER(_c_void_p)],
     "alp_mesh_destroy": [_c_void_p],
@@ -453,6 +455,27 @@ def distort_image(img, coeffs):
     out = np.empty_like(img)
     check(lib().alp_distort_image(as_fp(img), h, w, c, as_dp(cf), as_fp(out)))
     return out
+
+
+def cma_sample(mean, sigma, BD, bounds, P, n_max_resampling, seed, generation, return_tries=False):
+    """(P, D) candidates of one CMA-ES generation drawn on the device (alp_cma_sample): x = mean + sigma BD z,
+    re-drawn until inside ``bounds`` (D, 2) at most ``n_max_resampling`` times, then clipped."""
+    mean = np.ascontiguousarray(mean, dtype=np.float64)
+    D = mean.shape[0]
+    BD = np.ascontiguousarray(BD, dtype=np.float64)
+    if BD.shape != (D, D):
+        raise ValueError("BD must be (D, D)")
+    lo = hi = None
+    if bounds is not None:
+        b = np.asarray(bounds, dtype=np.float64)
+        lo, hi = np.ascontiguousarray(b[:, 0]), np.ascontiguousarray(b[:, 1])
+    x = np.empty((int(P), D), dtype=np.float64)
+    tries = np.empty(int(P), dtype=np.int32) if return_tries else None
+    check(lib().alp_cma_sample(as_dp(mean), float(sigma), as_dp(BD), None if lo is None else as_dp(lo),
+                               None if hi is None else as_dp(hi), D, int(P), int(n_max_resampling),
+                               ctypes.c_uint64(int(seed) & (2**64 - 1)), ctypes.c_uint64(int(generation)), as_dp(x),
+                               None if tries is None else tries.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
+    return (x, tries) if return_tries else x
 
 
 def distort_map(h, w, coeffs):

@@ -19,7 +19,9 @@ trajectory is not reproducible, and cmaes itself is absent; parity of the optimi
 defined at the evaluation boundary (same candidates -> same losses / argmin).
 
 ``ask_population()`` is the vectorised form used by the GPU path: the whole generation is
-sampled at once so that it can be evaluated by ONE kernel launch.
+sampled at once so that it can be evaluated by ONE kernel launch.  With ``sampler=`` (the device
+sampler ``alproj_amd._lib.cma_sample`` = ``alp_cma_sample``) the draws themselves happen on the GPU:
+the reference's default sigma = 1.0 makes almost every draw infeasible, i.e. 101 draws per candidate.
 """
 import math
 
@@ -32,7 +34,7 @@ _SIGMA_MAX = 1e32
 
 class CMA:
     def __init__(self, mean, sigma, bounds=None, n_max_resampling=100, seed=None,
-                 population_size=None, cov=None):
+                 population_size=None, cov=None, sampler=None):
         mean = np.asarray(mean, dtype=np.float64)
         if sigma <= 0:
             raise ValueError("sigma must be non-zero positive value")
@@ -103,6 +105,10 @@ class CMA:
         # PCG64 + ziggurat normals: ~4x the throughput of RandomState.randn; the reference's
         # stream is unseeded and cmaes is absent, so no particular stream has to be reproduced
         self._rng = np.random.Generator(np.random.PCG64(seed))
+        # optional device sampler for ask_population(): callable(mean, sigma, BD, bounds, P, n_max_resampling,
+        # seed, generation) -> (P, D); the same resample-then-clip procedure, counter-based random numbers
+        self._sampler = sampler
+        self._sampler_seed = int(seed) if seed is not None else int(np.random.SeedSequence().entropy % (1 << 63))
 
     # ------------------------------------------------------------------ properties
     @property
@@ -163,6 +169,10 @@ class CMA:
     def ask_population(self):
         """All ``population_size`` candidates of one generation as a (P, D) array, with the
         same re-sample-then-clip rule applied row-wise."""
+        if self._sampler is not None:
+            b, d = self._eigen()
+            return np.asarray(self._sampler(self._mean, self._sigma, b * d, self._bounds, self._lam,
+                                            self._n_max_resampling, self._sampler_seed, self._g), dtype=np.float64)
         x = self._sample(self._lam)
         bad = np.flatnonzero(~self._feasible(x))
         tries = 1

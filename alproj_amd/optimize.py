@@ -240,7 +240,8 @@ class CMAOptimizer(BaseOptimizer):
                 seed = int(s[0])
             optimizer = CMA(mean=normalized_init.astype("float64"), sigma=float(sigma),
                             bounds=normalized_bounds, population_size=population_size,
-                            n_max_resampling=n_max_resampling, seed=seed)
+                            n_max_resampling=n_max_resampling, seed=seed,
+                            sampler=_lib.cma_sample if d <= 32 else None)
             it = range(generation)
             best_normalized = normalized_init
             for _ in (tqdm(it) if progress else it):

@@ -179,7 +179,7 @@ def cma_loop(L, CMA, pts, base, targets, bounds_fn, pop, loss_kind, f_scale, see
     basev = L.params_vector(base)
     opt = CMA(mean=np.full(len(targets), 0.5), sigma=1.0,
               bounds=np.column_stack([np.zeros(len(targets)), np.ones(len(targets))]),
-              population_size=pop, n_max_resampling=100, seed=seed)
+              population_size=pop, n_max_resampling=100, seed=seed, sampler=L.cma_sample)      # as CMAOptimizer.optimize does
     state = {"t_ask": 0.0, "t_eval": 0.0, "t_tell": 0.0}
 
     def generation():

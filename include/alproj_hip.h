@@ -165,6 +165,19 @@ int alp_eval_population_wait(alp_points_t *pts, double *loss_out, int64_t *argmi
  * counterpart: the reference is one process). */
 int alp_eval_population_timing(alp_points_t *pts, float *kernel_ms, float *allreduce_ms);
 
+/* The candidate sampler of the CMA-ES loop on the device: replaces the `population_size` calls of
+ * `optimizer.ask()` per generation, src/alproj/optimize.py:420-421 (third-party cmaes==0.12.0,
+ * requirements.txt:14; bounds handling documented at optimize.py:381-384).  Candidate c of generation g:
+ * x = mean + sigma * BD z with z ~ N(0, I_D) (BD = B diag(D) of the covariance C = B D^2 B^T, D x D
+ * row-major); a draw outside [lower, upper] is re-drawn, the first feasible one of n_max_resampling tries
+ * wins, otherwise draw number n_max_resampling is clipped to the box.  lower = upper = NULL: no box.
+ * Counter-based (Philox4x32-10 keyed by seed; counter = try, candidate, generation): the same numbers on
+ * every rank.  x_out: P x D row-major host array; tries_out (optional, P ints): index of the draw used
+ * (n_max_resampling = clipped).  D <= 32. */
+int alp_cma_sample(const double *mean, double sigma, const double *BD, const double *lower, const double *upper,
+                   int D, int64_t P, int n_max_resampling, uint64_t seed, uint64_t generation, double *x_out,
+                   int32_t *tries_out);
+
 /* Loss of two host arrays of pixel coordinates (n x 2 row-major doubles each): replaces the
  * stand-alone rmse(), src/alproj/optimize.py:157-178 (loss_kind ALP_LOSS_MEAN_DIST) and
  * huber_loss(), :181-212 (ALP_LOSS_HUBER).  Float64 arithmetic on the device. */

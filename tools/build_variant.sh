@@ -8,5 +8,5 @@ mkdir -p build/abl
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Iinclude -Ialproj_amd/csrc \
     -ffp-contract=off "$@" -c alproj_amd/csrc/alp_raster.hip -o build/abl/raster_$name.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/abl/libalproj_$name.so build/alp_core.o build/alp_points.o \
-    build/abl/raster_$name.o build/alp_mesh.o build/alp_rasterize.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+    build/abl/raster_$name.o build/alp_mesh.o build/alp_rasterize.o build/alp_sampler.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 echo build/abl/libalproj_$name.so
