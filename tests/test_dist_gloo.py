@@ -53,6 +53,42 @@ def test_sharded_population_matches_single_process(tmp_path, world):
         np.testing.assert_array_equal(r["losses"], res[0]["losses"])      # identical on every rank
 
 
+def test_world8_row_shards_of_the_10000_row_grid_reproduce_the_single_process_losses():
+    """BASELINE config 5's decomposition: the 10 000 grid rows of the 100 M-vertex DSM over 8 ranks
+    (alproj_amd.dist.shard_rows).  On a 10 000 x 12 slice of that grid (every row, 12 columns: all the row
+    bookkeeping, 1/833 of the arithmetic) the per-rank SUMS, packed and combined exactly as the all-reduce
+    delivers them (pack_partials / combine_partials), equal the single-process mean losses to 1e-12, the
+    argmin is the same, and every rank generates only its own rows of the surface (row-keyed noise)."""
+    n_rows, n_cols, world = 10_000, 12, 8
+    full = syn.dsm_rows(n_rows, 0, n_rows)[:, :]                      # (rows * n_side, 3) would be 100 M: take columns below
+    # a rank's rows generated on their own equal the same rows of the whole surface
+    lo3, hi3 = adist.shard_rows(n_rows, 3, world)
+    np.testing.assert_array_equal(syn.dsm_rows(n_rows, lo3, hi3), full[lo3 * n_rows:hi3 * n_rows])
+    grid = full.reshape(n_rows, n_rows, 3)[:, 4000:4000 + n_cols, :]
+    del full
+    xyz = np.ascontiguousarray(grid[:, :, [0, 2, 1]].reshape(-1, 3).astype(np.float64))      # x, y, z
+    base = syn.standoff_params(n_rows)
+    base = dict(base, x=base["x"] - syn.ABS_ORIGIN_XZY[0], y=base["y"] - syn.ABS_ORIGIN_XZY[2], z=base["z"] - syn.ABS_ORIGIN_XZY[1])
+    truth = syn.perturbed(base)
+    uv = orc.project_points(xyz, truth) + np.random.default_rng(4).normal(0, 1.0, (len(xyz), 2))
+    bounds = orc.bounds_to_array(base, syn.TARGETS_D21)
+    X = np.random.default_rng(6).uniform(0.45, 0.55, (16, 21))
+    ref, ref_amin = orc.population_losses(xyz, uv, base, syn.TARGETS_D21, bounds, X, 10.0)
+    reduced = np.zeros(len(X) + 1)
+    rows_seen = 0
+    for r in range(world):
+        lo, hi = adist.shard_rows(n_rows, r, world)
+        rows_seen += hi - lo
+        sl = slice(lo * n_cols, hi * n_cols)
+        sums = np.array([orc.huber(uv[sl], orc.project_points(xyz[sl], orc.candidate_params(base, syn.TARGETS_D21, bounds, x)), 10.0)
+                         * (sl.stop - sl.start) for x in X])
+        reduced += adist.pack_partials(sums, sl.stop - sl.start)         # what ncclAllReduce(sum) leaves on every rank
+    assert rows_seen == n_rows and reduced[-1] == len(xyz)
+    losses, amin = adist.combine_partials(reduced)
+    np.testing.assert_allclose(losses, ref, rtol=1e-12)
+    assert amin == ref_amin
+
+
 def test_shard_bounds_cover_everything():
     for n in (0, 1, 7, 100_000_000, 10_004_569):
         for world in (1, 2, 3, 8):

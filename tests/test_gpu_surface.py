@@ -2,6 +2,7 @@
 arrays of the reference's own get_colored_surface, and renders of the masked implicit grid
 against the oracle run on the reference's filtered index array."""
 import os
+import warnings
 
 import numpy as np
 import pytest
@@ -145,3 +146,58 @@ def test_reference_surface_behaviours(L):
         with mesh:
             _, col, _ = mesh.fetch_arrays()
             np.testing.assert_array_equal(col, np.float32(exp))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_get_colored_surface_io_branch_with_stand_in_rasterio(L, name, monkeypatch):
+    """alproj_amd.surface.get_colored_surface end to end, raster I/O included: rasterio (GDAL) is absent, so
+    the same stand-ins that fed the REFERENCE's get_colored_surface when g11 was captured
+    (tests/golden/gen_golden_surface.py: ``merge`` hands back the seeded rasters, ``fillnodata`` fills with a
+    fixed value) feed the product here -- merge, nodata masks, dsm_max_height, fillnodata call, the device
+    mesh: same vertices, colours, mask and offsets as the reference returned."""
+    import sys
+    import types
+    from alproj_amd import surface as asurf
+    fill_value = 1490.0
+    seen = {}
+
+    class FakeDataset:
+        def __init__(self, data, nodata, transform):
+            self.data, self.nodata, self.transform = data, nodata, transform
+            self.dtypes = tuple(str(data.dtype) for _ in range(data.shape[0]))
+
+    def merge(datasets, bounds=None, res=None, resampling=None):
+        seen.setdefault("merge_bounds", []).append(bounds)
+        return datasets[0].data.copy(), datasets[0].transform
+
+    def fillnodata(arr, mask, max_search_distance=None):
+        seen["max_search_distance"] = max_search_distance
+        out = arr.copy()
+        out[~mask] = fill_value
+        return out
+
+    mods = {"rasterio": types.ModuleType("rasterio"), "rasterio.merge": types.ModuleType("rasterio.merge"),
+            "rasterio.enums": types.ModuleType("rasterio.enums"), "rasterio.fill": types.ModuleType("rasterio.fill")}
+    mods["rasterio.merge"].merge = merge
+    mods["rasterio.enums"].Resampling = types.SimpleNamespace(cubic_spline="cubic_spline")
+    mods["rasterio.fill"].fillnodata = fillnodata
+    for k, v in mods.items():
+        monkeypatch.setitem(sys.modules, k, v)
+    nodata = G[f"{name}_nodata"]
+    raw = G[f"{name}_filled"].copy()
+    raw[nodata] = np.nan                                   # the DSM as it came out of `merge` when g11 was made
+    t = tuple(float(x) for x in G[f"{name}_transform"])
+    cm = float(G[f"{name}_color_max"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mesh, col_none, ind_none, off = asurf.get_colored_surface(
+            FakeDataset(G[f"{name}_aerial"], None, t), FakeDataset(raw[np.newaxis], None, t), {"x": 0.0, "y": 0.0},
+            distance=10, res=1.0, color_max=None if np.isnan(cm) else cm)
+    assert col_none is None and ind_none is None
+    assert seen["merge_bounds"] == [(-10.0, -10.0, 10.0, 10.0)] * 2 and seen["max_search_distance"] == 300
+    with mesh:
+        vert, col, valid = mesh.fetch_arrays()
+    np.testing.assert_array_equal(off, G[f"{name}_offsets"])
+    np.testing.assert_array_equal(vert, G[f"{name}_vert"].astype(np.float32))
+    np.testing.assert_array_equal(col, G[f"{name}_col"].astype(np.float32))
+    np.testing.assert_array_equal(valid, ~nodata.ravel())
