@@ -591,10 +591,10 @@ __device__ __forceinline__ void emit_general(const View &v, const float q[3][3],
 // one after the other inside the workgroup made those few workgroups the critical path of the whole
 // frame (0.8 ms for a handful of tiles while the rest of the chip idled).  They are appended to two
 // device queues instead and rasterised by their own launches, spread over every CU:
-//   raster_coop4_kernel  boxes of at most 8 x 8 centres: FOUR triangles per wave, 16 lanes = a 4 x 4
+//   raster_coop4_body    boxes of at most 8 x 8 centres: FOUR triangles per wave, 16 lanes = a 4 x 4
 //                        pixel block each (a 6 x 3 box costs two steps of a quarter wave instead of two
 //                        steps of a whole one);
-//   raster_coop_kernel   larger boxes: one triangle per wave, 8 x 8 pixel blocks (coop_raster).
+//   raster_coop_body     larger boxes: one triangle per wave, 8 x 8 pixel blocks (coop_raster).
 // Same integers and the same float32 depth expression as the inline walk.
 __device__ __forceinline__ void park_append(bool take, const Deferred &d, Deferred *__restrict__ queue,
                                             unsigned *__restrict__ count, unsigned cap) {
@@ -612,9 +612,9 @@ __device__ __forceinline__ void park_append(bool take, const Deferred &d, Deferr
     if (take && slot < cap) queue[slot] = d;       // an overflow is noticed by finish_frame (queue grown, frame redone)
 }
 
-__global__ __launch_bounds__(256) void raster_coop_kernel(View v, unsigned long long *__restrict__ vis,
-                                                          const Deferred *__restrict__ queue,
-                                                          const unsigned *__restrict__ count, unsigned cap) {
+__device__ __forceinline__ void raster_coop_body(const View &v, unsigned long long *__restrict__ vis,
+                                                 const Deferred *__restrict__ queue,
+                                                 const unsigned *__restrict__ count, unsigned cap) {
     const unsigned n = min(*count, cap);
     const int lane = (int)(threadIdx.x & 63);
     // workgroups go to the 8 XCDs round-robin: XCD x takes the x-th contiguous eighth of the queue
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void raster_coop_kernel(View v, unsigned long 
     const unsigned chunk = (n + 7u) >> 3, xcd = blockIdx.x & 7u, lo = xcd * chunk, hi = min(lo + chunk, n);
     const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(((blockIdx.x >> 3) * blockDim.x + threadIdx.x) >> 6));
     const unsigned nwaves = ((gridDim.x >> 3) * blockDim.x) >> 6;
-    if (lo + wave >= hi) return;
+    if (lo + wave >= hi) return;               // (returns from this body only: it is inlined into raster_parked_kernel)
     Deferred nextd = queue[lo + wave];         // wave-uniform address
     for (unsigned it = lo + wave; it < hi; it += nwaves) {
         const Deferred d = nextd;
@@ -639,9 +639,9 @@ __global__ __launch_bounds__(256) void raster_coop_kernel(View v, unsigned long 
     }
 }
 
-__global__ __launch_bounds__(256) void raster_coop4_kernel(View v, unsigned long long *__restrict__ vis,
-                                                           const Deferred *__restrict__ queue,
-                                                           const unsigned *__restrict__ count, unsigned cap) {
+__device__ __forceinline__ void raster_coop4_body(const View &v, unsigned long long *__restrict__ vis,
+                                                  const Deferred *__restrict__ queue,
+                                                  const unsigned *__restrict__ count, unsigned cap) {
     const unsigned n = min(*count, cap);
     const unsigned chunk = (n + 7u) >> 3, xcd = blockIdx.x & 7u, lo = xcd * chunk, hi = min(lo + chunk, n);   // as in raster_coop_kernel
     const unsigned group = ((blockIdx.x >> 3) * blockDim.x + threadIdx.x) >> 4, ngroups = ((gridDim.x >> 3) * blockDim.x) >> 4;
@@ -692,9 +692,9 @@ __global__ __launch_bounds__(256) void raster_coop4_kernel(View v, unsigned long
 // with the larger of its (at most two) keys: the row segments of both triangles of a cell travel in the
 // same 64-byte line-requests (the chip serves ~23 G atomic line-requests/s; 16-lane groups stepping
 // 8 x 2 blocks measured 130 M vector instructions for this stage, a wave per cell needs half).
-__global__ __launch_bounds__(256) void raster_cell_kernel(View v, unsigned long long *__restrict__ vis,
-                                                          const ParkedCell *__restrict__ queue,
-                                                          const unsigned *__restrict__ count, unsigned cap) {
+__device__ __forceinline__ void raster_cell_body(const View &v, unsigned long long *__restrict__ vis,
+                                                 const ParkedCell *__restrict__ queue,
+                                                 const unsigned *__restrict__ count, unsigned cap) {
     const unsigned n = min(*count, cap);
     const int lane = (int)(threadIdx.x & 63), lx = lane & 7, ly = lane >> 3;
     const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
@@ -742,6 +742,18 @@ __global__ __launch_bounds__(256) void raster_cell_kernel(View v, unsigned long 
         }
         if (key) vis_max(vis, v, i, j, key);
     }
+}
+
+// The three consumers of the parked work in ONE launch (three launches per round cost ~15 us of gaps):
+// every wave takes its share of the cells, then of the large triangles, then of the small ones.
+__global__ __launch_bounds__(256) void raster_parked_kernel(View v, unsigned long long *__restrict__ vis,
+                                                            const Deferred *__restrict__ small_q, const Deferred *__restrict__ large_q,
+                                                            const ParkedCell *__restrict__ cell_q,
+                                                            const unsigned *__restrict__ counts, unsigned cap_small,
+                                                            unsigned cap_large, unsigned cap_cell) {
+    raster_cell_body(v, vis, cell_q, counts + 2, cap_cell);
+    raster_coop_body(v, vis, large_q, counts + 1, cap_large);
+    raster_coop4_body(v, vis, small_q, counts + 0, cap_small);
 }
 
 // ------------------------------------------------------------------ kernel 2: per-triangle raster
@@ -1570,6 +1582,10 @@ __global__ __launch_bounds__(256) void distort_map_kernel(int w, int h, RemapCoe
     }
 }
 
+// (Measured and not kept, round 2: a two-stage software pipeline -- the loads of a thread's next pixel in
+// flight during the float64 interpolation of the current one.  The kernel without its float64 arithmetic
+// takes 115 us, with it 176 us; the pipelined form needs 111 VGPRs (4 waves per SIMD) and takes 167 us,
+// 220 us at 5 waves and 500 us at 6 (spills).)
 template <bool IMPLICIT>
 __global__ __launch_bounds__(256) void resolve_kernel(const float *__restrict__ vert, const float *__restrict__ value,
                                                       const int *__restrict__ ind, long long gw, View v,
@@ -1809,6 +1825,8 @@ unsigned initial_queue_cap() {
     return 1u << 20;
 }
 
+// Queues of parked work: [first round | second round] per kind.  The second round (far tiles: hardly
+// anything to park) gets an eighth of the first round's capacity; finish_frame grows either on overflow.
 int ensure_park(alp_mesh *m, unsigned cap_small, unsigned cap_large, unsigned cap_cell) {
     if (m->park_small && m->park_cap[0] >= cap_small && m->park_cap[1] >= cap_large && m->park_cap[2] >= cap_cell) return ALP_OK;
     if (m->park_small) hipFree(m->park_small);
@@ -1816,12 +1834,16 @@ int ensure_park(alp_mesh *m, unsigned cap_small, unsigned cap_large, unsigned ca
     m->park_small = nullptr;
     m->park_large = nullptr;
     m->park_cell = nullptr;
-    ALP_HIP(hipMalloc((void **)&m->park_small, ((size_t)cap_small + cap_large) * sizeof(Deferred)));
-    ALP_HIP(hipMalloc((void **)&m->park_cell, (size_t)cap_cell * sizeof(ParkedCell)));
-    m->park_large = (Deferred *)m->park_small + cap_small;
-    m->park_cap[0] = cap_small;
-    m->park_cap[1] = cap_large;
-    m->park_cap[2] = cap_cell;
+    const unsigned caps[3] = {cap_small, cap_large, cap_cell};
+    unsigned b[3];
+    for (int k = 0; k < 3; ++k) b[k] = std::max(m->park_cap_b[k], caps[k] / 8 + 64);
+    ALP_HIP(hipMalloc((void **)&m->park_small, ((size_t)cap_small + b[0] + cap_large + b[1]) * sizeof(Deferred)));
+    ALP_HIP(hipMalloc((void **)&m->park_cell, ((size_t)cap_cell + b[2]) * sizeof(ParkedCell)));
+    m->park_large = (Deferred *)m->park_small + cap_small + b[0];
+    for (int k = 0; k < 3; ++k) {
+        m->park_cap[k] = caps[k];
+        m->park_cap_b[k] = b[k];
+    }
     return ALP_OK;
 }
 
@@ -1865,8 +1887,9 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
     if (m->n_tri > 0) {
         // queue counters, four per round: [0] work items, [1] general entries, [2] small parked, [3] large parked
         ALP_HIP(hipMemsetAsync(m->qcount_dev, 0, QC_TOTAL * sizeof(unsigned), st));
-        // the consumers of the rare cases (near-plane crossings, 64 px and more) of one round
-        auto drain_round = [&](int round) -> int {
+        // the consumers of one round: (a) the rare cases (near-plane crossings, 64 px and more), (b) what
+        // raster_grid_kernel parked; the second round's parked entries follow the first round's in the queues
+        auto drain_rare = [&](int round) -> int {
             unsigned *items = m->qcount_dev + QC_STRIDE * round, *general = items + 1;
             hipLaunchKernelGGL((raster_general_kernel<IMPLICIT>), dim3(cu * 2), dim3(256), 0, st, m->vert, m->ind,
                                (long long)m->grid_w, v, m->vis, m->gqueue, general, m->gcap, m->queue, items, m->qcap);
@@ -1874,17 +1897,16 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
             hipLaunchKernelGGL((raster_large_kernel<IMPLICIT>), dim3(cu * 8), dim3(256), 0, st, m->vert, m->ind,
                                (long long)m->grid_w, v, m->vis, m->queue, items, m->qcap);
             ALP_HIP(hipGetLastError());
-            if constexpr (IMPLICIT) {          // the triangles the grid kernel parked
-                hipLaunchKernelGGL(raster_coop4_kernel, dim3(cu * 8), dim3(256), 0, st, v, m->vis, m->park_small, items + 2,
-                                   m->park_cap[0]);
-                ALP_HIP(hipGetLastError());
-                hipLaunchKernelGGL(raster_coop_kernel, dim3(cu * 8), dim3(256), 0, st, v, m->vis, m->park_large, items + 3,
-                                   m->park_cap[1]);
-                ALP_HIP(hipGetLastError());
-                hipLaunchKernelGGL(raster_cell_kernel, dim3(cu * 8), dim3(256), 0, st, v, m->vis, m->park_cell, items + 4,
-                                   m->park_cap[2]);
-                ALP_HIP(hipGetLastError());
-            }
+            return ALP_OK;
+        };
+        auto drain_parked = [&](int round) -> int {
+            unsigned *items = m->qcount_dev + QC_STRIDE * round;
+            const unsigned *cap = round ? m->park_cap_b : m->park_cap;
+            const int wgs = round ? cu * 2 : cu * 8;
+            hipLaunchKernelGGL(raster_parked_kernel, dim3(wgs), dim3(256), 0, st, v, m->vis,
+                               m->park_small + (round ? m->park_cap[0] : 0), m->park_large + (round ? m->park_cap[1] : 0),
+                               m->park_cell + (round ? m->park_cap[2] : 0), items + 2, cap[0], cap[1], cap[2]);
+            ALP_HIP(hipGetLastError());
             return ALP_OK;
         };
         if constexpr (IMPLICIT) {
@@ -1959,9 +1981,13 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
                 }
             }
 #endif
-            if (int e = drain_round(0)) return e;
+            if (int e = drain_rare(0)) return e;
+            if (int e = drain_parked(0)) return e;
             if (cull.enabled && cull.occlusion) {
-                // depth pyramid of what the first round drew, occlusion test of the far tiles, second round
+                // depth pyramid of everything the first round drew, occlusion test of the far tiles, second round.
+                // (Measured and not kept: building the pyramid BEFORE the first round's parked cells / triangles
+                // are drawn and running the second round on a second stream next to them -- the parked geometry
+                // is the main occluder, three times as many far tiles survive, 1.23 instead of 1.06 ms.)
                 const HizDims dm = hiz_dims(v.w, v.h);
                 hipLaunchKernelGGL(hiz_build_kernel, dim3((unsigned)dm.w[3], (unsigned)dm.h[3]), dim3(256), 0, st, m->vis, v.w,
                                    v.h, dm, m->hiz);
@@ -1973,10 +1999,12 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
                 ALP_HIP(hipGetLastError());
                 hipLaunchKernelGGL(raster_grid_kernel, dim3(grid_wgs), dim3(256), 0, st, m->vert, m->valid,
                                    (int)m->grid_h, (int)m->grid_w, v, m->vis, m->gqueue, m->qcount_dev + QC_STRIDE + 1, m->gcap,
-                                   along_rows, second_list, counts + 2, m->park_small, m->park_large, m->park_cell,
-                                   m->qcount_dev + QC_STRIDE + 2, m->park_cap[0], m->park_cap[1], m->park_cap[2]);
+                                   along_rows, second_list, counts + 2, m->park_small + m->park_cap[0],
+                                   m->park_large + m->park_cap[1], m->park_cell + m->park_cap[2], m->qcount_dev + QC_STRIDE + 2,
+                                   m->park_cap_b[0], m->park_cap_b[1], m->park_cap_b[2]);
                 ALP_HIP(hipGetLastError());
-                if (int e = drain_round(1)) return e;
+                if (int e = drain_rare(1)) return e;
+                if (int e = drain_parked(1)) return e;
             }
 #ifdef ALP_RASTER_STATS
             {
@@ -1997,7 +2025,7 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
                                (long long)m->n_tri, (long long)m->grid_w, v, m->vis, m->gqueue, m->qcount_dev + 1,
                                m->gcap);
             ALP_HIP(hipGetLastError());
-            if (int e = drain_round(0)) return e;
+            if (int e = drain_rare(0)) return e;
         }
         ALP_HIP(hipMemcpyAsync(m->qcount_host, m->qcount_dev, 2 * QC_STRIDE * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     }
@@ -2042,16 +2070,21 @@ int finish_frame(alp_mesh *m) {
         ALP_HIP(hipStreamSynchronize(ctx().stream));
         m->unchecked = false;
         const unsigned *h = m->qcount_host;
-        const unsigned items = std::max(h[0], h[QC_STRIDE]), general = std::max(h[1], h[QC_STRIDE + 1]),
-                       psmall = std::max(h[2], h[QC_STRIDE + 2]), plarge = std::max(h[3], h[QC_STRIDE + 3]),
-                       pcell = std::max(h[4], h[QC_STRIDE + 4]);
-        const bool park_ok = !m->park_small || (psmall <= m->park_cap[0] && plarge <= m->park_cap[1] && pcell <= m->park_cap[2]);
+        const unsigned items = std::max(h[0], h[QC_STRIDE]), general = std::max(h[1], h[QC_STRIDE + 1]);
+        bool park_ok = true;
+        unsigned want_a[3], want_b[3];
+        for (int k = 0; k < 3; ++k) {
+            want_a[k] = m->park_cap[k];
+            want_b[k] = m->park_cap_b[k];
+            if (m->park_small && h[2 + k] > m->park_cap[k]) { park_ok = false; want_a[k] = h[2 + k] + h[2 + k] / 4 + 1024; }
+            if (m->park_small && h[QC_STRIDE + 2 + k] > m->park_cap_b[k]) { park_ok = false; want_b[k] = h[QC_STRIDE + 2 + k] + h[QC_STRIDE + 2 + k] / 4 + 1024; }
+        }
         if (items <= m->qcap && general <= m->gcap && park_ok) break;
-        if (!park_ok)
-            if (int e = ensure_park(m, std::max(m->park_cap[0], psmall + psmall / 4 + 1024),
-                                    std::max(m->park_cap[1], plarge + plarge / 4 + 1024),
-                                    std::max(m->park_cap[2], pcell + pcell / 4 + 1024)))
-                return e;
+        if (!park_ok) {
+            for (int k = 0; k < 3; ++k) m->park_cap_b[k] = want_b[k];
+            m->park_cap[0] = 0;           // force the reallocation
+            if (int e = ensure_park(m, want_a[0], want_a[1], want_a[2])) return e;
+        }
         if (items > m->qcap)
             if (int e = ensure_queue(m, items + items / 4 + 1024)) return e;
         if (general > m->gcap)

@@ -61,7 +61,8 @@ struct alp_mesh {
     unsigned gcap = 0;
     alp::Deferred *park_small = nullptr, *park_large = nullptr;   // implicit grid: parked triangles (one allocation)
     alp::ParkedCell *park_cell = nullptr;                         // implicit grid: parked cells
-    unsigned park_cap[3] = {0, 0, 0};                             // small, large, cells
+    unsigned park_cap[3] = {0, 0, 0};                             // small, large, cells: first round
+    unsigned park_cap_b[3] = {0, 0, 0};                           // second round (its entries follow the first round's)
     // per round (2 rounds x QC_STRIDE) [0] work items, [1] general entries, [2] small parked, [3] large parked,
     // [4] parked cells; then the three tile-list lengths of the frame plan
     unsigned *qcount_dev = nullptr;
