@@ -241,7 +241,10 @@ class CMAOptimizer(BaseOptimizer):
             optimizer = CMA(mean=normalized_init.astype("float64"), sigma=float(sigma),
                             bounds=normalized_bounds, population_size=population_size,
                             n_max_resampling=n_max_resampling, seed=seed,
-                            sampler=_lib.cma_sample if d <= 32 else None)
+                            # the device sampler costs a launch + a copy (~0.07 ms): it pays from a few thousand
+                            # deviates per generation (pop 256 / D 21: 0.10 ms against 7 ms of numpy at sigma = 1);
+                            # at GCP scale (pop 50 / D 9) the numpy path is the faster one (0.17 vs 0.24 ms / generation)
+                            sampler=_lib.cma_sample if (d <= 32 and population_size * d >= 2048) else None)
             it = range(generation)
             best_normalized = normalized_init
             for _ in (tqdm(it) if progress else it):
