@@ -965,14 +965,24 @@ static void make_tile_cull(const View &v, TileCull *c) {
 // list (drawn first: the occluders) and the FAR list (tested against the depth pyramid of the first
 // round before they are drawn).  counts[0] = near, counts[1] = far.  Wave-aggregated appends keep the
 // lists roughly in tile order.
+// Workgroup-aggregated append (all 256 threads call it): ONE atomicAdd per workgroup and list -- a
+// reservation per wave made the two list counters the cost of these tiny kernels (1500 same-address
+// atomics: 23 us for tile_plan_kernel).  The order inside the list follows the thread order.
 __device__ __forceinline__ void list_append(bool take, unsigned value, unsigned *__restrict__ list, unsigned *count) {
+    __shared__ unsigned s_cnt[4], s_base;
     const unsigned long long m = __ballot(take);
-    if (!m) return;
-    const int lane = (int)(threadIdx.x & 63);
-    unsigned base = 0;
-    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(count, (unsigned)__popcll(m));
-    base = (unsigned)__builtin_amdgcn_readlane((int)base, __ffsll((long long)m) - 1);
-    if (take) list[base + __popcll(m & ((1ull << lane) - 1ull))] = value;
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    if (lane == 0) s_cnt[wave] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        s_base = total ? atomicAdd(count, total) : 0u;
+    }
+    __syncthreads();
+    unsigned before = 0;
+    for (int w = 0; w < wave; ++w) before += s_cnt[w];
+    if (take) list[s_base + before + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = value;
+    __syncthreads();         // s_cnt / s_base are reused by the next call
 }
 
 __global__ __launch_bounds__(256) void tile_plan_kernel(const float *__restrict__ tile_bounds, unsigned n_tiles, TileCull cull,
@@ -1866,7 +1876,7 @@ int ensure_frame(alp_mesh *m, int w, int h) {
     if (m->image) hipFree(m->image);
     m->vis = nullptr;
     m->image = nullptr;
-    ALP_HIP(hipMalloc((void **)&m->vis, (size_t)w * h * sizeof(unsigned long long)));
+    ALP_HIP(hipMalloc((void **)&m->vis, (size_t)w * h * sizeof(unsigned long long) + QC_TOTAL * sizeof(unsigned)));   // + the frame's counters
     ALP_HIP(hipMalloc((void **)&m->image, (size_t)w * h * 3 * sizeof(float)));
     if (m->hiz) hipFree(m->hiz);
     m->hiz = nullptr;
@@ -1883,14 +1893,15 @@ template <bool IMPLICIT>
 int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_distance) {
     hipStream_t st = ctx().stream;
     const int cu = ctx().cu_count;
-    ALP_HIP(hipMemsetAsync(m->vis, 0, (size_t)v.w * v.h * sizeof(unsigned long long), st));
+    // one fill clears the visibility buffer AND the frame's queue / list counters, which live right behind it
+    ALP_HIP(hipMemsetAsync(m->vis, 0, (size_t)v.w * v.h * sizeof(unsigned long long) + QC_TOTAL * sizeof(unsigned), st));
+    unsigned *const fcount = (unsigned *)(m->vis + (size_t)v.w * v.h);
     if (m->n_tri > 0) {
         // queue counters, four per round: [0] work items, [1] general entries, [2] small parked, [3] large parked
-        ALP_HIP(hipMemsetAsync(m->qcount_dev, 0, QC_TOTAL * sizeof(unsigned), st));
         // the consumers of one round: (a) the rare cases (near-plane crossings, 64 px and more), (b) what
         // raster_grid_kernel parked; the second round's parked entries follow the first round's in the queues
         auto drain_rare = [&](int round) -> int {
-            unsigned *items = m->qcount_dev + QC_STRIDE * round, *general = items + 1;
+            unsigned *items = fcount + QC_STRIDE * round, *general = items + 1;
             hipLaunchKernelGGL((raster_general_kernel<IMPLICIT>), dim3(cu * 2), dim3(256), 0, st, m->vert, m->ind,
                                (long long)m->grid_w, v, m->vis, m->gqueue, general, m->gcap, m->queue, items, m->qcap);
             ALP_HIP(hipGetLastError());
@@ -1900,7 +1911,7 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
             return ALP_OK;
         };
         auto drain_parked = [&](int round) -> int {
-            unsigned *items = m->qcount_dev + QC_STRIDE * round;
+            unsigned *items = fcount + QC_STRIDE * round;
             const unsigned *cap = round ? m->park_cap_b : m->park_cap;
             const int wgs = round ? cu * 2 : cu * 8;
             hipLaunchKernelGGL(raster_parked_kernel, dim3(wgs), dim3(256), 0, st, v, m->vis,
@@ -1927,7 +1938,7 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
                 ALP_HIP(hipGetLastError());
             }
             unsigned *near_list = m->tile_lists, *far_list = near_list + tiles, *second_list = far_list + tiles,
-                     *counts = m->qcount_dev + 2 * QC_STRIDE;   // [0] near, [1] far, [2] far survivors (cleared with the queue counters)
+                     *counts = fcount + 2 * QC_STRIDE;   // [0] near, [1] far, [2] far survivors (cleared with the queue counters)
             TileCull cull;
             make_tile_cull(v, &cull);
             if (getenv("ALP_NO_TILE_CULL")) cull.enabled = 0;     // development: measure / cross-check the exact path alone
@@ -1943,9 +1954,9 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
             // first round: the near tiles (the occluders).  One workgroup per possible list entry; the
             // ones beyond the list's length leave at once.
             hipLaunchKernelGGL(raster_grid_kernel, dim3(grid_wgs), dim3(256), 0, st, m->vert, m->valid,
-                               (int)m->grid_h, (int)m->grid_w, v, m->vis, m->gqueue, m->qcount_dev + 1, m->gcap,
+                               (int)m->grid_h, (int)m->grid_w, v, m->vis, m->gqueue, fcount + 1, m->gcap,
                                along_rows, near_list, counts + 0, m->park_small, m->park_large, m->park_cell,
-                               m->qcount_dev + 2, m->park_cap[0], m->park_cap[1], m->park_cap[2]);
+                               fcount + 2, m->park_cap[0], m->park_cap[1], m->park_cap[2]);
             ALP_HIP(hipGetLastError());
 #ifdef ALP_WG_TIMING
             {   // duration of every workgroup of the first round
@@ -1998,9 +2009,9 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
                                    counts, dm, m->hiz, second_list, counts + 2);
                 ALP_HIP(hipGetLastError());
                 hipLaunchKernelGGL(raster_grid_kernel, dim3(grid_wgs), dim3(256), 0, st, m->vert, m->valid,
-                                   (int)m->grid_h, (int)m->grid_w, v, m->vis, m->gqueue, m->qcount_dev + QC_STRIDE + 1, m->gcap,
+                                   (int)m->grid_h, (int)m->grid_w, v, m->vis, m->gqueue, fcount + QC_STRIDE + 1, m->gcap,
                                    along_rows, second_list, counts + 2, m->park_small + m->park_cap[0],
-                                   m->park_large + m->park_cap[1], m->park_cell + m->park_cap[2], m->qcount_dev + QC_STRIDE + 2,
+                                   m->park_large + m->park_cap[1], m->park_cell + m->park_cap[2], fcount + QC_STRIDE + 2,
                                    m->park_cap_b[0], m->park_cap_b[1], m->park_cap_b[2]);
                 ALP_HIP(hipGetLastError());
                 if (int e = drain_rare(1)) return e;
@@ -2022,12 +2033,12 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
 #endif
             const int grid = (int)(want < (long long)cu * RASTER_BLOCKS_PER_CU ? want : (long long)cu * RASTER_BLOCKS_PER_CU);
             hipLaunchKernelGGL((raster_kernel<IMPLICIT>), dim3(grid), dim3(256), 0, st, m->vert, m->ind, m->valid,
-                               (long long)m->n_tri, (long long)m->grid_w, v, m->vis, m->gqueue, m->qcount_dev + 1,
+                               (long long)m->n_tri, (long long)m->grid_w, v, m->vis, m->gqueue, fcount + 1,
                                m->gcap);
             ALP_HIP(hipGetLastError());
             if (int e = drain_rare(0)) return e;
         }
-        ALP_HIP(hipMemcpyAsync(m->qcount_host, m->qcount_dev, 2 * QC_STRIDE * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        ALP_HIP(hipMemcpyAsync(m->qcount_host, fcount, 2 * QC_STRIDE * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     }
     const long long npix = (long long)v.w * v.h;
     const long long want = (npix + 255) / 256;
