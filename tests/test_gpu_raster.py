@@ -476,3 +476,63 @@ def test_near_field_cell_poking_a_viewport_corner(L, corner):
     with L.Mesh(vert, None, ind) as m:
         m.render_enqueue(L.params_vector(p), None)
         assert_vis_equal(m.fetch_visibility(), ref)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_poses_culling_and_occlusion_stay_exact(L, seed):
+    """Random cameras around, above, inside and beside a 400 x 260 surface (non-square: several tile rows and
+    columns, partial tiles), small frames so that most cells are far below a pixel: frustum culling, the near /
+    far split and the depth-pyramid occlusion test must never change a single visibility word (each frame is
+    compared with the frozen oracle and with the same library running with both cullings switched off)."""
+    import os
+    rng = np.random.default_rng(100 + seed)
+    gh, gw = 260, 400
+    yy, xx = np.mgrid[0:gh, 0:gw].astype(np.float64)
+    z = 60 * np.sin(xx / 45.0) * np.cos(yy / 33.0) + 15 * np.sin(xx / 7.0) * np.sin(yy / 9.0) + rng.normal(0, 0.3, (gh, gw))
+    vert = np.stack([xx.ravel(), (z - z.min()).ravel(), (gh - 1 - yy).ravel()], 1).astype(np.float32)      # X, Z(up), Y
+    valid = None
+    if seed % 2:
+        valid = rng.random(gh * gw) > 0.02
+    with L.Mesh(vert, None, None, grid=(gh, gw)) as m:
+        if valid is not None:
+            m.set_valid(valid)
+        ind = None
+        if valid is not None:          # the oracle draws the filtered index array; ids are mapped below
+            from alproj_amd import synthetic as syn
+            a = (np.arange(gw - 1)[None, :] + np.arange(gh - 1)[:, None] * gw).ravel()
+            full = np.stack([a, a + gw, a + gw + 1, a, a + gw + 1, a + 1], axis=1).reshape(-1, 3)
+            keep = np.flatnonzero(valid[full].all(axis=1))
+            ind = full[keep]
+        for k in range(5):
+            w, h = [(160, 120), (96, 64), (320, 200), (64, 200), (240, 90)][k]
+            kind = rng.integers(0, 4)
+            if kind == 0:      # beside the surface looking across it
+                cam = dict(x=-rng.uniform(5, 300), y=rng.uniform(0, gh), z=float(z.max() - z.min()) + rng.uniform(-40, 80), pan=rng.uniform(60, 120))
+            elif kind == 1:    # above it looking down-ish
+                cam = dict(x=rng.uniform(0, gw), y=rng.uniform(0, gh), z=float(z.max() - z.min()) + rng.uniform(20, 400), pan=rng.uniform(0, 360))
+            elif kind == 2:    # inside the valley system, low above the ground
+                cx, cy = rng.integers(5, gw - 5), rng.integers(5, gh - 5)
+                cam = dict(x=float(cx), y=float(gh - 1 - cy), z=float(z[cy, cx] - z.min()) + rng.uniform(1.2, 6.0), pan=rng.uniform(0, 360))
+            else:              # far away
+                cam = dict(x=-rng.uniform(500, 3000), y=rng.uniform(-500, gh + 500), z=rng.uniform(50, 800), pan=rng.uniform(70, 110))
+            p = dict(orc.vector_to_params(np.zeros(25)), a1=1.0, a2=1.0, fov=rng.uniform(25, 88), tilt=rng.uniform(-60, 15),
+                     roll=rng.uniform(-25, 25), w=w, h=h, cx=w / 2, cy=h / 2, **cam)
+            pv = L.params_vector(p)
+            m.render_enqueue(pv, None)
+            got = m.fetch_visibility()
+            ref = orast.visibility(vert, ind, p, None, grid=None if ind is not None else (gh, gw))
+            if ind is None:
+                assert_vis_equal(got, ref)
+            else:
+                hit = ref != 0
+                np.testing.assert_array_equal(got != 0, hit)
+                np.testing.assert_array_equal(got[hit] >> np.uint64(32), ref[hit] >> np.uint64(32))
+                tri_dev = 0xFFFFFFFF - (got[hit] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+                tri_ref = 0xFFFFFFFF - (ref[hit] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+                np.testing.assert_array_equal(tri_dev, keep[tri_ref])
+            os.environ["ALP_NO_TILE_CULL"] = "1"
+            try:
+                m.render_enqueue(pv, None)
+                np.testing.assert_array_equal(m.fetch_visibility(), got)
+            finally:
+                os.environ.pop("ALP_NO_TILE_CULL", None)
