@@ -85,6 +85,7 @@ int alp_mesh_set_value_source(alp_mesh_t *m, int source) {
 int alp_mesh_set_valid(alp_mesh_t *m, const uint8_t *valid) {
     if (int rc = require_init()) return rc;
     ALP_REQUIRE(m, "mesh handle is NULL");
+    if (m->valid_derived) return apply_derived_mask(m, valid);   // filtered grid: its own mask stays in force
     if (!valid) {
         if (m->valid) hipFree(m->valid);
         m->valid = nullptr;

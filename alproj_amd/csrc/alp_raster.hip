@@ -1793,6 +1793,100 @@ __global__ __launch_bounds__(256) void check_grid_kernel(const int *__restrict__
     if (bad) *mismatch = 1u;
 }
 
+// Is an index array a FILTERED regular grid (the triangles of surface.py:194-201 in their order, some
+// removed -- what get_colored_surface returns for a DSM with nodata, surface.py:203-205)?  Pass 1, per
+// triangle of the array: it must be a grid triangle, later in grid order than its predecessor; its bit is
+// set in `present`, its vertices are marked.  Pass 2, per grid triangle NOT in the array: one of its
+// vertices must be unmarked -- then "draw the triangles whose three vertices are marked" draws exactly the
+// array, and the mesh is rendered by the implicit-grid kernels with that vertex mask.
+__device__ __forceinline__ long long subgrid_id(const int *__restrict__ ind, long long t, long long gw, long long gh) {
+    const long long a = ind[3 * t], b = ind[3 * t + 1], c = ind[3 * t + 2];
+    int type;
+    if (b == a + gw && c == a + gw + 1) type = 0;
+    else if (b == a + gw + 1 && c == a + 1) type = 1;
+    else return -1;
+    const long long row = a / gw, col = a - row * gw;
+    if (a < 0 || row >= gh - 1 || col >= gw - 1) return -1;
+    return 2 * (row * (gw - 1) + col) + type;
+}
+
+__global__ __launch_bounds__(256) void subgrid_mark_kernel(const int *__restrict__ ind, long long n_tri, long long gw, long long gh,
+                                                           unsigned *__restrict__ present, unsigned char *__restrict__ mark,
+                                                           unsigned *__restrict__ mismatch) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n_tri; t += stride) {
+        const long long id = subgrid_id(ind, t, gw, gh);
+        if (id < 0 || (t > 0 && subgrid_id(ind, t - 1, gw, gh) >= id)) { bad = true; continue; }
+        atomicOr(&present[id >> 5], 1u << (id & 31));
+        mark[ind[3 * t]] = 1;
+        mark[ind[3 * t + 1]] = 1;
+        mark[ind[3 * t + 2]] = 1;
+    }
+    if (bad) *mismatch = 1u;
+}
+
+__global__ __launch_bounds__(256) void subgrid_absent_kernel(long long n_grid_tri, long long gw, const unsigned *__restrict__ present,
+                                                             const unsigned char *__restrict__ mark, unsigned *__restrict__ mismatch) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < n_grid_tri; id += stride) {
+        if (present[id >> 5] >> (id & 31) & 1u) continue;
+        const Idx3 e = tri_vertices<true>(nullptr, gw, id);
+        bad |= mark[e.a] && mark[e.b] && mark[e.c];
+    }
+    if (bad) *mismatch = 1u;
+}
+
+// rank[w] = number of set bits in present[0 .. w): block sums, then (after the host scanned them) the words
+__global__ __launch_bounds__(256) void subgrid_blocksum_kernel(const unsigned *__restrict__ present, long long n_words,
+                                                               unsigned *__restrict__ block_sums) {
+    __shared__ unsigned s[4];
+    const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+    unsigned c = w < n_words ? (unsigned)__popc(present[w]) : 0u;
+    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ __launch_bounds__(256) void subgrid_rank_kernel(const unsigned *__restrict__ present, long long n_words,
+                                                           const unsigned *__restrict__ block_offsets, unsigned *__restrict__ rank) {
+    __shared__ unsigned s[256];
+    const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+    s[threadIdx.x] = w < n_words ? (unsigned)__popc(present[w]) : 0u;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {                  // Hillis-Steele inclusive scan
+        const unsigned t = threadIdx.x >= (unsigned)d ? s[threadIdx.x - d] : 0u;
+        __syncthreads();
+        s[threadIdx.x] += t;
+        __syncthreads();
+    }
+    if (w < n_words) rank[w] = block_offsets[blockIdx.x] + (threadIdx.x ? s[threadIdx.x - 1] : 0u);
+}
+
+// visibility words with the grid's triangle ids -> positions in the caller's (filtered) index array
+__global__ __launch_bounds__(256) void vis_translate_kernel(const unsigned long long *__restrict__ vis, long long npix,
+                                                            const unsigned *__restrict__ present, const unsigned *__restrict__ rank,
+                                                            unsigned long long *__restrict__ out) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    unsigned long long key = vis[p];
+    if (key) {
+        const unsigned id = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+        const unsigned pos = rank[id >> 5] + (unsigned)__popc(present[id >> 5] & ((1u << (id & 31)) - 1u));
+        key = (key & 0xFFFFFFFF00000000ull) | (unsigned long long)(0xFFFFFFFFu - pos);
+    }
+    out[p] = key;
+}
+
+// valid = derived AND (user mask or all ones)
+__global__ __launch_bounds__(256) void mask_and_kernel(const unsigned char *__restrict__ derived, const unsigned char *__restrict__ user,
+                                                       long long n, unsigned char *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = derived[i] && (!user || user[i]);
+}
+
 __global__ __launch_bounds__(256) void narrow_indices_kernel(const long long *__restrict__ src, long long count,
                                                              long long dst_off, int *__restrict__ dst) {
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -1854,6 +1948,89 @@ int ensure_park(alp_mesh *m, unsigned cap_small, unsigned cap_large, unsigned ca
         m->park_cap[k] = caps[k];
         m->park_cap_b[k] = b[k];
     }
+    return ALP_OK;
+}
+
+int apply_derived_mask(alp_mesh *m, const unsigned char *user) {
+    hipStream_t st = ctx().stream;
+    unsigned char *user_dev = nullptr;
+    if (user) {
+        if (int rc = scratch_reserve((size_t)m->n_vert, (void **)&user_dev)) return rc;
+        if (int rc = upload_chunked(user_dev, user, (size_t)m->n_vert)) return rc;
+    }
+    if (!m->valid) ALP_HIP(hipMalloc((void **)&m->valid, (size_t)m->n_vert));
+    hipLaunchKernelGGL(mask_and_kernel, dim3((unsigned)((m->n_vert + 255) / 256)), dim3(256), 0, st, m->valid_derived, user_dev,
+                       (long long)m->n_vert, m->valid);
+    ALP_HIP(hipGetLastError());
+    ALP_HIP(hipStreamSynchronize(st));
+    return ALP_OK;
+}
+
+// alp_mesh_create, explicit index array that is not the full grid: is it the grid with triangles removed
+// such that a vertex mask says which (see subgrid_mark_kernel)?  On success the mesh becomes an implicit
+// grid with that mask; on any mismatch it stays what it was.  `first` = the array's first triangle.
+int try_subgrid(alp_mesh *m, const long long first[3]) {
+    const long long a = first[0], b = first[1], c = first[2];
+    const long long gw = c == a + 1 ? b - a - 1 : b - a;
+    if (a < 0 || gw < 2 || m->n_vert % gw) return ALP_OK;
+    const long long gh = m->n_vert / gw;
+    if (gh < 2) return ALP_OK;
+    const long long full = 2 * (gh - 1) * (gw - 1);
+    // a small part of a large grid is cheaper as the index array it is
+    if (m->n_tri >= full || m->n_tri * 4 < full) return ALP_OK;
+    hipStream_t st = ctx().stream;
+    const long long words = (full + 31) / 32, blocks = (words + 255) / 256;
+    unsigned *block_dev = nullptr;
+    auto giveup = [&](int code) {
+        for (void *p : {(void *)m->valid_derived, (void *)m->tri_present, (void *)m->tri_rank, (void *)block_dev})
+            if (p) hipFree(p);
+        m->valid_derived = nullptr;
+        m->tri_present = m->tri_rank = nullptr;
+        return code;
+    };
+    if (hipMalloc((void **)&m->valid_derived, (size_t)m->n_vert) != hipSuccess ||
+        hipMalloc((void **)&m->tri_present, (size_t)words * 4) != hipSuccess ||
+        hipMalloc((void **)&m->tri_rank, (size_t)words * 4) != hipSuccess ||
+        hipMalloc((void **)&block_dev, (size_t)blocks * 4) != hipSuccess)
+        return giveup(fail(ALP_EHIP, "sub-grid check: hipMalloc"));
+    hipError_t e = hipMemsetAsync(m->valid_derived, 0, (size_t)m->n_vert, st);
+    if (e == hipSuccess) e = hipMemsetAsync(m->tri_present, 0, (size_t)words * 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(m->qcount_dev, 0, sizeof(unsigned), st);
+    if (e != hipSuccess) return giveup(fail(ALP_EHIP, "sub-grid check: memset"));
+    hipLaunchKernelGGL(subgrid_mark_kernel, dim3(ctx().cu_count * 8), dim3(256), 0, st, m->ind, (long long)m->n_tri, gw, gh,
+                       m->tri_present, m->valid_derived, m->qcount_dev);
+    hipLaunchKernelGGL(subgrid_absent_kernel, dim3(ctx().cu_count * 8), dim3(256), 0, st, full, gw, m->tri_present,
+                       m->valid_derived, m->qcount_dev);
+    hipLaunchKernelGGL(subgrid_blocksum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, m->tri_present, words, block_dev);
+    std::vector<unsigned> sums((size_t)blocks);
+    e = hipMemcpyAsync(m->qcount_host, m->qcount_dev, sizeof(unsigned), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(sums.data(), block_dev, (size_t)blocks * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return giveup(fail(ALP_EHIP, "sub-grid check: %s", hipGetErrorString(e)));
+    if (*m->qcount_host != 0) return giveup(ALP_OK);                       // not a filtered grid: keep the index array
+    unsigned long long run = 0;
+    for (auto &s : sums) {
+        const unsigned here = s;
+        s = (unsigned)run;
+        run += here;
+    }
+    if ((long long)run != m->n_tri) return giveup(ALP_OK);                  // cannot happen after the order check; be safe
+    e = hipMemcpyAsync(block_dev, sums.data(), (size_t)blocks * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(subgrid_rank_kernel, dim3((unsigned)blocks), dim3(256), 0, st, m->tri_present, words, block_dev,
+                           m->tri_rank);
+        e = hipStreamSynchronize(st);
+    }
+    if (e != hipSuccess) return giveup(fail(ALP_EHIP, "sub-grid ranks: %s", hipGetErrorString(e)));
+    hipFree(block_dev);
+    block_dev = nullptr;
+    if (int rc = apply_derived_mask(m, nullptr)) return giveup(rc);
+    hipFree(m->ind);
+    m->ind = nullptr;
+    m->implicit = true;
+    m->grid_h = gh;
+    m->grid_w = gw;
+    m->n_tri = full;
     return ALP_OK;
 }
 
@@ -2205,6 +2382,13 @@ int alp_mesh_create(const float *vert, const float *value, int64_t n_vert, const
             }
         }
     }
+    // ... and when they were (surface.py:203-205), the grid with a vertex mask
+    if (!implicit && !m->implicit && n_tri >= 1 && !getenv("ALP_NO_GRID_DETECT")) {
+        long long first[3];
+        for (int k = 0; k < 3; ++k)
+            first[k] = ind_dtype == ALP_I32 ? (long long)((const int *)ind)[k] : ((const long long *)ind)[k];
+        if ((rc = try_subgrid(m, first))) return bail(rc);
+    }
     *out = m;
     return ALP_OK;
 }
@@ -2212,7 +2396,8 @@ int alp_mesh_create(const float *vert, const float *value, int64_t n_vert, const
 int alp_mesh_destroy(alp_mesh_t *m) {
     if (!m) return ALP_OK;
     if (ctx().ready) hipStreamSynchronize(ctx().stream);
-    for (void *p : {(void *)m->vert, (void *)m->value, (void *)m->ind, (void *)m->valid, (void *)m->vis, (void *)m->image,
+    for (void *p : {(void *)m->vert, (void *)m->value, (void *)m->ind, (void *)m->valid, (void *)m->valid_derived,
+                    (void *)m->tri_present, (void *)m->tri_rank, (void *)m->vis, (void *)m->image,
                     (void *)m->queue, (void *)m->gqueue, (void *)m->qcount_dev, (void *)m->compact_counts, (void *)m->compact_offsets,
                     (void *)m->tile_bounds, (void *)m->tile_lists, (void *)m->hiz, (void *)m->park_small, (void *)m->park_cell})
         if (p) hipFree(p);
@@ -2248,7 +2433,17 @@ int alp_render_fetch_visibility(alp_mesh_t *m, uint64_t *out) {
     ALP_REQUIRE(m && out, "NULL argument");
     if (!m->rendered) return fail(ALP_ESTATE, "alp_render_fetch_visibility: nothing rendered yet");
     if (int e = finish_frame(m)) return e;
-    ALP_HIP(hipMemcpyAsync(out, m->vis, (size_t)m->w * m->h * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx().stream));
+    const unsigned long long *src = m->vis;
+    if (m->tri_present) {                    // filtered grid: the caller's triangle numbering
+        const long long npix = (long long)m->w * m->h;
+        unsigned long long *tr = nullptr;
+        if (int rc = scratch_reserve((size_t)npix * sizeof(uint64_t), (void **)&tr)) return rc;
+        hipLaunchKernelGGL(vis_translate_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx().stream, m->vis, npix,
+                           m->tri_present, m->tri_rank, tr);
+        ALP_HIP(hipGetLastError());
+        src = tr;
+    }
+    ALP_HIP(hipMemcpyAsync(out, src, (size_t)m->w * m->h * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx().stream));
     ALP_HIP(hipStreamSynchronize(ctx().stream));
     return ALP_OK;
 }

@@ -47,6 +47,12 @@ struct alp_mesh {
     float *vert = nullptr, *value = nullptr;
     int *ind = nullptr;
     unsigned char *valid = nullptr;    // optional, per vertex: 0 = nodata, its triangles are not drawn
+    // A filtered index array of the regular grid (surface.py:203-205: the triangles of nodata vertices removed)
+    // recognised at creation: rendered as the implicit grid with the vertex mask it implies; these map the
+    // grid's triangle ids back to positions in the caller's array (alp_render_fetch_visibility)
+    unsigned char *valid_derived = nullptr;   // the mask implied by the index array (valid = derived AND the caller's)
+    unsigned *tri_present = nullptr;          // bit per grid triangle: present in the caller's array
+    unsigned *tri_rank = nullptr;             // per 32-bit word of tri_present: number of present triangles before it
     float *tile_bounds = nullptr;      // implicit grid: bounding box (centre, half extent) per raster_grid_kernel tile
     unsigned *tile_lists = nullptr;    // implicit grid: near / far / surviving-far tile ids of the current frame + counters
     unsigned *hiz = nullptr;           // depth pyramid of the current frame size (levels 8 .. 256 px)
@@ -88,4 +94,6 @@ int ensure_park(alp_mesh *m, unsigned cap_small, unsigned cap_large, unsigned ca
 constexpr int QC_STRIDE = 8;           // counters per round
 constexpr int QC_TOTAL = 2 * QC_STRIDE + 4;
 unsigned initial_queue_cap();
+// valid = (mask implied by a filtered grid index array) AND `user` (host, n_vert bytes; NULL = all ones)
+int apply_derived_mask(alp_mesh *m, const unsigned char *user);
 }  // namespace alp

@@ -404,11 +404,23 @@ def main():
         variants = [("implicit_grid", False)]
         if not args.no_raster_explicit:
             variants.append(("int32_indices", True))
+            variants.append(("nodata_filtered_indices", True))
         for name, explicit in variants:
             ind = None
-            if explicit:     # time the index-array kernel itself (a full regular grid would be recognised)
+            if name == "int32_indices":     # time the index-array kernel itself (a full regular grid would be recognised)
                 os.environ["ALP_NO_GRID_DETECT"] = "1"
                 ind = syn.grid_indices(n_side, np.int32)
+            elif explicit:   # what get_colored_surface returns for a DSM with nodata (surface.py:203-205): 0.5 % of the
+                ind = syn.grid_indices(n_side, np.int32)   # vertices in 4 x 4 patches, their triangles removed
+                hole = np.zeros((n_side, n_side), dtype=bool)
+                rr = np.random.default_rng(5).integers(0, n_side - 4, (n_total // 3200, 2))
+                for dy in range(4):
+                    for dx in range(4):
+                        hole[rr[:, 0] + dy, rr[:, 1] + dx] = True
+                hole = hole.ravel()
+                keep = ~(hole[ind[:, 0]] | hole[ind[:, 1]] | hole[ind[:, 2]])
+                ind = ind[keep]
+                del hole, keep
             t_mesh = time.perf_counter()
             mesh = L.Mesh(surf["vert"], None, ind, grid=None if explicit else (n_side, n_side))
             mesh.render_enqueue(pv_cam, surf["offsets"])
@@ -419,11 +431,12 @@ def main():
             img = mesh.fetch()
             # algorithmic bytes per frame: vertices 12 B (value == vert), indices 12 B per
             # triangle when explicit, visibility 8 B written + 8 B read per pixel, 12 B per pixel out
-            alg = n_total * 12 + (n_tri * 12 if explicit else 0) + W * H * (16 + 12)
+            n_tri_v = n_tri if ind is None else len(ind)
+            alg = n_total * 12 + (n_tri_v * 12 if name == "int32_indices" else 0) + W * H * (16 + 12)
             tr, tr_src = pmc_traffic("raster_" + name)
             out["raster"][name] = {
                 "ms_per_frame": wall_r / k_r * 1e3, "device_ms_per_frame": dev_r / k_r,
-                "gvertices_per_s": n_total / (wall_r / k_r) / 1e9, "frames_timed": k_r,
+                "gvertices_per_s": n_total / (wall_r / k_r) / 1e9, "frames_timed": k_r, "triangles": n_tri_v,
                 "covered_fraction": float((img[:, :, 0] > 0).mean()),
                 "upload_inclusive_ms_first_frame": t_mesh * 1e3,
                 "roofline": {"bound": "hbm", "achieved": alg / (dev_r / k_r / 1e3) / 1e9, "peak": HBM_PEAK / 1e9,

@@ -194,6 +194,10 @@ int alp_loss_uv(const double *observed, const double *projected, int64_t n, int 
  * ind    n_tri x 3 indices (ind_dtype ALP_I32 or ALP_I64), or NULL for the implicit
  *        regular grid of src/alproj/surface.py:194-201 with grid_h x grid_w vertices
  *        (n_vert == grid_h * grid_w; vertex id = row * grid_w + col).
+ *        An index array that IS that grid, or that grid with the triangles of nodata
+ *        vertices removed (src/alproj/surface.py:203-205, order kept), is recognised on the
+ *        device and rendered by the grid kernels (same result, no 12 B/triangle index reads);
+ *        triangle ids reported by alp_render_fetch_visibility stay positions in `ind`.
  */
 typedef struct alp_mesh alp_mesh_t;
 

@@ -201,3 +201,83 @@ def test_get_colored_surface_io_branch_with_stand_in_rasterio(L, name, monkeypat
     np.testing.assert_array_equal(vert, G[f"{name}_vert"].astype(np.float32))
     np.testing.assert_array_equal(col, G[f"{name}_col"].astype(np.float32))
     np.testing.assert_array_equal(valid, ~nodata.ravel())
+
+
+def _filtered_case(n=96, holes=0.04, seed=5):
+    s = syn.surface(n)
+    rng = np.random.default_rng(seed)
+    vvalid = rng.random(n * n) > holes
+    vvalid[: 3 * n] &= rng.random(3 * n) > 0.5                   # a ragged first rows: the first kept triangle varies
+    full = syn.grid_indices(n)
+    kept = full[vvalid[full].all(axis=1)]
+    p = syn.base_params(n)
+    p.update(w=320, h=200, cx=160.0, cy=100.0, tilt=-20.0, z=p["z"] + 30, k1=-0.05, p2=1e-3)
+    return s, vvalid, full, kept, p
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.int64])
+def test_filtered_grid_index_array_is_recognised(L, dtype):
+    """The index array get_colored_surface returns for a DSM with nodata (surface.py:203-205) is the grid
+    with triangles removed: it is rendered by the implicit-grid kernels under the vertex mask it implies,
+    and the triangle ids handed back are positions in the caller's array."""
+    s, vvalid, full, kept, p = _filtered_case()
+    ref = orast.visibility(s["vert"], kept, p, s["offsets"])
+    derived = np.zeros(len(vvalid), dtype=bool)
+    derived[kept.ravel()] = True
+    with L.Mesh(s["vert"], None, kept.astype(dtype)) as m:
+        assert (m.fetch_arrays()[2] == derived).all() and not derived.all()      # the mask exists: recognised
+        m.render_enqueue(L.params_vector(p), s["offsets"])
+        np.testing.assert_array_equal(m.fetch_visibility(), ref)
+        # a caller's mask on top narrows it; None brings the array's own mask back
+        rng = np.random.default_rng(8)
+        user = rng.random(len(vvalid)) > 0.03
+        m.set_valid(user)
+        m.render_enqueue(L.params_vector(p), s["offsets"])
+        sub = np.flatnonzero(user[kept].all(axis=1))
+        ovis = orast.visibility(s["vert"], kept[sub], p, s["offsets"])
+        vis = m.fetch_visibility()
+        hit = ovis != 0
+        np.testing.assert_array_equal(vis != 0, hit)
+        np.testing.assert_array_equal(vis[hit] >> np.uint64(32), ovis[hit] >> np.uint64(32))
+        np.testing.assert_array_equal(0xFFFFFFFF - (vis[hit] & np.uint64(0xFFFFFFFF)).astype(np.int64),
+                                      sub[0xFFFFFFFF - (ovis[hit] & np.uint64(0xFFFFFFFF)).astype(np.int64)])
+        m.set_valid(None)
+        m.render_enqueue(L.params_vector(p), s["offsets"])
+        np.testing.assert_array_equal(m.fetch_visibility(), ref)
+    assert (ref != 0).mean() > 0.3
+
+
+def test_filtered_grid_image_equals_index_kernels(L, monkeypatch):
+    from alproj_amd import project as prj
+    s, vvalid, full, kept, p = _filtered_case(n=128, seed=11)
+    col = syn.colors(len(s["vert"]))
+    exp = orast.render(s["vert"], col, kept, p, s["offsets"], 20.0)
+    got = prj.persp_proj(s["vert"], col, kept, p, s["offsets"], 20.0)
+    np.testing.assert_array_equal(got, exp)
+    monkeypatch.setenv("ALP_NO_GRID_DETECT", "1")
+    np.testing.assert_array_equal(prj.persp_proj(s["vert"], col, kept, p, s["offsets"], 20.0), exp)
+
+
+@pytest.mark.parametrize("case", ["no_mask_explains_it", "shuffled", "duplicate", "flipped", "foreign_triangle", "sparse"])
+def test_index_arrays_that_are_not_a_filtered_grid_stay_explicit(L, case):
+    s, vvalid, full, kept, p = _filtered_case()
+    rng = np.random.default_rng(2)
+    if case == "no_mask_explains_it":        # one triangle dropped whose vertices all stay in use
+        ind = np.delete(kept, len(kept) // 2, axis=0)
+    elif case == "shuffled":
+        ind = kept[rng.permutation(len(kept))]
+    elif case == "duplicate":
+        ind = np.insert(kept, 100, kept[100], axis=0)
+    elif case == "flipped":                  # same triangle, other winding / vertex order
+        ind = kept.copy()
+        ind[777] = ind[777][[0, 2, 1]]
+    elif case == "foreign_triangle":
+        ind = kept.copy()
+        ind[500] = [0, 5, 4000]
+    else:                                    # a small part of the grid: cheaper as the array it is
+        ind = kept[: len(full) // 5]
+    ref = orast.visibility(s["vert"], ind, p, s["offsets"])
+    with L.Mesh(s["vert"], None, ind) as m:
+        assert m.fetch_arrays()[2].all()                                          # no mask: not converted
+        m.render_enqueue(L.params_vector(p), s["offsets"])
+        np.testing.assert_array_equal(m.fetch_visibility(), ref)
