@@ -242,6 +242,9 @@ def main():
     t_up = time.perf_counter()
     pts = L.Points(xyz_l, origin, args.precision)
     t_up = time.perf_counter() - t_up              # host -> device upload of the vertex array (not in `value`)
+    t_up2 = time.perf_counter()                    # ... and once more: the first large copy of a process pays the
+    L.Points(xyz_l, origin, args.precision).close()   # runtime's one-off set-up of its pageable-memory path
+    t_up2 = time.perf_counter() - t_up2
     t_gen = time.perf_counter() - t_gen
     pv_truth = L.params_vector(truth)
 
@@ -291,7 +294,8 @@ def main():
         # the communicator the library itself reports (ncclCommInitRank succeeded on every rank)
         "rccl": {"rank": comm_rank, "nranks": comm_world},
         # SURVEY 8(d) c2 asks for the end-to-end figure beside the kernel figure; it is never `value`
-        "pcie_inclusive": {"upload_s": t_up, "fetch_uv_s": t_fetch,
+        "pcie_inclusive": {"upload_s": t_up, "upload_s_second_time": t_up2,
+                           "upload_gb_per_s_second_time": xyz_l.nbytes / t_up2 / 1e9, "fetch_uv_s": t_fetch,
                            "gpoints_per_s_one_pass_incl_upload_and_fetch":
                                n_local / (t_up + ms_per_step / 1e3 + t_fetch) / 1e9},
     }
