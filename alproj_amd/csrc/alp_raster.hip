@@ -41,6 +41,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace alp {
@@ -109,7 +110,7 @@ __device__ unsigned long long g_wgtime[8 * 131072];
 #define WGT(k) ((void)0)
 #endif
 #ifdef ALP_RASTER_STATS     // development build: fragment / request census printed after every frame
-__device__ unsigned long long g_rstat[24];
+__device__ unsigned long long g_rstat[24 + 8 * 8];
 
 #define RSTAT(k, n) atomicAdd(&g_rstat[k], (unsigned long long)(n))
 #else
@@ -1181,6 +1182,16 @@ __global__ __launch_bounds__(256) void tile_occlusion_kernel(const float *__rest
 #ifndef GRID_WAVES_PER_EU
 #define GRID_WAVES_PER_EU 8
 #endif
+#ifndef PATCH_MIN_FAST
+#define PATCH_MIN_FAST 64   // tiles with fewer FAST cells send their fragments straight to the visibility buffer
+#endif
+#ifndef PATCH_WORDS_NEAR
+#define PATCH_WORDS_NEAR 4096       // LDS patch of the first round's workgroups (8 bytes per pixel)
+#endif
+#ifndef PATCH_WORDS_FAR
+#define PATCH_WORDS_FAR 0           // ... and of the second round's: none.  Its fragments are sparse (0.3 per cell) and the round is not
+                                    // request-bound; 512 / 1024 words cost 20 / 30 us of occupancy (100 M-vertex frame)
+#endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRID_WAVES_PER_EU)))
 void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__restrict__ valid, int gh, int gw, View v,
                         unsigned long long *__restrict__ vis, unsigned *__restrict__ gqueue,
@@ -1188,7 +1199,7 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
                         const unsigned *__restrict__ tile_list, const unsigned *__restrict__ tile_count,
                         Deferred *__restrict__ park_small, Deferred *__restrict__ park_large,
                         ParkedCell *__restrict__ park_cell, unsigned *__restrict__ park_counts, unsigned park_cap_small,
-                        unsigned park_cap_large, unsigned park_cap_cell) {
+                        unsigned park_cap_large, unsigned park_cap_cell, int patch_cap) {
     // s_xy[].x of a vertex without window coordinates: behind the near plane / outside the
     // fixed-point range / masked out (nodata: its triangles do not exist, surface.py:203-205)
     constexpr int BEHIND = INT_MIN, RANGE = INT_MIN + 1, NODATA = INT_MIN + 2;
@@ -1200,6 +1211,9 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
     // triangles, so 2 * GT_NC entries always suffice)
     __shared__ unsigned short s_park[2 * GT_NC];
     __shared__ unsigned s_nfast, s_nslow, s_npark[3], s_park_base[3];
+    // the tile's depth patch (dynamic LDS, patch_cap words): see phase 3
+    extern __shared__ unsigned long long s_patch[];
+    __shared__ int s_wbb[4][4];
     // ---- phase 0: this workgroup's tile (the frame plan dropped, deferred or culled the others)
     // Workgroups are handed to the 8 XCDs round-robin; each XCD has its own L2.  List position =
     // (XCD) * chunk + (turn): one XCD walks a CONTIGUOUS eighth of the list, i.e. neighbouring tiles,
@@ -1232,6 +1246,7 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
     constexpr int GT_VPT = (GT_NV + 255) / 256;
     float vx[GT_VPT], vy[GT_VPT], vz[GT_VPT];
     unsigned char vok[GT_VPT];
+    int bb_x0 = INT_MAX, bb_x1 = INT_MIN, bb_y0 = INT_MAX, bb_y1 = INT_MIN;     // snapped vertices of this thread
 #pragma unroll
     for (int k = 0; k < GT_VPT; ++k) {
         const int idx = (int)threadIdx.x + 256 * k;
@@ -1261,10 +1276,27 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
                 if (fabsf(xw) < COORD_LIMIT && fabsf(yw) < COORD_LIMIT) {
                     xy = make_int2(snap(xw), snap(yw));
                     s_iw[idx] = iw;
+                    bb_x0 = min(bb_x0, xy.x);
+                    bb_x1 = max(bb_x1, xy.x);
+                    bb_y0 = min(bb_y0, xy.y);
+                    bb_y1 = max(bb_y1, xy.y);
                 }
             }
         }
         if (idx < GT_NV) s_xy[idx] = xy;
+    }
+    if (patch_cap) {                   // the tile's footprint: per wave here, combined after the barrier
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            bb_x0 = min(bb_x0, __shfl_xor(bb_x0, m, 64));
+            bb_x1 = max(bb_x1, __shfl_xor(bb_x1, m, 64));
+            bb_y0 = min(bb_y0, __shfl_xor(bb_y0, m, 64));
+            bb_y1 = max(bb_y1, __shfl_xor(bb_y1, m, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            int *o = s_wbb[threadIdx.x >> 6];
+            o[0] = bb_x0; o[1] = bb_x1; o[2] = bb_y0; o[3] = bb_y1;
+        }
     }
     __syncthreads();
     WGT(1);
@@ -1340,6 +1372,50 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
     if (nfast + nslow == 123456) vis[0] = s_q[threadIdx.x];
     return;
 #endif
+#ifdef ALP_RASTER_STATS
+    {   // census by the tile's screen footprint: would an LDS patch of that size pay?
+        __shared__ int s_bb[4];
+        __shared__ unsigned s_boxpix[3];
+        if (threadIdx.x == 0) { s_bb[0] = INT_MAX; s_bb[1] = INT_MIN; s_bb[2] = INT_MAX; s_bb[3] = INT_MIN; s_boxpix[0] = s_boxpix[1] = s_boxpix[2] = 0; }
+        __syncthreads();
+        bool sentinel = false;
+        for (int i = threadIdx.x; i < GT_NV; i += 256) {
+            const int2 P = s_xy[i];
+            if (P.x > NODATA) { atomicMin(&s_bb[0], P.x); atomicMax(&s_bb[1], P.x); atomicMin(&s_bb[2], P.y); atomicMax(&s_bb[3], P.y); }
+            else if (P.x != BEHIND || true) sentinel |= (P.x == RANGE);
+        }
+        auto boxpix = [&](int id) {
+            int lr, lc; cell_rc(id, lr, lc);
+            const int ia = lr * GT_VW + lc;
+            const int2 P0 = s_xy[ia], P1 = s_xy[ia + GT_VW], P2 = s_xy[ia + GT_VW + 1], P3 = s_xy[ia + 1];
+            if (!(P0.x > NODATA && P1.x > NODATA && P2.x > NODATA && P3.x > NODATA)) return 0;
+            const int minx = min(min(P0.x, P1.x), min(P2.x, P3.x)), maxx = max(max(P0.x, P1.x), max(P2.x, P3.x));
+            const int miny = min(min(P0.y, P1.y), min(P2.y, P3.y)), maxy = max(max(P0.y, P1.y), max(P2.y, P3.y));
+            const int i0 = max((minx + SUB / 2 - 1) >> 8, 0), i1 = min((maxx - SUB / 2) >> 8, v.w - 1);
+            const int j0 = max((miny + SUB / 2 - 1) >> 8, 0), j1 = min((maxy - SUB / 2) >> 8, v.h - 1);
+            return (i1 >= i0 && j1 >= j0) ? (i1 - i0 + 1) * (j1 - j0 + 1) : 0;
+        };
+        for (int e = threadIdx.x; e < nfast; e += 256) atomicAdd(&s_boxpix[0], (unsigned)boxpix(s_q[e]));
+        for (int e = threadIdx.x; e < nslow; e += 256) atomicAdd(&s_boxpix[1], (unsigned)boxpix(s_q[GT_NC - 1 - e]));
+        for (int e = threadIdx.x; e < (int)ncell; e += 256) atomicAdd(&s_boxpix[2], (unsigned)boxpix(s_park[e]));
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int i0 = max((s_bb[0] + SUB / 2 - 1) >> 8, 0), i1 = min((s_bb[1] - SUB / 2) >> 8, v.w - 1);
+            const int j0 = max((s_bb[2] + SUB / 2 - 1) >> 8, 0), j1 = min((s_bb[3] - SUB / 2) >> 8, v.h - 1);
+            const long long area = (i1 >= i0 && j1 >= j0) ? (long long)(((i1 - i0 + 8) & ~7)) * (j1 - j0 + 1) : 0;
+            const int b = area <= 512 ? 0 : area <= 1024 ? 1 : area <= 2048 ? 2 : area <= 4096 ? 3 : area <= 8192 ? 4 : area <= 16384 ? 5 : area <= 65536 ? 6 : 7;
+            RSTAT(24 + 8 * b + 0, 1);
+            RSTAT(24 + 8 * b + 1, area);
+            RSTAT(24 + 8 * b + 2, nfast);
+            RSTAT(24 + 8 * b + 3, nslow);
+            RSTAT(24 + 8 * b + 4, ncell);
+            RSTAT(24 + 8 * b + 5, s_boxpix[0]);
+            RSTAT(24 + 8 * b + 6, s_boxpix[1]);
+            RSTAT(24 + 8 * b + 7, s_boxpix[2]);
+        }
+        __syncthreads();
+    }
+#endif
     if (threadIdx.x == 0) {
         RSTAT(10, 1);
         RSTAT(11, nfast);
@@ -1353,6 +1429,44 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
     // e(a->c) = -e(c->a) exactly), stepped by whole pixels -- the same integers, tie rule and depth
     // expression as emit_small.  A triangle with area <= 0 can never have all three biased values
     // >= 0, and a centre outside a triangle's own box is outside the triangle.
+    //
+    // Where the fragments go.  What bounds this stage is the chip's rate of atomic line-requests, and the
+    // fragments of FAST cells arrive one or two per request.  A tile whose footprint (the pixel centres
+    // inside the bounding box of its snapped vertices, rows of whole 8-pixel lines) fits the workgroup's
+    // LDS patch therefore collects them there with ds_max_u64 -- the same keys, and max is associative --
+    // and sends the patch to the visibility buffer afterwards: consecutive lanes = consecutive pixels,
+    // 8 fragments per request, every pixel once per tile.
+    int pI0 = 0, pJ0 = 0, pW = 0, pH = 0;
+    bool use_patch = false;
+    if (patch_cap && nfast >= PATCH_MIN_FAST) {
+        const int x0 = min(min(s_wbb[0][0], s_wbb[1][0]), min(s_wbb[2][0], s_wbb[3][0]));
+        const int x1 = max(max(s_wbb[0][1], s_wbb[1][1]), max(s_wbb[2][1], s_wbb[3][1]));
+        const int y0 = min(min(s_wbb[0][2], s_wbb[1][2]), min(s_wbb[2][2], s_wbb[3][2]));
+        const int y1 = max(max(s_wbb[0][3], s_wbb[1][3]), max(s_wbb[2][3], s_wbb[3][3]));
+        // |snapped| < COORD_LIMIT * SUB: no overflow in the roundings below
+        const int i0 = max((x0 + SUB / 2 - 1) >> 8, 0), i1 = min((x1 - SUB / 2) >> 8, v.w - 1);
+        const int j0 = max((y0 + SUB / 2 - 1) >> 8, 0), j1 = min((y1 - SUB / 2) >> 8, v.h - 1);
+        if (i1 >= i0 && j1 >= j0) {
+            pI0 = i0 & ~7;
+            pJ0 = j0;
+            pW = (i1 - pI0 + 8) & ~7;
+            pH = j1 - j0 + 1;
+            use_patch = mul24(pW, pH) <= patch_cap;      // pW, pH <= 2^15
+        }
+    }
+    const int patch_n = use_patch ? mul24(pW, pH) : 0;
+    if (use_patch) {
+        for (int k = threadIdx.x; k < patch_n; k += 256) s_patch[k] = 0ull;
+        __syncthreads();
+    }
+    auto fast_cells = [&](auto to_patch) {
+    constexpr bool PATCH = decltype(to_patch)::value;
+    auto sink = [&](int i, int j, unsigned long long key) {
+        if constexpr (PATCH)
+            __hip_atomic_fetch_max(&s_patch[mul24(j - pJ0, pW) + (i - pI0)], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else
+            vis_max(vis, v, i, j, key);
+    };
 #pragma unroll 1
     for (int e = threadIdx.x; e < nfast; e += 256) {
         const int id = s_q[e];
@@ -1400,13 +1514,13 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
                     const float q = __builtin_fmaf((float)(u[2] + bs[2]), iwc,
                                                    __builtin_fmaf((float)(u[1] + bs[1]), iwb,
                                                                   (float)(u[0] + bs[0]) * iwa)) * inv0;
-                    vis_max(vis, v, i, j, ((unsigned long long)__float_as_uint(q) << 32) | lo0);
+                    sink(i, j, ((unsigned long long)__float_as_uint(q) << 32) | lo0);
                 }
                 if ((u[3] | u[4] | u[5]) >= 0) {      // (a, c, d)
                     const float q = __builtin_fmaf((float)(u[5] + bs[5]), iwd,
                                                    __builtin_fmaf((float)(u[4] + bs[4]), iwc,
                                                                   (float)(u[3] + bs[3]) * iwa)) * inv1;
-                    vis_max(vis, v, i, j, ((unsigned long long)__float_as_uint(q) << 32) | lo1);
+                    sink(i, j, ((unsigned long long)__float_as_uint(q) << 32) | lo1);
                 }
 #pragma unroll
                 for (int k = 0; k < 6; ++k) u[k] -= ey[k] * SUB;
@@ -1414,6 +1528,23 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
 #pragma unroll
             for (int k = 0; k < 6; ++k) row[k] += ex[k] * SUB;
         }
+    }
+    };
+    if (use_patch) {
+        fast_cells(std::true_type{});
+        __syncthreads();
+        // the patch goes out row by row; a thread's next word is 256 further on
+        const int step_rows = 256 / pW, step_cols = 256 - step_rows * pW;
+        int row = (int)threadIdx.x / pW, col = (int)threadIdx.x - row * pW;
+        for (int k = threadIdx.x; k < patch_n; k += 256) {
+            const unsigned long long key = s_patch[k];
+            if (key) vis_max(vis, v, pI0 + col, pJ0 + row, key);
+            row += step_rows;
+            col += step_cols;
+            if (col >= pW) { col -= pW; ++row; }
+        }
+    } else {
+        fast_cells(std::false_type{});
     }
 #if defined(GRID_STOP_AFTER) && GRID_STOP_AFTER == 3
     return;
@@ -2063,6 +2194,15 @@ int ensure_frame(alp_mesh *m, int w, int h) {
     return ALP_OK;
 }
 
+// development: ALP_PATCH_NEAR / ALP_PATCH_FAR override the patch sizes (words; 0 switches the patches off)
+static int patch_words_env(const char *name, int dflt) {
+    if (const char *e = getenv(name)) {
+        const long w = atol(e);
+        if (w >= 0 && w <= 5632) return (int)w;
+    }
+    return dflt;
+}
+
 // Enqueue one whole frame on the library stream, no host round trip: clear, raster passes (the
 // queue lengths stay on the device), resolve.  The two queue counters are copied to pinned host
 // memory at the end; finish_frame() checks them before anything reads the frame.
@@ -2130,10 +2270,13 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
             ALP_HIP(hipGetLastError());
             // first round: the near tiles (the occluders).  One workgroup per possible list entry; the
             // ones beyond the list's length leave at once.
-            hipLaunchKernelGGL(raster_grid_kernel, dim3(grid_wgs), dim3(256), 0, st, m->vert, m->valid,
+            // LDS depth patches (words of 8 bytes; 0 = none).  Static LDS of the kernel is 19 KB: 64 KB per workgroup in all.
+            static const int patch_near = patch_words_env("ALP_PATCH_NEAR", PATCH_WORDS_NEAR),
+                             patch_far = patch_words_env("ALP_PATCH_FAR", PATCH_WORDS_FAR);
+            hipLaunchKernelGGL(raster_grid_kernel, dim3(grid_wgs), dim3(256), (size_t)patch_near * 8, st, m->vert, m->valid,
                                (int)m->grid_h, (int)m->grid_w, v, m->vis, m->gqueue, fcount + 1, m->gcap,
                                along_rows, near_list, counts + 0, m->park_small, m->park_large, m->park_cell,
-                               fcount + 2, m->park_cap[0], m->park_cap[1], m->park_cap[2]);
+                               fcount + 2, m->park_cap[0], m->park_cap[1], m->park_cap[2], patch_near);
             ALP_HIP(hipGetLastError());
 #ifdef ALP_WG_TIMING
             {   // duration of every workgroup of the first round
@@ -2185,11 +2328,11 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
                 hipLaunchKernelGGL(tile_occlusion_kernel, dim3(plan_grid), dim3(256), 0, st, m->tile_bounds, cull, far_list,
                                    counts, dm, m->hiz, second_list, counts + 2);
                 ALP_HIP(hipGetLastError());
-                hipLaunchKernelGGL(raster_grid_kernel, dim3(grid_wgs), dim3(256), 0, st, m->vert, m->valid,
+                hipLaunchKernelGGL(raster_grid_kernel, dim3(grid_wgs), dim3(256), (size_t)patch_far * 8, st, m->vert, m->valid,
                                    (int)m->grid_h, (int)m->grid_w, v, m->vis, m->gqueue, fcount + QC_STRIDE + 1, m->gcap,
                                    along_rows, second_list, counts + 2, m->park_small + m->park_cap[0],
                                    m->park_large + m->park_cap[1], m->park_cell + m->park_cap[2], fcount + QC_STRIDE + 2,
-                                   m->park_cap_b[0], m->park_cap_b[1], m->park_cap_b[2]);
+                                   m->park_cap_b[0], m->park_cap_b[1], m->park_cap_b[2], patch_far);
                 ALP_HIP(hipGetLastError());
                 if (int e = drain_rare(1)) return e;
                 if (int e = drain_parked(1)) return e;
@@ -2236,12 +2379,17 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
     m->unchecked = m->n_tri > 0;
 #ifdef ALP_RASTER_STATS
     {
-        unsigned long long hs[24], zero[24] = {0};
+        unsigned long long hs[24 + 64], zero[24 + 64] = {0};
         ALP_HIP(hipStreamSynchronize(st));
         ALP_HIP(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_rstat), sizeof(hs)));
         ALP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rstat), zero, sizeof(zero)));
         fprintf(stderr, "[raster stats] inline tris %llu | inline fragments by bbox width: 1px %llu, 2-3 %llu, 4-7 %llu, "
                         ">=8 %llu | coop tris %llu fragments %llu\n", hs[2], hs[3], hs[4], hs[5], hs[6], hs[8], hs[7]);
+        static const char *bn[8] = {"<=512", "<=1K", "<=2K", "<=4K", "<=8K", "<=16K", "<=64K", ">64K"};
+        for (int b = 0; b < 8; ++b)
+            fprintf(stderr, "[footprint %6s px] tiles %7llu  area %10llu  cells FAST %9llu SLOW %9llu PARKED %8llu | box centres FAST %10llu "
+                            "SLOW %10llu PARKED %10llu\n", bn[b], hs[24 + 8 * b], hs[25 + 8 * b], hs[26 + 8 * b], hs[27 + 8 * b], hs[28 + 8 * b],
+                    hs[29 + 8 * b], hs[30 + 8 * b], hs[31 + 8 * b]);
         fprintf(stderr, "[grid stats] (unused %llu) tiles drawn %llu | FAST cells %llu (wave rounds %llu) SLOW cells %llu (wave "
                         "rounds %llu)\n", hs[9], hs[10], hs[11], hs[13], hs[12], hs[14]);
     }

@@ -7,6 +7,7 @@
 // MODE 0: lane l -> consecutive words (8 lanes per 64-B line), wave base pseudo-random
 // MODE 1: lane l -> one word in each of 64 different lines of a 64-line neighbourhood
 // MODE 2: fully random words over the buffer
+// MODE 4-8: alignment and lines per instruction (the printed rate counts 64 lanes per instruction)
 // MODE 3: like 0 but only 8 lanes active per instruction (8 instructions for the same 64 words)
 template <int MODE>
 __global__ __launch_bounds__(256) void k(unsigned long long *buf, uint32_t nwords, int iters) {
@@ -20,6 +21,11 @@ __global__ __launch_bounds__(256) void k(unsigned long long *buf, uint32_t nword
         if (MODE == 0) atomicMax(&buf[base + lane], key);
         if (MODE == 1) atomicMax(&buf[base + lane * 8 + (s & 7)], key);
         if (MODE == 2) { uint32_t r = (s ^ (lane * 2246822519u)) * 3266489917u; atomicMax(&buf[(r >> 3) % nwords], key); }
+        if (MODE == 4) atomicMax(&buf[(base & ~15u) + lane], key);            // 128-byte aligned
+        if (MODE == 5) atomicMax(&buf[(base & ~7u) + lane], key);             // 64-byte aligned
+        if (MODE == 6) { if (lane < 16) atomicMax(&buf[(base & ~15u) + lane], key); }   // one aligned 128-byte line per instruction
+        if (MODE == 7) { if (lane < 8) atomicMax(&buf[(base & ~7u) + lane], key); }     // one aligned 64-byte line per instruction
+        if (MODE == 8) { if (lane < 1) atomicMax(&buf[base], key); }                    // one word per instruction
         if (MODE == 3) for (int g = 0; g < 8; ++g) if ((lane >> 3) == g) atomicMax(&buf[base + lane], key);
     }
 }
@@ -44,5 +50,10 @@ int main() {
     run<1>("64 words in 64 neighbouring lines", buf, nwords);
     run<2>("64 random words", buf, nwords);
     run<3>("same 64 words, 8 lanes per instruction", buf, nwords);
+    run<4>("64 consecutive words, 128-B aligned", buf, nwords);
+    run<5>("64 consecutive words, 64-B aligned", buf, nwords);
+    run<6>("16 lanes: one aligned 128-B line (x4 = instr/s)", buf, nwords);
+    run<7>("8 lanes: one aligned 64-B line (x8 = instr/s)", buf, nwords);
+    run<8>("1 lane (x64 = instr/s)", buf, nwords);
     return 0;
 }
