@@ -1606,7 +1606,10 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
     // near tiles: 0.5 ms of same-address atomics), then every thread writes whole entries.
     __syncthreads();
     const unsigned np_small = s_npark[0], np_large = s_npark[1];
-    if (np_small + np_large + ncell == 0) return;
+    if (np_small + np_large + ncell == 0) {
+        WGT(4);
+        return;
+    }
     if (threadIdx.x < 3) {
         const unsigned cnt = threadIdx.x == 0 ? np_small : (threadIdx.x == 1 ? np_large : ncell);
         s_park_base[threadIdx.x] = cnt ? atomicAdd(park_counts + threadIdx.x, cnt) : 0u;
@@ -1732,7 +1735,10 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float *__restrict__ 
                                                       const int *__restrict__ ind, long long gw, View v,
                                                       RemapCoef rc, int identity_remap, double min_distance,
                                                       const unsigned long long *__restrict__ vis,
-                                                      float *__restrict__ out) {
+                                                      float *__restrict__ out, const unsigned *__restrict__ frame_counts,
+                                                      unsigned *__restrict__ host_counts) {
+    // the frame's queue counters go to pinned host memory for finish_frame (a copy node of its own costs 5 us)
+    if (host_counts && blockIdx.x == 0 && threadIdx.x < 2 * QC_STRIDE) host_counts[threadIdx.x] = frame_counts[threadIdx.x];
     const long long npix = (long long)v.w * v.h;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += stride) {
@@ -2358,7 +2364,6 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
             ALP_HIP(hipGetLastError());
             if (int e = drain_rare(0)) return e;
         }
-        ALP_HIP(hipMemcpyAsync(m->qcount_host, fcount, 2 * QC_STRIDE * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     }
     const long long npix = (long long)v.w * v.h;
     const long long want = (npix + 255) / 256;
@@ -2371,7 +2376,8 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
                          rc.c0 > 0 && rc.c1 > 0;
     hipLaunchKernelGGL((resolve_kernel<IMPLICIT>), dim3(grid), dim3(256), 0, st, m->vert,
                        m->coords_as_value ? nullptr : m->value, m->ind,
-                       (long long)m->grid_w, v, rc, identity, min_distance, m->vis, m->image);
+                       (long long)m->grid_w, v, rc, identity, min_distance, m->vis, m->image, fcount,
+                       m->n_tri > 0 ? m->qcount_host : nullptr);
     ALP_HIP(hipGetLastError());
     m->last_v = v;
     m->last_rc = rc;
