@@ -752,9 +752,15 @@ __global__ __launch_bounds__(256) void raster_parked_kernel(View v, unsigned lon
                                                             const ParkedCell *__restrict__ cell_q,
                                                             const unsigned *__restrict__ counts, unsigned cap_small,
                                                             unsigned cap_large, unsigned cap_cell) {
+#ifndef PARKED_SKIP_CELLS       // development: the stages one by one (wrong image)
     raster_cell_body(v, vis, cell_q, counts + 2, cap_cell);
+#endif
+#ifndef PARKED_SKIP_COOP
     raster_coop_body(v, vis, large_q, counts + 1, cap_large);
+#endif
+#ifndef PARKED_SKIP_COOP4
     raster_coop4_body(v, vis, small_q, counts + 0, cap_small);
+#endif
 }
 
 // ------------------------------------------------------------------ kernel 2: per-triangle raster
