@@ -504,7 +504,7 @@ def test_random_poses_culling_and_occlusion_stay_exact(L, seed):
             keep = np.flatnonzero(valid[full].all(axis=1))
             ind = full[keep]
         for k in range(5):
-            w, h = [(160, 120), (96, 64), (320, 200), (64, 200), (240, 90)][k]
+            w, h = [(160, 120), (97, 64), (333, 200), (64, 200), (243, 90)][k]      # widths off the 8-pixel lines too (LDS patches)
             kind = rng.integers(0, 4)
             if kind == 0:      # beside the surface looking across it
                 cam = dict(x=-rng.uniform(5, 300), y=rng.uniform(0, gh), z=float(z.max() - z.min()) + rng.uniform(-40, 80), pan=rng.uniform(60, 120))
