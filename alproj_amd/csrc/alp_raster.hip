@@ -13,18 +13,26 @@
 //   project.py:111-143  distort(): inverted-coefficient source map, nearest gather, 0 border
 //                                                                         -> remap_source()
 //
-// Pipeline (all on the library stream):
-//   1. clear the 64-bit visibility buffer (one word per pixel: float32 1/vz << 32 | ~triangle id)
+// Pipeline (all on the library stream, no host round trip; DESIGN.md section 5 has the launch table):
+//   1. clear the 64-bit visibility buffer (one word per pixel: float32 1/vz << 32 | ~triangle id) and the
+//      frame's queue / list counters behind it
 //   2. coverage, one of
-//      raster_grid_kernel  regular-grid meshes (no index array, or an index array recognised
-//                          as the full grid at mesh creation): one workgroup per tile of 32x8
-//                          cells, vertices transformed/projected/snapped once into LDS, one
-//                          lane per cell = two triangles;
-//      raster_kernel       any index array: one thread per triangle, three gathered vertices;
-//      both end in emit_snapped(): 32-bit bounding-box rejection and back-face test, then an
-//      inline walk of the bounding box with exact integer edge functions (64-bit atomicMax per
-//      covered pixel centre) for triangles under 64 px; larger ones are split into 64x64-pixel
-//      work items appended to a device queue
+//      regular-grid meshes (no index array, or an index array recognised at mesh creation as the grid or
+//      as the grid minus the triangles of masked vertices):
+//        tile_plan_kernel        tiles of 64x16 cells: frustum culling, NEAR / FAR lists
+//        raster_grid_kernel      first round, NEAR tiles: one workgroup per tile, vertices transformed /
+//                                projected / snapped once into LDS, one lane per cell = two triangles;
+//                                fragments of small cells through an LDS depth patch where the tile's
+//                                footprint fits one, larger cells and triangles parked in device queues
+//        raster_parked_kernel    the parked cells (a wave per cell) and triangles (a wave per triangle)
+//        hiz_build / hiz_top / tile_occlusion_kernel   depth pyramid, occlusion test of the FAR tiles
+//        raster_grid_kernel, raster_parked_kernel      second round: the surviving FAR tiles
+//      any other index array:
+//        raster_kernel           one thread per triangle, three gathered vertices
+//      all of them use emit_small(): 32-bit bounding-box rejection and back-face test, then an inline walk of
+//      the bounding box with exact integer edge functions (64-bit atomicMax per covered pixel centre) for
+//      triangles under 64 px; near-plane crossings and larger triangles go to raster_general_kernel, which
+//      splits them into 64x64-pixel work items
 //   3. raster_large_kernel: one wave per work item, one lane per pixel column
 //   4. resolve_kernel: one thread per OUTPUT pixel: distortion source map (float64), fetch the
 //      winning triangle, perspective-correct interpolation by ray/triangle intersection in view
