@@ -1000,11 +1000,63 @@ __device__ __forceinline__ void list_append(bool take, unsigned value, unsigned 
     __syncthreads();         // s_cnt / s_base are reused by the next call
 }
 
+// The screen rectangle of a FAR tile, for the occlusion test: the tile's bounding box is projected (its eight
+// corners lie in front of the camera: vz_min >= 2) and the rectangle widened by two pixels (float32 rounding,
+// 1/256-pixel snapping), clamped to the viewport.  false: no usable rectangle (the tile is kept untested).
+// tile_plan_kernel and tile_occlusion_kernel must see the SAME rectangle: the pyramid is only built where
+// the plan said rectangles lie.
+__device__ __forceinline__ bool far_tile_rect(const float *__restrict__ tb, const TileCull &cull, int &px0, int &px1, int &py0,
+                                              int &py1, float &zmin) {
+    const float c[3] = {tb[0] - cull.cam[0], tb[1] - cull.cam[1], tb[2] - cull.cam[2]};
+    const float e[3] = {tb[3], tb[4], tb[5]};
+    float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+    zmin = INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float d0 = c[0] + ((k & 1) ? e[0] : -e[0]), d1 = c[1] + ((k & 2) ? e[1] : -e[1]), d2 = c[2] + ((k & 4) ? e[2] : -e[2]);
+        const float vx = cull.R[0][0] * d0 + cull.R[0][1] * d1 + cull.R[0][2] * d2;
+        const float vy = cull.R[1][0] * d0 + cull.R[1][1] * d1 + cull.R[1][2] * d2;
+        const float vz = cull.R[2][0] * d0 + cull.R[2][1] * d1 + cull.R[2][2] * d2;
+        const float iz = 1.0f / vz;
+        const float xw = (cull.fx * vx * iz + 1.0f) * cull.sx, yw = (cull.fy * vy * iz + 1.0f) * cull.sy;
+        x0 = fminf(x0, xw); x1 = fmaxf(x1, xw);
+        y0 = fminf(y0, yw); y1 = fmaxf(y1, yw);
+        zmin = fminf(zmin, vz);
+    }
+    // zmin >= 2 by construction of the far list (up to rounding: re-checked, NaN gives no rectangle)
+    if (!(zmin >= 1.5f && x1 - x0 < 2048.0f && y1 - y0 < 2048.0f)) return false;
+    // pixels whose centres can be touched: [x0 - 2, x1 + 2] clamped to the viewport
+    px0 = max((int)floorf(x0 - 2.0f), 0);
+    px1 = min((int)floorf(x1 + 2.0f), cull.w - 1);
+    py0 = max((int)floorf(y0 - 2.0f), 0);
+    py1 = min((int)floorf(y1 + 2.0f), cull.h - 1);
+    return true;
+}
+
+// max over the wave, result in lane 63 (DPP inside the rows of 16 lanes, then row broadcasts)
+__device__ __forceinline__ unsigned wave_max_to_lane63(unsigned x) {
+#define ALP_STEP(CTRL, ROWS) x = max(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, ROWS, 0xf, false));
+    ALP_STEP(0xB1, 0xf)     // quad_perm [1,0,3,2]
+    ALP_STEP(0x4E, 0xf)     // quad_perm [2,3,0,1]
+    ALP_STEP(0x141, 0xf)    // row_half_mirror
+    ALP_STEP(0x140, 0xf)    // row_mirror: every lane holds its row's maximum
+    ALP_STEP(0x142, 0xa)    // row_bcast15 into rows 1 and 3
+    ALP_STEP(0x143, 0xc)    // row_bcast31 into rows 2 and 3: lane 63 holds the wave's
+#undef ALP_STEP
+    return x;
+}
+
+// `region` (four words, zero when the frame starts): the union of the FAR tiles' rectangles as maxima --
+// 65535 - first column, last column + 1, 65535 - first row, last row + 1 -- for hiz_build_kernel.
 __global__ __launch_bounds__(256) void tile_plan_kernel(const float *__restrict__ tile_bounds, unsigned n_tiles, TileCull cull,
                                                         unsigned *__restrict__ near_list, unsigned *__restrict__ far_list,
-                                                        unsigned *__restrict__ counts) {
+                                                        unsigned *__restrict__ counts, unsigned *__restrict__ region) {
+    __shared__ unsigned s_region[4];
+    if (threadIdx.x < 4) s_region[threadIdx.x] = 0u;
+    __syncthreads();
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     int kind = 0;                       // 0 dropped, 1 near, 2 far
+    unsigned reg[4] = {0u, 0u, 0u, 0u};
     if (t < n_tiles) {
         kind = 1;
         if (cull.enabled) {
@@ -1029,11 +1081,27 @@ __global__ __launch_bounds__(256) void tile_plan_kernel(const float *__restrict_
             else if (cull.occlusion) {
                 const float cell = fmaxf(2.0f * e0 / (float)GT_W, 2.0f * e2 / (float)GT_H);
                 kind = (vz_min >= 2.0f && vz_min >= cull.near_limit * cell) ? 2 : 1;
+                int px0, px1, py0, py1;
+                float zmin;
+                if (kind == 2 && far_tile_rect(tb, cull, px0, px1, py0, py1, zmin) && px0 <= px1 && py0 <= py1) {
+                    reg[0] = 65535u - (unsigned)px0;
+                    reg[1] = (unsigned)px1 + 1u;
+                    reg[2] = 65535u - (unsigned)py0;
+                    reg[3] = (unsigned)py1 + 1u;
+                }
             }
         }
     }
+    if (__ballot(reg[1] != 0u)) {          // wave-uniform
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned m = wave_max_to_lane63(reg[k]);
+            if ((threadIdx.x & 63) == 63) atomicMax(&s_region[k], m);
+        }
+    }
     list_append(kind == 1, t, near_list, counts + 0);
-    list_append(kind == 2, t, far_list, counts + 1);
+    list_append(kind == 2, t, far_list, counts + 1);     // (its barriers also order s_region)
+    if (threadIdx.x < 4 && s_region[threadIdx.x]) atomicMax(region + threadIdx.x, s_region[threadIdx.x]);
 }
 
 // ---- depth pyramid of the visibility buffer after the first round.  Level L holds, per block of
@@ -1063,10 +1131,19 @@ static long long hiz_total(int w, int h) {
 }
 
 // one workgroup per 64 x 64 pixels: levels 0..3
+// -- only where FAR tiles can look: the union of their rectangles (tile_plan_kernel), rounded outwards to the
+// 256-pixel blocks of the top level so that every texel the occlusion test can read is complete; the far
+// field is a band under the horizon, the rest of the 168 MB buffer is not read (35 -> ~8 us per 100 M-vertex frame)
 __global__ __launch_bounds__(256) void hiz_build_kernel(const unsigned long long *__restrict__ vis, int w, int h, HizDims dm,
-                                                        unsigned *__restrict__ hiz) {
+                                                        unsigned *__restrict__ hiz, const unsigned *__restrict__ region) {
     __shared__ unsigned s_min[64 + 16 + 4 + 1];
     const int rx = blockIdx.x * 64, ry = blockIdx.y * 64;
+    {
+        const unsigned r0 = region[0], r1 = region[1], r2 = region[2], r3 = region[3];
+        if (r1 == 0u || r3 == 0u) return;                              // no FAR tile has a rectangle
+        const int X0 = (int)(65535u - r0) & ~255, X1 = (int)(r1 - 1u) | 255, Y0 = (int)(65535u - r2) & ~255, Y1 = (int)(r3 - 1u) | 255;
+        if (rx + 63 < X0 || rx > X1 || ry + 63 < Y0 || ry > Y1) return;
+    }
     if (threadIdx.x < 85) s_min[threadIdx.x] = 0x7F800000u;       // +inf: no pixel of the viewport in the block yet
     __syncthreads();
     const int col = threadIdx.x & 63;
@@ -1153,27 +1230,9 @@ __global__ __launch_bounds__(256) void tile_occlusion_kernel(const float *__rest
     if (i < n) {
         t = far_list[i];
         keep = true;
-        const float *tb = tile_bounds + 6ull * t;
-        const float c[3] = {tb[0] - cull.cam[0], tb[1] - cull.cam[1], tb[2] - cull.cam[2]};
-        const float e[3] = {tb[3], tb[4], tb[5]};
-        float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY, zmin = INFINITY;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float d0 = c[0] + ((k & 1) ? e[0] : -e[0]), d1 = c[1] + ((k & 2) ? e[1] : -e[1]), d2 = c[2] + ((k & 4) ? e[2] : -e[2]);
-            const float vx = cull.R[0][0] * d0 + cull.R[0][1] * d1 + cull.R[0][2] * d2;
-            const float vy = cull.R[1][0] * d0 + cull.R[1][1] * d1 + cull.R[1][2] * d2;
-            const float vz = cull.R[2][0] * d0 + cull.R[2][1] * d1 + cull.R[2][2] * d2;
-            const float iz = 1.0f / vz;
-            const float xw = (cull.fx * vx * iz + 1.0f) * cull.sx, yw = (cull.fy * vy * iz + 1.0f) * cull.sy;
-            x0 = fminf(x0, xw); x1 = fmaxf(x1, xw);
-            y0 = fminf(y0, yw); y1 = fmaxf(y1, yw);
-            zmin = fminf(zmin, vz);
-        }
-        // zmin >= 2 by construction of the far list (up to rounding: re-checked, NaN keeps the tile)
-        if (zmin >= 1.5f && x1 - x0 < 2048.0f && y1 - y0 < 2048.0f) {
-            // pixels whose centres can be touched: [x0 - 2, x1 + 2] clamped to the viewport
-            const int px0 = max((int)floorf(x0 - 2.0f), 0), px1 = min((int)floorf(x1 + 2.0f), cull.w - 1);
-            const int py0 = max((int)floorf(y0 - 2.0f), 0), py1 = min((int)floorf(y1 + 2.0f), cull.h - 1);
+        int px0, px1, py0, py1;
+        float zmin;
+        if (far_tile_rect(tile_bounds + 6ull * t, cull, px0, px1, py0, py1, zmin)) {
             if (px0 > px1 || py0 > py1) {
                 keep = false;                       // nothing of it can reach the viewport
             } else {
@@ -2286,7 +2345,7 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
             const unsigned plan_grid = (unsigned)((tiles + 255) / 256);
             const unsigned grid_wgs = (unsigned)((tiles + 7) / 8 * 8);     // whole turns of the 8 XCDs (see the kernel's phase 0)
             hipLaunchKernelGGL(tile_plan_kernel, dim3(plan_grid), dim3(256), 0, st, m->tile_bounds, (unsigned)tiles, cull,
-                               near_list, far_list, counts);
+                               near_list, far_list, counts, counts + 4);
             ALP_HIP(hipGetLastError());
             // first round: the near tiles (the occluders).  One workgroup per possible list entry; the
             // ones beyond the list's length leave at once.
@@ -2341,7 +2400,7 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
                 // is the main occluder, three times as many far tiles survive, 1.23 instead of 1.06 ms.)
                 const HizDims dm = hiz_dims(v.w, v.h);
                 hipLaunchKernelGGL(hiz_build_kernel, dim3((unsigned)dm.w[3], (unsigned)dm.h[3]), dim3(256), 0, st, m->vis, v.w,
-                                   v.h, dm, m->hiz);
+                                   v.h, dm, m->hiz, counts + 4);
                 ALP_HIP(hipGetLastError());
                 hipLaunchKernelGGL(hiz_top_kernel, dim3((unsigned)((dm.w[5] * dm.h[5] + 255) / 256)), dim3(256), 0, st, dm, m->hiz);
                 ALP_HIP(hipGetLastError());

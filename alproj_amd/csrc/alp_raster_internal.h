@@ -92,7 +92,7 @@ int ensure_queue(alp_mesh *m, unsigned cap);
 int ensure_gqueue(alp_mesh *m, unsigned cap);
 int ensure_park(alp_mesh *m, unsigned cap_small, unsigned cap_large, unsigned cap_cell);
 constexpr int QC_STRIDE = 8;           // counters per round
-constexpr int QC_TOTAL = 2 * QC_STRIDE + 4;
+constexpr int QC_TOTAL = 2 * QC_STRIDE + 8;   // two rounds of queue counters, three tile-list counters (+1), the FAR tiles' screen region (4)
 unsigned initial_queue_cap();
 // valid = (mask implied by a filtered grid index array) AND `user` (host, n_vert bytes; NULL = all ones)
 int apply_derived_mask(alp_mesh *m, const unsigned char *user);
