@@ -1109,7 +1109,7 @@ __global__ __launch_bounds__(256) void tile_plan_kernel(const float *__restrict_
 // (0 where a pixel is still empty): whatever is drawn later with a strictly smaller 1/vz everywhere in
 // the block cannot win a single pixel there (the visibility word only grows; equal depth is not
 // "strictly smaller", so the lower-triangle-index tie rule is never pre-empted).
-constexpr int HIZ_LEVELS = 6;
+constexpr int HIZ_LEVELS = 4;       // blocks of 8, 16, 32, 64 pixels
 
 struct HizDims { int w[HIZ_LEVELS], h[HIZ_LEVELS]; long long off[HIZ_LEVELS]; };
 
@@ -1132,8 +1132,9 @@ static long long hiz_total(int w, int h) {
 
 // one workgroup per 64 x 64 pixels: levels 0..3
 // -- only where FAR tiles can look: the union of their rectangles (tile_plan_kernel), rounded outwards to the
-// 256-pixel blocks of the top level so that every texel the occlusion test can read is complete; the far
-// field is a band under the horizon, the rest of the 168 MB buffer is not read (35 -> ~8 us per 100 M-vertex frame)
+// 64-pixel blocks of the top level written here, so that every texel the occlusion test can read is complete;
+// the far field is a band under the horizon, the rest of the 168 MB buffer is not read (35 -> 13 us per
+// 100 M-vertex frame)
 __global__ __launch_bounds__(256) void hiz_build_kernel(const unsigned long long *__restrict__ vis, int w, int h, HizDims dm,
                                                         unsigned *__restrict__ hiz, const unsigned *__restrict__ region) {
     __shared__ unsigned s_min[64 + 16 + 4 + 1];
@@ -1141,7 +1142,7 @@ __global__ __launch_bounds__(256) void hiz_build_kernel(const unsigned long long
     {
         const unsigned r0 = region[0], r1 = region[1], r2 = region[2], r3 = region[3];
         if (r1 == 0u || r3 == 0u) return;                              // no FAR tile has a rectangle
-        const int X0 = (int)(65535u - r0) & ~255, X1 = (int)(r1 - 1u) | 255, Y0 = (int)(65535u - r2) & ~255, Y1 = (int)(r3 - 1u) | 255;
+        const int X0 = (int)(65535u - r0) & ~63, X1 = (int)(r1 - 1u) | 63, Y0 = (int)(65535u - r2) & ~63, Y1 = (int)(r3 - 1u) | 63;
         if (rx + 63 < X0 || rx > X1 || ry + 63 < Y0 || ry > Y1) return;
     }
     if (threadIdx.x < 85) s_min[threadIdx.x] = 0x7F800000u;       // +inf: no pixel of the viewport in the block yet
@@ -1191,28 +1192,6 @@ __global__ __launch_bounds__(256) void hiz_build_kernel(const unsigned long long
     }
 }
 
-// levels 4 and 5 from level 3: one thread per level-5 texel
-__global__ __launch_bounds__(256) void hiz_top_kernel(HizDims dm, unsigned *__restrict__ hiz) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= dm.w[5] * dm.h[5]) return;
-    const int tx = t % dm.w[5], ty = t / dm.w[5];
-    unsigned m5 = 0x7F800000u;
-    for (int j = 0; j < 2; ++j)
-        for (int i = 0; i < 2; ++i) {
-            const int x4 = 2 * tx + i, y4 = 2 * ty + j;
-            if (x4 >= dm.w[4] || y4 >= dm.h[4]) continue;
-            unsigned m4 = 0x7F800000u;
-            for (int jj = 0; jj < 2; ++jj)
-                for (int ii = 0; ii < 2; ++ii) {
-                    const int x3 = 2 * x4 + ii, y3 = 2 * y4 + jj;
-                    if (x3 < dm.w[3] && y3 < dm.h[3]) m4 = min(m4, hiz[dm.off[3] + (long long)y3 * dm.w[3] + x3]);
-                }
-            hiz[dm.off[4] + (long long)y4 * dm.w[4] + x4] = m4;
-            m5 = min(m5, m4);
-        }
-    hiz[dm.off[5] + (long long)ty * dm.w[5] + tx] = m5;
-}
-
 // ---- occlusion test of the FAR tiles, one lane per tile: the tile's bounding box is projected
 // (its eight corners lie in front of the camera: vz_min >= 2), the screen rectangle is widened by two
 // pixels (float32 rounding, 1/256-pixel snapping), and the largest 1/vz anything in the tile can reach
@@ -1237,12 +1216,16 @@ __global__ __launch_bounds__(256) void tile_occlusion_kernel(const float *__rest
                 keep = false;                       // nothing of it can reach the viewport
             } else {
                 const float qmax = (1.0f / zmin) * 1.00002f;    // >= every interpolated float32 1/vz of the tile
+                // the coarsest level that covers the rectangle with at most 2 x 2 texels; hiz_build_kernel writes
+                // levels 0..3 (8..64 pixels): a larger rectangle (rare among FAR tiles) reads up to 8 x 8 texels
+                // of level 3, and one larger still is kept untested
                 int L = 0;
-                while (L < HIZ_LEVELS && (((px1 >> (3 + L)) - (px0 >> (3 + L))) > 1 || ((py1 >> (3 + L)) - (py0 >> (3 + L))) > 1)) ++L;
-                if (L < HIZ_LEVELS) {
+                while (L < 3 && (((px1 >> (3 + L)) - (px0 >> (3 + L))) > 1 || ((py1 >> (3 + L)) - (py0 >> (3 + L))) > 1)) ++L;
+                const int tx0 = px0 >> (3 + L), tx1 = px1 >> (3 + L), ty0 = py0 >> (3 + L), ty1 = py1 >> (3 + L);
+                if (tx1 - tx0 < 8 && ty1 - ty0 < 8) {
                     unsigned m = 0x7F800000u;
-                    for (int ty = py0 >> (3 + L); ty <= (py1 >> (3 + L)); ++ty)
-                        for (int tx = px0 >> (3 + L); tx <= (px1 >> (3 + L)); ++tx)
+                    for (int ty = ty0; ty <= ty1; ++ty)
+                        for (int tx = tx0; tx <= tx1; ++tx)
                             m = min(m, hiz[dm.off[L] + (long long)ty * dm.w[L] + tx]);
                     keep = !(qmax < __uint_as_float(m));
                 }
@@ -2401,8 +2384,6 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
                 const HizDims dm = hiz_dims(v.w, v.h);
                 hipLaunchKernelGGL(hiz_build_kernel, dim3((unsigned)dm.w[3], (unsigned)dm.h[3]), dim3(256), 0, st, m->vis, v.w,
                                    v.h, dm, m->hiz, counts + 4);
-                ALP_HIP(hipGetLastError());
-                hipLaunchKernelGGL(hiz_top_kernel, dim3((unsigned)((dm.w[5] * dm.h[5] + 255) / 256)), dim3(256), 0, st, dm, m->hiz);
                 ALP_HIP(hipGetLastError());
                 hipLaunchKernelGGL(tile_occlusion_kernel, dim3(plan_grid), dim3(256), 0, st, m->tile_bounds, cull, far_list,
                                    counts, dm, m->hiz, second_list, counts + 2);
