@@ -2374,9 +2374,15 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
                 }
             }
 #endif
-            if (int e = drain_rare(0)) return e;
+            // The rare cases (near-plane crossings, triangles of 64 px and more) of BOTH rounds are drawn once, after
+            // the second round's grid kernel: its general entries follow the first round's in the same queue.  The
+            // pyramid then lacks those few triangles as occluders -- it stays conservative -- and a frame has two
+            // launches fewer.
+            const bool two_rounds = cull.enabled && cull.occlusion;
+            if (!two_rounds)
+                if (int e = drain_rare(0)) return e;
             if (int e = drain_parked(0)) return e;
-            if (cull.enabled && cull.occlusion) {
+            if (two_rounds) {
                 // depth pyramid of everything the first round drew, occlusion test of the far tiles, second round.
                 // (Measured and not kept: building the pyramid BEFORE the first round's parked cells / triangles
                 // are drawn and running the second round on a second stream next to them -- the parked geometry
@@ -2389,12 +2395,12 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
                                    counts, dm, m->hiz, second_list, counts + 2);
                 ALP_HIP(hipGetLastError());
                 hipLaunchKernelGGL(raster_grid_kernel, dim3(grid_wgs), dim3(256), (size_t)patch_far * 8, st, m->vert, m->valid,
-                                   (int)m->grid_h, (int)m->grid_w, v, m->vis, m->gqueue, fcount + QC_STRIDE + 1, m->gcap,
+                                   (int)m->grid_h, (int)m->grid_w, v, m->vis, m->gqueue, fcount + 1, m->gcap,
                                    along_rows, second_list, counts + 2, m->park_small + m->park_cap[0],
                                    m->park_large + m->park_cap[1], m->park_cell + m->park_cap[2], fcount + QC_STRIDE + 2,
                                    m->park_cap_b[0], m->park_cap_b[1], m->park_cap_b[2], patch_far);
                 ALP_HIP(hipGetLastError());
-                if (int e = drain_rare(1)) return e;
+                if (int e = drain_rare(0)) return e;
                 if (int e = drain_parked(1)) return e;
             }
 #ifdef ALP_RASTER_STATS
