@@ -1677,6 +1677,19 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
         cell_rc(id, lr, lc);
         const int ia = lr * GT_VW + lc, ib = ia + GT_VW, ic = ib + 1, idd = ia + 1;
         const int2 A = s_xy[ia], B = s_xy[ib], C = s_xy[ic], D = s_xy[idd];
+#ifdef ALP_RASTER_STATS
+        {   // census of the parked cells' boxes
+            const int minx = min(min(A.x, B.x), min(C.x, D.x)), maxx = max(max(A.x, B.x), max(C.x, D.x));
+            const int miny = min(min(A.y, B.y), min(C.y, D.y)), maxy = max(max(A.y, B.y), max(C.y, D.y));
+            const int bw = min((maxx - SUB / 2) >> 8, v.w - 1) - max((minx + SUB / 2 - 1) >> 8, 0) + 1;
+            const int bh = min((maxy - SUB / 2) >> 8, v.h - 1) - max((miny + SUB / 2 - 1) >> 8, 0) + 1;
+            RSTAT(19, bh <= 2 ? 1 : 0);
+            RSTAT(20, bh <= 4 ? 1 : 0);
+            RSTAT(21, bw <= 4 ? 1 : 0);
+            RSTAT(22, bw * bh);
+            RSTAT(23, 1);
+        }
+#endif
         ParkedCell pc;
         pc.X[0] = A.x; pc.X[1] = B.x; pc.X[2] = C.x; pc.X[3] = D.x;
         pc.Y[0] = A.y; pc.Y[1] = B.y; pc.Y[2] = C.y; pc.Y[3] = D.y;
@@ -2456,6 +2469,8 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
             fprintf(stderr, "[footprint %6s px] tiles %7llu  area %10llu  cells FAST %9llu SLOW %9llu PARKED %8llu | box centres FAST %10llu "
                             "SLOW %10llu PARKED %10llu\n", bn[b], hs[24 + 8 * b], hs[25 + 8 * b], hs[26 + 8 * b], hs[27 + 8 * b], hs[28 + 8 * b],
                     hs[29 + 8 * b], hs[30 + 8 * b], hs[31 + 8 * b]);
+        fprintf(stderr, "[parked cells] %llu: box height <= 2: %llu, <= 4: %llu; width <= 4: %llu; centres in boxes %llu\n", hs[23], hs[19], hs[20],
+                hs[21], hs[22]);
         fprintf(stderr, "[grid stats] (unused %llu) tiles drawn %llu | FAST cells %llu (wave rounds %llu) SLOW cells %llu (wave "
                         "rounds %llu)\n", hs[9], hs[10], hs[11], hs[13], hs[12], hs[14]);
     }
