@@ -167,7 +167,10 @@ def pmc_traffic(name):
     for rnd in ("r02", "r01"):
         f = os.path.join(PROFILES, f"{rnd}_{name}_pmc_traffic.json")
         if os.path.exists(f):
-            return json.load(open(f)), os.path.relpath(f, ROOT)
+            try:
+                return json.load(open(f)), os.path.relpath(f, ROOT)
+            except (OSError, ValueError):      # an unreadable summary must not stop the measurement
+                continue
     return None, None
 
 
@@ -272,7 +275,12 @@ def main():
     if args.precision == "f32":
         t_json, traffic_src = pmc_traffic("project")
         if t_json:
-            traffic = t_json["hbm_bytes_per_vertex"] * n_local
+            # either the per-vertex summary or tools/pmc_traffic.py's per-kernel table of a 100 M-vertex probe
+            per_vertex = t_json.get("hbm_bytes_per_vertex")
+            if per_vertex is None and t_json.get("kernels"):
+                k = next(iter(t_json["kernels"].values()))
+                per_vertex = k["hbm_bytes_per_frame"] / float(t_json.get("vertices_per_launch", 100_000_000))
+            traffic = per_vertex * n_local if per_vertex is not None else None
 
     out = {
         "metric": "Gpoints/s projected (pinhole + Brown-Conrady, single pose) over the 100M-vertex DSM; "
@@ -446,7 +454,7 @@ def main():
                 "roofline": {"bound": "hbm", "achieved": alg / (dev_r / k_r / 1e3) / 1e9, "peak": HBM_PEAK / 1e9,
                              "unit": "GB/s", "frac": alg / (dev_r / k_r / 1e3) / HBM_PEAK,
                              "algorithmic_bytes_per_frame": alg,
-                             "traffic": tr["hbm_bytes_per_frame"] if tr else None, "traffic_source": tr_src,
+                             "traffic": tr.get("hbm_bytes_per_frame") if tr else None, "traffic_source": tr_src,
                              # SURVEY 8(d) also counts the reference's separate remap pass (12 B read +
                              # 12 B written per pixel), which is fused away here
                              "frac_with_survey_remap_bytes": (alg + W * H * 24) / (dev_r / k_r / 1e3) / HBM_PEAK},

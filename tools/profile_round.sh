@@ -16,7 +16,18 @@ python3 tools/rocpd_summary.py gpurun_out/prof_$R/raster2/p_results.db "" --csv 
 # 3. HBM traffic (FETCH_SIZE / WRITE_SIZE passes)
 python3 tools/pmc_traffic.py gpurun_out/prof_$R/${R}_raster_implicit_grid_pmc_traffic.json 3 "raster_,resolve_,hiz_,tile_plan,tile_occ" -- python3 tools/probe_raster.py 100000000 3 > /dev/null 2>&1 </dev/null
 python3 tools/pmc_traffic.py gpurun_out/prof_$R/${R}_raster_int32_indices_pmc_traffic.json 3 "raster_,resolve_" -- python3 tools/probe_raster.py 100000000 3 explicit > /dev/null 2>&1 </dev/null
-python3 tools/pmc_traffic.py gpurun_out/prof_$R/${R}_project_pmc.json 3 "project_kernel" -- python3 tools/probe_project.py 100000000 3 f32 > /dev/null 2>&1 </dev/null
+python3 tools/pmc_traffic.py gpurun_out/prof_$R/${R}_project_pmc_kernels.json 3 "project_kernel" -- python3 tools/probe_project.py 100000000 3 f32 > /dev/null 2>&1 </dev/null
+python3 - <<PY
+import json
+d = json.load(open("gpurun_out/prof_$R/${R}_project_pmc_kernels.json"))
+k = d["kernels"]["alp::project_kernel<float>"]
+json.dump({"kernel": "project_kernel<float>", "vertices_per_launch": 100000000,
+           "fetch_bytes_per_launch_x2_corrected": k["fetch_bytes_per_frame_x2_corrected"],
+           "write_bytes_per_launch": k["write_bytes_per_frame"], "correction": d["correction"],
+           "hbm_bytes_per_launch": k["hbm_bytes_per_frame"], "hbm_bytes_per_vertex": k["hbm_bytes_per_frame"] / 1e8,
+           "algorithmic_bytes_per_vertex": 20, "command": d["command"]},
+          open("gpurun_out/prof_$R/${R}_project_pmc_traffic.json", "w"), indent=1)
+PY
 # 4. the frame timeline
 tools/probe_frame.sh ${R}_final 100000000 > gpurun_out/prof_$R/${R}_raster_frame_timeline.txt 2>&1
 ls gpurun_out/prof_$R
