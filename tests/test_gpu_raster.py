@@ -536,3 +536,57 @@ def test_random_poses_culling_and_occlusion_stay_exact(L, seed):
                 np.testing.assert_array_equal(m.fetch_visibility(), got)
             finally:
                 os.environ.pop("ALP_NO_TILE_CULL", None)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_mid_field_frames_with_depth_patches_stay_exact(L, seed):
+    """Frames in which a cell is 0.5 ... 8 pixels and a tile of 64 x 16 cells has a footprint of 1 000 ... 30 000
+    pixels: the first-round tiles that collect their fragments in an LDS depth patch, those that do not fit one,
+    parked cells and parked triangles next to each other.  Every visibility word against the frozen oracle,
+    with the patches on, and the same frame with the culling switched off."""
+    import os
+    rng = np.random.default_rng(500 + seed)
+    gh, gw = 420, 610
+    yy, xx = np.mgrid[0:gh, 0:gw].astype(np.float64)
+    z = 40 * np.sin(xx / 70.0 + seed) * np.cos(yy / 55.0) + 6 * np.sin(xx / 5.0) * np.sin(yy / 6.0) + rng.normal(0, 0.25, (gh, gw))
+    vert = np.stack([xx.ravel(), (z - z.min()).ravel(), (gh - 1 - yy).ravel()], 1).astype(np.float32)      # X, Z(up), Y
+    w, h = [(640, 427), (901, 600), (1111, 733), (512, 512), (777, 333), (640, 427), (1280, 200), (333, 777)][seed]
+    side = seed % 4
+    height = float(z.max() - z.min())
+    if side == 0:
+        cam = dict(x=-rng.uniform(20, 200), y=rng.uniform(0.2, 0.8) * gh, z=height + rng.uniform(5, 120), pan=rng.uniform(75, 105))
+    elif side == 1:
+        cam = dict(x=gw + rng.uniform(20, 200), y=rng.uniform(0.2, 0.8) * gh, z=height + rng.uniform(5, 120), pan=rng.uniform(255, 285))
+    elif side == 2:
+        cam = dict(x=rng.uniform(0.2, 0.8) * gw, y=-rng.uniform(20, 200), z=height + rng.uniform(5, 120), pan=rng.uniform(-15, 15) % 360)
+    else:
+        cam = dict(x=rng.uniform(0.3, 0.7) * gw, y=rng.uniform(0.3, 0.7) * gh, z=height + rng.uniform(60, 250), pan=rng.uniform(0, 360))
+    p = dict(orc.vector_to_params(np.zeros(25)), a1=1.0, a2=1.0, fov=rng.uniform(35, 75), tilt=rng.uniform(-50, -8) if side < 3 else rng.uniform(-89, -60),
+             roll=rng.uniform(-10, 10), w=w, h=h, cx=w / 2, cy=h / 2, **cam)
+    valid = rng.random(gh * gw) > 0.01 if seed % 3 == 0 else None
+    a = (np.arange(gw - 1)[None, :] + np.arange(gh - 1)[:, None] * gw).ravel()
+    full = np.stack([a, a + gw, a + gw + 1, a, a + gw + 1, a + 1], axis=1).reshape(-1, 3)
+    keep = np.flatnonzero(valid[full].all(axis=1)) if valid is not None else None
+    ref = orast.visibility(vert, full if keep is None else full[keep], p, None)
+    assert (ref != 0).mean() > 0.03         # the camera sees the surface (a sanity check of the case, not of the kernel)
+    with L.Mesh(vert, None, None, grid=(gh, gw)) as m:
+        if valid is not None:
+            m.set_valid(valid)
+        pv = L.params_vector(p)
+        m.render_enqueue(pv, None)
+        got = m.fetch_visibility()
+        if keep is None:
+            assert_vis_equal(got, ref)
+        else:
+            hit = ref != 0
+            np.testing.assert_array_equal(got != 0, hit)
+            np.testing.assert_array_equal(got[hit] >> np.uint64(32), ref[hit] >> np.uint64(32))
+            np.testing.assert_array_equal(0xFFFFFFFF - (got[hit] & np.uint64(0xFFFFFFFF)).astype(np.int64),
+                                          keep[0xFFFFFFFF - (ref[hit] & np.uint64(0xFFFFFFFF)).astype(np.int64)])
+        for env in ("ALP_NO_TILE_CULL", "ALP_NO_OCCLUSION"):
+            os.environ[env] = "1"
+            try:
+                m.render_enqueue(pv, None)
+                np.testing.assert_array_equal(m.fetch_visibility(), got)
+            finally:
+                os.environ.pop(env, None)
