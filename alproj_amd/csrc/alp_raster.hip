@@ -2426,6 +2426,22 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
                 ALP_HIP(hipStreamSynchronize(st));
                 fprintf(stderr, "[frame plan] tiles %lld: near %u, far %u of which %u survive the occlusion test\n", tiles, hc[0],
                         hc[1], hc[2]);
+                if (two_rounds) {
+                    // how many NEAR tiles would an occlusion test against the FINISHED frame drop (an upper bound for
+                    // what more rounds could gain)?  Full-frame pyramid, the NEAR list through tile_occlusion_kernel.
+                    const HizDims dm = hiz_dims(v.w, v.h);
+                    const unsigned full[4] = {65535u, (unsigned)v.w, 65535u, (unsigned)v.h}, zero = 0;
+                    ALP_HIP(hipMemcpy(counts + 4, full, sizeof(full), hipMemcpyHostToDevice));
+                    ALP_HIP(hipMemcpy(counts + 3, &zero, sizeof(zero), hipMemcpyHostToDevice));
+                    hipLaunchKernelGGL(hiz_build_kernel, dim3((unsigned)dm.w[3], (unsigned)dm.h[3]), dim3(256), 0, st, m->vis, v.w, v.h, dm,
+                                       m->hiz, counts + 4);
+                    hipLaunchKernelGGL(tile_occlusion_kernel, dim3(plan_grid), dim3(256), 0, st, m->tile_bounds, cull, near_list,
+                                       counts - 1, dm, m->hiz, second_list, counts + 3);      // counts[-1 + 1] = the NEAR count
+                    unsigned left = 0;
+                    ALP_HIP(hipStreamSynchronize(st));
+                    ALP_HIP(hipMemcpy(&left, counts + 3, sizeof(left), hipMemcpyDeviceToHost));
+                    fprintf(stderr, "[frame plan] of the %u NEAR tiles %u survive a test against the finished frame\n", hc[0], left);
+                }
             }
 #endif
         } else {
