@@ -1828,10 +1828,14 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float *__restrict__ 
                 const long long ids[3] = {id.a, id.b, id.c};
                 // float64 view-space vertices: Rd (v - camd)
                 double Q[3][3];
+                float P[3][3];                     // the vertices themselves: they are the values when no value array is given
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const float *pp = vert + 3 * ids[k];
-                    const double d0 = (double)pp[0] - v.camd[0], d1 = (double)pp[1] - v.camd[1], d2 = (double)pp[2] - v.camd[2];
+                    P[k][0] = pp[0];
+                    P[k][1] = pp[1];
+                    P[k][2] = pp[2];
+                    const double d0 = (double)P[k][0] - v.camd[0], d1 = (double)P[k][1] - v.camd[1], d2 = (double)P[k][2] - v.camd[2];
 #pragma unroll
                     for (int c = 0; c < 3; ++c) Q[k][c] = (v.Rd[c][0] * d0 + v.Rd[c][1] * d1) + v.Rd[c][2] * d2;
                 }
@@ -1855,10 +1859,17 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float *__restrict__ 
                     masked = alpha * dA + beta * dB + gamma * dC < min_distance;
                 }
                 if (!masked) {
-                    const float *val = value ? value : vert;
-                    const float *va = val + 3 * ids[0], *vb = val + 3 * ids[1], *vc = val + 3 * ids[2];
+                    if (value) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) o[c] = (float)(alpha * va[c] + beta * vb[c] + gamma * vc[c]);
+                        for (int k = 0; k < 3; ++k) {
+                            const float *pv_ = value + 3 * ids[k];
+                            P[k][0] = pv_[0];
+                            P[k][1] = pv_[1];
+                            P[k][2] = pv_[2];
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) o[c] = (float)(alpha * P[0][c] + beta * P[1][c] + gamma * P[2][c]);
                 }
             }
         }
