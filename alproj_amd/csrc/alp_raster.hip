@@ -2202,9 +2202,10 @@ int try_subgrid(alp_mesh *m, const long long first[3]) {
     const long long words = (full + 31) / 32, blocks = (words + 255) / 256;
     unsigned *block_dev = nullptr;
     auto giveup = [&](int code) {
-        for (void *p : {(void *)m->valid_derived, (void *)m->tri_present, (void *)m->tri_rank, (void *)block_dev})
+        // (m->valid: the mesh is being created, a mask can only be this function's own, half-made one)
+        for (void *p : {(void *)m->valid_derived, (void *)m->tri_present, (void *)m->tri_rank, (void *)block_dev, (void *)m->valid})
             if (p) hipFree(p);
-        m->valid_derived = nullptr;
+        m->valid_derived = m->valid = nullptr;
         m->tri_present = m->tri_rank = nullptr;
         return code;
     };
