@@ -5,8 +5,7 @@ export TMPDIR=/tmp
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_FLAT SQ_ACTIVE_INST_MISC SQ_WAIT_ANY" \
            "SQ_WAIT_INST_ANY SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_SALU SQ_INSTS_FLAT SQ_INST_LEVEL_SMEM" \
-           "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_TC_STALL SQC_DCACHE_BUSY_CYCLES SQ_IFETCH SQC_ICACHE_MISSES SQC_ICACHE_REQ" \
-           "TA_FLAT_ATOMIC_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_BUSY_avr SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_INST_LEVEL_VMEM"; do
+           "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_TC_STALL SQC_DCACHE_BUSY_CYCLES SQ_IFETCH SQC_ICACHE_MISSES SQC_ICACHE_REQ"; do
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $set -d gpurun_out/ppmc_$i -o p -- python3 tools/probe_raster.py ${1:-100000000} 3 > gpurun_out/ppmc_$i.log 2>&1 </dev/null
   python3 - <<PY
