@@ -51,11 +51,16 @@ def raycast(vert, value, ind, params, offsets=None, grid=None):
     return dict(tri=tri, depth=depth, depth2=depth2, edge=edge, value=val)
 
 
-def safe_mask(rc, edge_px=1.0 / 128, depth_rel=1e-4):
-    """Pixels whose outcome no implementation-defined rule can change."""
+def safe_mask(rc, edge_px=1.0 / 128, depth_rel=1e-4, depth24_steps=None):
+    """Pixels whose outcome no implementation-defined rule can change.  With ``depth24_steps`` the first and
+    second hit must also lie that many steps of a 24-bit depth buffer apart in the window depth the reference's
+    projection produces, 0.5 - 0.5 / vz (project.py:48-53 uploaded untransposed; ~1 m per step at 3 km): the
+    criterion for comparisons with a real OpenGL, whose depth renderbuffer is DEPTH_COMPONENT24."""
     hit = rc["tri"] >= 0
-    with np.errstate(invalid="ignore"):
+    with np.errstate(invalid="ignore", divide="ignore"):
         separated = (rc["depth2"] - rc["depth"]) > depth_rel * rc["depth"]
+        if depth24_steps is not None:
+            separated &= (0.5 / rc["depth"] - 0.5 / rc["depth2"]) * (2 ** 24 - 1) > depth24_steps
     return (rc["edge"] > edge_px) & (~hit | separated)
 
 

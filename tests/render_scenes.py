@@ -33,3 +33,56 @@ SCENES = {
     "grid_wide_fov": lambda: _grid_scene(100, 256, 192, fov=88.0, tilt=-30.0, pan=120.0),
     "hand_made_indices": _hand_made,
 }
+
+
+# ---- scenes of the OpenGL fixtures (tests/golden/gen_golden_gl.py -> g15_gl_render.npz) -----------------
+# The reference's own persp_proj ran UNMODIFIED on each of these on a real OpenGL (Mesa llvmpipe); the CPU
+# oracle and the HIP path are compared with what it returned.  Every scene is rebuilt from seeds here, so
+# the fixture stores only GL's outputs.
+
+def _far_scene():
+    """terrain 1.2 ... 4.2 km from the camera (2 m cells): the distance the reference is used at
+    (example.py:26, docs/usage.md:56), where a 24-bit depth buffer resolves ~1 m"""
+    n, res, w, h = 2000, 2.0, 480, 320
+    s = syn.surface(n, res=res)
+    p = dict(syn.base_params(n, res), w=w, h=h, cx=w / 2.0, cy=h / 2.0, tilt=-8.0, fov=40.0)
+    p["z"] += 400.0
+    return dict(vert=s["vert"], ind=None, grid=(n, n), params=p, offsets=s["offsets"])
+
+
+def _nodata_scene():
+    """the index array get_colored_surface returns for a DSM with nodata (surface.py:203-205): the grid's
+    triangles minus those touching a masked vertex"""
+    s = _grid_scene(100, 288, 192, tilt=-14.0, pan=100.0)
+    n = 100
+    rng = np.random.default_rng(77)
+    bad = np.zeros(n * n, dtype=bool)
+    for r, c in rng.integers(2, n - 6, (40, 2)):
+        bad.reshape(n, n)[r:r + 3, c:c + 4] = True
+    ind = syn.grid_indices(n, np.int64)
+    s["ind"] = ind[~bad[ind].any(axis=1)]
+    s["grid"] = None
+    return s
+
+
+def _with(scene, **kw):
+    def make():
+        s = SCENES[scene]() if isinstance(scene, str) else scene()
+        s.update(kw)
+        return s
+    return make
+
+
+def _coloured():
+    s = SCENES["grid_tilt_roll"]()
+    s["value"] = syn.colors(s["grid"][0] ** 2)
+    return s
+
+
+GL_SCENES = dict(SCENES)
+GL_SCENES.update({
+    "grid_colours": _coloured,                                                # sim_image's call (project.py:322)
+    "grid_min_distance": _with("grid_tilted", min_distance=60.0),             # project.py:235,247
+    "grid_nodata_indices": _nodata_scene,
+    "grid_far_3km": _far_scene,
+})
