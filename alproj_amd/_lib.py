@@ -68,13 +68,16 @@ _SIGNATURES = {
     "alp_loss_uv": [_c_dp, _c_dp, _c_i64, _c_int, _c_double, _c_dp],
     "alp_cma_sample": [_c_dp, _c_double, _c_dp, _c_dp, _c_dp, _c_int, _c_i64, _c_int, ctypes.c_uint64, ctypes.c_uint64, _c_dp,
                        ctypes.POINTER(ctypes.c_int32)],
-    "alp_mesh_create": [_c_fp, _c_fp, _c_i64, _c_void_p, _c_int, _c_i64, _c_i64, _c_i64,
+    "alp_mesh_create": [_c_void_p, _c_int, _c_void_p, _c_int, _c_i64, _c_void_p, _c_int, _c_i64, _c_i64, _c_i64,
                         ctypes.POINTER(_c_void_p)],
     "alp_mesh_destroy": [_c_void_p],
     "alp_render": [_c_void_p, _c_dp, _c_dp, _c_double, _c_fp],
     "alp_render_enqueue": [_c_void_p, _c_dp, _c_dp, _c_double],
     "alp_render_fetch": [_c_void_p, _c_fp],
     "alp_render_fetch_visibility": [_c_void_p, ctypes.POINTER(ctypes.c_uint64)],
+    "alp_render_fetch_u8": [_c_void_p, ctypes.c_float, _c_int, ctypes.POINTER(ctypes.c_uint8)],
+    "alp_mesh_set_value": [_c_void_p, _c_void_p, _c_int],
+    "alp_mesh_frame_counts": [_c_void_p, ctypes.POINTER(_c_i64)],
     "alp_mesh_set_value_source": [_c_void_p, _c_int],
     "alp_mesh_set_valid": [_c_void_p, ctypes.POINTER(ctypes.c_uint8)],
     "alp_mesh_from_rasters": [_c_void_p, _c_int, _c_i64, _c_i64, _c_dp, ctypes.c_double, _c_void_p, _c_int,
@@ -147,7 +150,8 @@ def device_info():
 
 def params_vector(params):
     """dict -> float64[25] in ABI order (raises KeyError on a missing key like the reference)."""
-    out = np.array([0.0 if params[k] is None else float(params[k]) for k in PARAM_KEYS], dtype=np.float64)
+    # None is meaningful for cx / cy only; float(None) raises for every other key, as the reference's arithmetic does
+    out = np.array([0.0 if (params[k] is None and k in ("cx", "cy")) else float(params[k]) for k in PARAM_KEYS], dtype=np.float64)
     # the reference's intrinsic_mat substitutes w/2, h/2 for cx/cy = None (optimize.py:27-30)
     if params["cx"] is None:
         out[23] = out[21] / 2
@@ -277,6 +281,15 @@ class Points:
         return losses, int(amin.value)
 
 
+def _vertex_array(a):
+    """float32 and float64 arrays go to the library as they are (float64 is cast on the device during the upload:
+    the reference's ``astype("f4")``, project.py:213-214, without a host pass); anything else becomes float64 first."""
+    a = np.asarray(a)
+    if a.dtype not in (np.float32, np.float64):
+        a = a.astype(np.float64)
+    return np.ascontiguousarray(a)
+
+
 class Mesh:
     """Device-resident triangle mesh (RAII wrapper of alp_mesh_t).
 
@@ -285,11 +298,11 @@ class Mesh:
 
     def __init__(self, vert, value=None, ind=None, grid=None):
         l = lib()
-        vert = np.ascontiguousarray(vert, dtype=np.float32)
+        vert = _vertex_array(vert)
         if vert.ndim != 2 or vert.shape[1] != 3:
             raise ValueError("vert must have shape (N, 3)")
         if value is not None:
-            value = np.ascontiguousarray(value, dtype=np.float32)
+            value = _vertex_array(value)
             if value.shape != vert.shape:
                 raise ValueError("value must have the shape of vert")
         if ind is None:
@@ -306,11 +319,38 @@ class Mesh:
             gh = gw = 0
             ind_p, code, n_tri = ind.ctypes.data_as(_c_void_p), (ALP_I64 if ind.dtype == np.int64 else ALP_I32), ind.shape[0]
         h = _c_void_p()
-        check(l.alp_mesh_create(as_fp(vert), None if value is None else as_fp(value), vert.shape[0], ind_p, code,
+        check(l.alp_mesh_create(vert.ctypes.data_as(_c_void_p), dtype_code(vert),
+                                None if value is None else value.ctypes.data_as(_c_void_p),
+                                ALP_F32 if value is None else dtype_code(value), vert.shape[0], ind_p, code,
                                 n_tri, gh, gw, ctypes.byref(h)))
         self._h, self._lib = h, l
         self.shape = None
         self.n_vert = vert.shape[0]
+        self.has_value = value is not None
+
+    def set_value(self, value):
+        """Replace the stored per-vertex values (None drops them: value == vert)."""
+        if value is None:
+            check(self._lib.alp_mesh_set_value(self._h, None, ALP_F32))
+        else:
+            value = _vertex_array(value)
+            if value.shape != (self.n_vert, 3):
+                raise ValueError("value must have shape (n_vert, 3)")
+            check(self._lib.alp_mesh_set_value(self._h, value.ctypes.data_as(_c_void_p), dtype_code(value)))
+        self.has_value = value is not None
+
+    def frame_counts(self):
+        """(full frames, frames served from the visibility cache by the resolve stage alone)"""
+        c = (_c_i64 * 2)()
+        check(self._lib.alp_mesh_frame_counts(self._h, c))
+        return int(c[0]), int(c[1])
+
+    def fetch_u8(self, scale=255.0, reverse_channels=True):
+        """The last frame as (h, w, 3) uint8 = (image * scale).astype(uint8), channels reversed: sim_image's tail"""
+        out = np.empty(self.shape, dtype=np.uint8)
+        check(self._lib.alp_render_fetch_u8(self._h, float(scale), int(bool(reverse_channels)),
+                                            out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))))
+        return out
 
     @classmethod
     def from_rasters(cls, dsm, transform, z_max, aerial, color_div, nodata=None):
@@ -347,6 +387,7 @@ class Mesh:
                                       as_dp(off), ctypes.byref(h)))
         self = cls.__new__(cls)
         self._h, self._lib, self.shape, self.n_vert = h, l, None, dsm.size
+        self.has_value = True
         return self, off
 
     def set_valid(self, valid):

@@ -82,9 +82,33 @@ int alp_mesh_set_value_source(alp_mesh_t *m, int source) {
     return ALP_OK;
 }
 
+int alp_mesh_set_value(alp_mesh_t *m, const void *value, int value_dtype) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(m, "mesh handle is NULL");
+    if (!value) {
+        if (m->value) {
+            ALP_HIP(hipStreamSynchronize(ctx().stream));      // a resolve that reads it may be in flight
+            hipFree(m->value);
+        }
+        m->value = nullptr;
+        return ALP_OK;
+    }
+    ALP_REQUIRE(value_dtype == ALP_F32 || value_dtype == ALP_F64, "value_dtype must be ALP_F32 or ALP_F64");
+    if (!m->value) ALP_HIP(hipMalloc((void **)&m->value, (size_t)m->n_vert * 12));
+    return upload_f32(m->value, value, value_dtype, m->n_vert);    // stream-ordered behind any resolve in flight
+}
+
+int alp_mesh_frame_counts(alp_mesh_t *m, int64_t counts[2]) {
+    ALP_REQUIRE(m && counts, "NULL argument");
+    counts[0] = m->frames_full;
+    counts[1] = m->frames_resolve_only;
+    return ALP_OK;
+}
+
 int alp_mesh_set_valid(alp_mesh_t *m, const uint8_t *valid) {
     if (int rc = require_init()) return rc;
     ALP_REQUIRE(m, "mesh handle is NULL");
+    m->vis_current = false;
     if (m->valid_derived) return apply_derived_mask(m, valid);   // filtered grid: its own mask stays in force
     if (!valid) {
         if (m->valid) hipFree(m->valid);

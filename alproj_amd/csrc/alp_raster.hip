@@ -1903,6 +1903,25 @@ constexpr int COMPACT_CHUNK = 4096;
 // set_gcp (src/alproj/gcp.py:644-648) against the resident coordinate image instead of a merge
 // with the reverse_proj table: pixel (u[i], v[i]) -> x, y, z = channels (0, 2, 1) + offsets,
 // NaN where the pixel is outside the image or does not see the surface (x <= 0, project.py:369)
+// sim_image's tail (project.py:322-324): (raw * 255).astype(uint8), RGB -> BGR.  numpy's float32 -> uint8 cast is the
+// x86 truncating conversion to int32 followed by a wrap to 8 bits (NaN and out-of-range give 0x80000000 -> 0).
+__global__ __launch_bounds__(256) void image_u8_kernel(const float *__restrict__ img, long long npix, float scale, int reverse,
+                                                       unsigned char *__restrict__ out) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
+        unsigned char b[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float x = img[3 * i + c] * scale;
+            const int q = (x >= -2147483648.0f && x < 2147483648.0f) ? (int)x : (int)0x80000000;   // false for NaN too
+            b[c] = (unsigned char)(q & 0xFF);
+        }
+        out[3 * i + 0] = reverse ? b[2] : b[0];
+        out[3 * i + 1] = b[1];
+        out[3 * i + 2] = reverse ? b[0] : b[2];
+    }
+}
+
 __global__ __launch_bounds__(256) void gather_pixels_kernel(const float *__restrict__ image, int w, int h,
                                                             const int *__restrict__ u, const int *__restrict__ v,
                                                             long long n, double o0, double o1, double o2,
@@ -2107,11 +2126,38 @@ __global__ __launch_bounds__(256) void mask_and_kernel(const unsigned char *__re
     if (i < n) out[i] = derived[i] && (!user || user[i]);
 }
 
-__global__ __launch_bounds__(256) void narrow_indices_kernel(const long long *__restrict__ src, long long count,
-                                                             long long dst_off, int *__restrict__ dst) {
+// alp_mesh_create with float64 vertices / values (what get_colored_surface returns, surface.py:189-193): the cast of
+// project.py:213-214 (``astype("f4")``: round to nearest even) on the device, chunk by chunk during the upload
+__global__ __launch_bounds__(256) void cast_f64_f32_kernel(const double *__restrict__ src, long long count, long long dst_off,
+                                                           float *__restrict__ dst) {
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
-        dst[dst_off + i] = (int)src[i];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) dst[dst_off + i] = (float)src[i];
+}
+
+// an out-of-range index would fault in the raster kernels: counted on the device (the host loop over 6e8
+// indices of a 100 M-vertex mesh took longer than their upload)
+__global__ __launch_bounds__(256) void check_index_range_kernel(const int *__restrict__ ind, long long count, long long n_vert,
+                                                                unsigned *__restrict__ bad) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    unsigned mine = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const int v = ind[i];
+        mine += (v < 0 || v >= n_vert) ? 1u : 0u;
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
+__global__ __launch_bounds__(256) void narrow_indices_kernel(const long long *__restrict__ src, long long count,
+                                                             long long dst_off, int *__restrict__ dst, long long n_vert,
+                                                             unsigned *__restrict__ bad) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    unsigned mine = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const long long v = src[i];
+        mine += (v < 0 || v >= n_vert) ? 1u : 0u;
+        dst[dst_off + i] = (int)v;
+    }
+    if (mine) atomicAdd(bad, mine);
 }
 
 }  // namespace alp
@@ -2274,6 +2320,7 @@ int ensure_frame(alp_mesh *m, int w, int h) {
     if (m->image) hipFree(m->image);
     m->vis = nullptr;
     m->image = nullptr;
+    m->vis_current = false;
     ALP_HIP(hipMalloc((void **)&m->vis, (size_t)w * h * sizeof(unsigned long long) + QC_TOTAL * sizeof(unsigned)));   // + the frame's counters
     ALP_HIP(hipMalloc((void **)&m->image, (size_t)w * h * 3 * sizeof(float)));
     if (m->hiz) hipFree(m->hiz);
@@ -2296,14 +2343,18 @@ static int patch_words_env(const char *name, int dflt) {
 // Enqueue one whole frame on the library stream, no host round trip: clear, raster passes (the
 // queue lengths stay on the device), resolve.  The two queue counters are copied to pinned host
 // memory at the end; finish_frame() checks them before anything reads the frame.
+// `resolve_only`: the visibility buffer (and the frame's counters behind it) already hold this view's finished
+// raster passes -- only the resolve runs (the visibility cache, see alp_mesh::vis_current).
 template <bool IMPLICIT>
-int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_distance) {
+int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_distance, bool resolve_only = false) {
     hipStream_t st = ctx().stream;
     const int cu = ctx().cu_count;
-    // one fill clears the visibility buffer AND the frame's queue / list counters, which live right behind it
-    ALP_HIP(hipMemsetAsync(m->vis, 0, (size_t)v.w * v.h * sizeof(unsigned long long) + QC_TOTAL * sizeof(unsigned), st));
     unsigned *const fcount = (unsigned *)(m->vis + (size_t)v.w * v.h);
-    if (m->n_tri > 0) {
+    m->vis_current = false;          // until every launch below has been accepted
+    // one fill clears the visibility buffer AND the frame's queue / list counters, which live right behind it
+    if (!resolve_only)
+        ALP_HIP(hipMemsetAsync(m->vis, 0, (size_t)v.w * v.h * sizeof(unsigned long long) + QC_TOTAL * sizeof(unsigned), st));
+    if (m->n_tri > 0 && !resolve_only) {
         // queue counters, four per round: [0] work items, [1] general entries, [2] small parked, [3] large parked
         // the consumers of one round: (a) the rare cases (near-plane crossings, 64 px and more), (b) what
         // raster_grid_kernel parked; the second round's parked entries follow the first round's in the queues
@@ -2487,6 +2538,8 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
     m->last_rc = rc;
     m->last_min_distance = min_distance;
     m->unchecked = m->n_tri > 0;
+    m->vis_current = true;
+    ++(resolve_only ? m->frames_resolve_only : m->frames_full);
 #ifdef ALP_RASTER_STATS
     {
         unsigned long long hs[24 + 64], zero[24 + 64] = {0};
@@ -2508,6 +2561,13 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
 #endif
     m->rendered = true;
     return ALP_OK;
+}
+
+// everything of a View the raster passes read (the resolve's float64 members follow from the same parameters)
+static bool same_view(const View &a, const View &b) {
+    return a.w == b.w && a.h == b.h && a.fx == b.fx && a.fy == b.fy && a.sx == b.sx && a.sy == b.sy && a.fxd == b.fxd && a.fyd == b.fyd &&
+           !memcmp(a.R, b.R, sizeof(a.R)) && !memcmp(a.camf, b.camf, sizeof(a.camf)) && !memcmp(a.caml, b.caml, sizeof(a.caml)) &&
+           !memcmp(a.Rd, b.Rd, sizeof(a.Rd)) && !memcmp(a.camd, b.camd, sizeof(a.camd));
 }
 
 // Before anything reads the last frame: wait for it and make sure neither queue overflowed.  A
@@ -2546,14 +2606,36 @@ int finish_frame(alp_mesh *m) {
 
 }  // namespace
 
+// n x 3 float32 or float64 host array -> n x 3 float32 on the device; float64 is staged through the library
+// scratch in chunks and cast there (no host pass over the array, no float32 copy on the host)
+int alp::upload_f32(float *dst, const void *src, int dtype, int64_t n_vert) {
+    const size_t count = (size_t)n_vert * 3;
+    if (dtype == ALP_F32) return upload_chunked(dst, src, count * 4);
+    const size_t CH = (size_t)24 << 20;                 // doubles per chunk: 192 MB (tools/h2d_rate.hip: large chunks, no sync in between)
+    const size_t ch = count < CH ? count : CH;
+    double *stage = nullptr;
+    if (int rc = scratch_reserve(ch * 8, (void **)&stage)) return rc;
+    hipStream_t st = ctx().stream;
+    for (size_t off = 0; off < count; off += ch) {
+        const size_t cnt = count - off < ch ? count - off : ch;
+        ALP_HIP(hipMemcpyAsync(stage, (const double *)src + off, cnt * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(cast_f64_f32_kernel, dim3(4096), dim3(256), 0, st, stage, (long long)cnt, (long long)off, dst);
+        ALP_HIP(hipGetLastError());
+    }
+    ALP_HIP(hipStreamSynchronize(st));
+    return ALP_OK;
+}
+
 extern "C" {
 
-int alp_mesh_create(const float *vert, const float *value, int64_t n_vert, const void *ind, int ind_dtype,
-                    int64_t n_tri, int64_t grid_h, int64_t grid_w, alp_mesh_t **out) {
+int alp_mesh_create(const void *vert, int vert_dtype, const void *value, int value_dtype, int64_t n_vert, const void *ind,
+                    int ind_dtype, int64_t n_tri, int64_t grid_h, int64_t grid_w, alp_mesh_t **out) {
     if (int rc = require_init()) return rc;
     ALP_REQUIRE(out, "out is NULL");
     *out = nullptr;
     ALP_REQUIRE(vert && n_vert > 0, "vert is NULL or empty");
+    ALP_REQUIRE(vert_dtype == ALP_F32 || vert_dtype == ALP_F64, "vert_dtype must be ALP_F32 or ALP_F64");
+    ALP_REQUIRE(!value || value_dtype == ALP_F32 || value_dtype == ALP_F64, "value_dtype must be ALP_F32 or ALP_F64");
     ALP_REQUIRE(n_vert < ((int64_t)1 << 31), "more than 2^31 vertices");
     const bool implicit = ind == nullptr;
     if (implicit) {
@@ -2573,44 +2655,52 @@ int alp_mesh_create(const float *vert, const float *value, int64_t n_vert, const
     int rc = ALP_OK;
     auto bail = [&](int code) { alp_mesh_destroy(m); return code; };
     if (hipMalloc((void **)&m->vert, (size_t)n_vert * 12) != hipSuccess) return bail(fail(ALP_EHIP, "hipMalloc vert"));
-    if ((rc = upload_chunked(m->vert, vert, (size_t)n_vert * 12))) return bail(rc);
+    if ((rc = upload_f32(m->vert, vert, vert_dtype, n_vert))) return bail(rc);
     if (value) {
         if (hipMalloc((void **)&m->value, (size_t)n_vert * 12) != hipSuccess) return bail(fail(ALP_EHIP, "hipMalloc value"));
-        if ((rc = upload_chunked(m->value, value, (size_t)n_vert * 12))) return bail(rc);
-    }
-    if (!implicit && n_tri > 0) {
-        if (hipMalloc((void **)&m->ind, (size_t)n_tri * 12) != hipSuccess) return bail(fail(ALP_EHIP, "hipMalloc ind"));
-        if (ind_dtype == ALP_I32) {
-            if ((rc = upload_chunked(m->ind, ind, (size_t)n_tri * 12))) return bail(rc);
-            // range check on the host copy: an out-of-range index would fault in the kernels
-            const int *h = (const int *)ind;
-            for (int64_t i = 0; i < n_tri * 3; ++i)
-                if (h[i] < 0 || h[i] >= n_vert) return bail(fail(ALP_EINVAL, "index %lld out of range at %lld", (long long)h[i], (long long)i));
-        } else {
-            const long long *h = (const long long *)ind;
-            for (int64_t i = 0; i < n_tri * 3; ++i)
-                if (h[i] < 0 || h[i] >= n_vert) return bail(fail(ALP_EINVAL, "index %lld out of range at %lld", h[i], (long long)i));
-            const int64_t CH = 16 << 20;
-            long long *stage = nullptr;
-            const int64_t total = n_tri * 3;
-            const int64_t ch = total < CH ? total : CH;
-            if (hipMalloc((void **)&stage, (size_t)ch * 8) != hipSuccess) return bail(fail(ALP_EHIP, "hipMalloc stage"));
-            for (int64_t off = 0; off < total && !rc; off += ch) {
-                const int64_t cnt = total - off < ch ? total - off : ch;
-                hipError_t e = hipMemcpyAsync(stage, h + off, (size_t)cnt * 8, hipMemcpyHostToDevice, ctx().stream);
-                if (e == hipSuccess) {
-                    hipLaunchKernelGGL(narrow_indices_kernel, dim3(4096), dim3(256), 0, ctx().stream, stage, cnt, off, m->ind);
-                    e = hipStreamSynchronize(ctx().stream);
-                }
-                if (e != hipSuccess) rc = fail(ALP_EHIP, "index upload: %s", hipGetErrorString(e));
-            }
-            hipFree(stage);
-            if (rc) return bail(rc);
-        }
+        if ((rc = upload_f32(m->value, value, value_dtype, n_vert))) return bail(rc);
     }
     if (hipMalloc((void **)&m->qcount_dev, QC_TOTAL * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void **)&m->qcount_host, QC_TOTAL * sizeof(unsigned), hipHostMallocDefault) != hipSuccess)
         return bail(fail(ALP_EHIP, "hipMalloc queue counter"));
+    if (!implicit && n_tri > 0) {
+        hipStream_t st = ctx().stream;
+        if (hipMalloc((void **)&m->ind, (size_t)n_tri * 12) != hipSuccess) return bail(fail(ALP_EHIP, "hipMalloc ind"));
+        if (hipMemsetAsync(m->qcount_dev, 0, sizeof(unsigned), st) != hipSuccess) return bail(fail(ALP_EHIP, "index check: memset"));
+        const int64_t total = n_tri * 3;
+        if (ind_dtype == ALP_I32) {
+            if ((rc = upload_chunked(m->ind, ind, (size_t)total * 4))) return bail(rc);
+            hipLaunchKernelGGL(check_index_range_kernel, dim3(4096), dim3(256), 0, st, m->ind, (long long)total, (long long)n_vert,
+                               m->qcount_dev);
+        } else {
+            // int64 (what numpy builds, surface.py:194-201; project.py:215 casts with astype("i4")): narrowed on the
+            // device, staged through the library scratch in chunks of 192 MB
+            const int64_t CH = 24 << 20;
+            const int64_t ch = total < CH ? total : CH;
+            long long *stage = nullptr;
+            if ((rc = scratch_reserve((size_t)ch * 8, (void **)&stage))) return bail(rc);
+            for (int64_t off = 0; off < total; off += ch) {
+                const int64_t cnt = total - off < ch ? total - off : ch;
+                if (hipMemcpyAsync(stage, (const long long *)ind + off, (size_t)cnt * 8, hipMemcpyHostToDevice, st) != hipSuccess)
+                    return bail(fail(ALP_EHIP, "index upload"));
+                hipLaunchKernelGGL(narrow_indices_kernel, dim3(4096), dim3(256), 0, st, stage, (long long)cnt, (long long)off, m->ind,
+                                   (long long)n_vert, m->qcount_dev);
+            }
+        }
+        // range check (an out-of-range index would fault in the kernels): counted by the kernels above
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(m->qcount_host, m->qcount_dev, sizeof(unsigned), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return bail(fail(ALP_EHIP, "index upload: %s", hipGetErrorString(e)));
+        if (*m->qcount_host != 0) {
+            // name the first offender like the host check did (cold path: a scan of the caller's array)
+            for (int64_t i = 0; i < total; ++i) {
+                const long long v = ind_dtype == ALP_I32 ? (long long)((const int *)ind)[i] : ((const long long *)ind)[i];
+                if (v < 0 || v >= n_vert) return bail(fail(ALP_EINVAL, "index %lld out of range at %lld", v, (long long)i));
+            }
+            return bail(fail(ALP_EINVAL, "%u indices out of range", *m->qcount_host));
+        }
+    }
     if ((rc = ensure_queue(m, initial_queue_cap()))) return bail(rc);
     if ((rc = ensure_gqueue(m, initial_queue_cap()))) return bail(rc);
     // The index array the reference builds (surface.py:194-201) is the full regular grid unless
@@ -2675,7 +2765,10 @@ int alp_render_enqueue(alp_mesh_t *m, const double params[ALP_NPARAM], const dou
     RemapCoef rc;
     make_view(params, offsets, &v, &rc);
     if (int e = ensure_frame(m, v.w, v.h)) return e;
-    return m->implicit ? render_impl<true>(m, v, rc, min_distance) : render_impl<false>(m, v, rc, min_distance);
+    // same view as the frame whose visibility buffer is still there: the raster passes would rebuild it bit for bit
+    static const bool no_cache = getenv("ALP_NO_VIS_CACHE") != nullptr;      // tests: force the full frame
+    const bool cached = m->vis_current && !no_cache && same_view(v, m->last_v);
+    return m->implicit ? render_impl<true>(m, v, rc, min_distance, cached) : render_impl<false>(m, v, rc, min_distance, cached);
 }
 
 int alp_render_fetch(alp_mesh_t *m, float *out) {
@@ -2684,6 +2777,22 @@ int alp_render_fetch(alp_mesh_t *m, float *out) {
     if (!m->rendered) return fail(ALP_ESTATE, "alp_render_fetch: nothing rendered yet");
     if (int e = finish_frame(m)) return e;
     ALP_HIP(hipMemcpyAsync(out, m->image, (size_t)m->w * m->h * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx().stream));
+    ALP_HIP(hipStreamSynchronize(ctx().stream));
+    return ALP_OK;
+}
+
+int alp_render_fetch_u8(alp_mesh_t *m, float scale, int reverse_channels, uint8_t *out) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(m && out, "NULL argument");
+    if (!m->rendered) return fail(ALP_ESTATE, "alp_render_fetch_u8: nothing rendered yet");
+    if (int e = finish_frame(m)) return e;
+    const long long npix = (long long)m->w * m->h;
+    unsigned char *dev = nullptr;
+    if (int rc = scratch_reserve((size_t)npix * 3, (void **)&dev)) return rc;
+    hipLaunchKernelGGL(image_u8_kernel, dim3(ctx().cu_count * 16), dim3(256), 0, ctx().stream, m->image, npix, scale,
+                       reverse_channels, dev);
+    ALP_HIP(hipGetLastError());
+    ALP_HIP(hipMemcpyAsync(out, dev, (size_t)npix * 3, hipMemcpyDeviceToHost, ctx().stream));
     ALP_HIP(hipStreamSynchronize(ctx().stream));
     return ALP_OK;
 }
@@ -2856,6 +2965,7 @@ int alp_render_load(alp_mesh_t *m, const float *image, int64_t h, int64_t w) {
     if (int e = ensure_frame(m, (int)w, (int)h)) return e;
     if (int e = upload_chunked(m->image, image, (size_t)h * w * 3 * sizeof(float))) return e;
     ALP_HIP(hipMemsetAsync(m->vis, 0, (size_t)h * w * sizeof(unsigned long long), ctx().stream));   // no visibility belongs to it
+    m->vis_current = false;
     m->rendered = true;
     m->valid_total = -1;
     return ALP_OK;

@@ -78,6 +78,12 @@ struct alp_mesh {
     alp::RemapCoef last_rc;
     double last_min_distance = 0;
     bool rendered = false;
+    // Visibility cache: `vis` holds the finished visibility buffer of view `last_v` for the mesh's current vertices
+    // and mask.  A render with the same view then runs the resolve alone (new value source, lens coefficients or
+    // min_distance: the reference's sim_image + reverse_proj pair at one pose, example.py:28,31).  Cleared by
+    // everything that changes what a raster pass would draw (alp_mesh_set_valid, alp_render_load, a new frame size).
+    bool vis_current = false;
+    int64_t frames_full = 0, frames_resolve_only = 0;
     // reverse_proj compaction scratch
     unsigned *compact_counts = nullptr;
     unsigned long long *compact_offsets = nullptr;
@@ -88,6 +94,7 @@ struct alp_mesh {
 namespace alp {
 // defined in alp_raster.hip
 int upload_chunked(void *dst, const void *src, size_t bytes);
+int upload_f32(float *dst, const void *src, int dtype, int64_t n_vert);   // n x 3 float32 / float64 host -> float32 device
 int ensure_queue(alp_mesh *m, unsigned cap);
 int ensure_gqueue(alp_mesh *m, unsigned cap);
 int ensure_park(alp_mesh *m, unsigned cap_small, unsigned cap_large, unsigned cap_cell);

@@ -21,17 +21,79 @@ Extensions (keyword-only, defaults keep the reference behaviour): ``ind=None`` t
 an index array; a ``Mesh`` object can be passed as ``vert`` to re-render a device-resident
 mesh with new camera parameters (the reference re-uploads everything on every call,
 project.py:210-215).
+
+The reference's call pattern -- ``sim_image(vert, col, ind, params, offsets)`` followed by
+``reverse_proj(img, vert, ind, params, offsets)`` with the SAME arrays (example.py:28,31; :57,59;
+:97,103) -- is served without a second upload: the last mesh stays on the device, keyed by the
+identity of the ``vert`` / ``ind`` arrays plus a content fingerprint (every 1024th row, head and
+tail), and a call that finds it re-renders it; at an unchanged pose only the resolve stage runs
+(the library's visibility cache).  ``MESH_CACHE = False`` (or ``clear_mesh_cache()``) switches it
+off; an in-place edit of a few vertices between two calls is the one thing the fingerprint can
+miss -- call ``clear_mesh_cache()`` after such an edit.
 """
 import math
 import warnings
+import weakref
+import zlib
 
 import numpy as np
 import pandas as pd
 
 from . import _lib
 
+MESH_CACHE = True
+_cache = {"mesh": None, "vert": None, "ind": None, "value": None, "grid": None}
+
+
+def _fingerprint(a):
+    """identity-independent part of a cache key: layout + CRC of every 1024th row, the first and the last 64 rows"""
+    a = np.asarray(a)
+    rows = a.reshape(a.shape[0], -1) if a.ndim > 1 else a.reshape(-1, 1)
+    parts = (rows[::1024], rows[:64], rows[-64:])
+    crc = 0
+    for part in parts:
+        crc = zlib.crc32(np.ascontiguousarray(part).view(np.uint8).reshape(-1), crc)
+    return (a.shape, a.dtype.str, a.strides, a.__array_interface__["data"][0], crc)
+
+
+def _key(a):
+    return None if a is None else (weakref.ref(a), _fingerprint(a))
+
+
+def _same(key, a):
+    if key is None or a is None:
+        return key is None and a is None
+    return key[0]() is a and key[1] == _fingerprint(a)
+
+
+def clear_mesh_cache():
+    """Drop the device-resident mesh kept for the next call (frees its HBM unless a ReverseProjection still
+    holds it)."""
+    _cache.update(mesh=None, vert=None, ind=None, value=None, grid=None)
+
+
+def _resident_mesh(vert, value, ind, grid_shape):
+    """-> (mesh, owned): the device mesh of these arrays, from the cache when the same arrays were rendered last.
+    ``value`` None = the vertices themselves.  ``owned`` meshes are the caller's to close."""
+    cacheable = MESH_CACHE and isinstance(vert, np.ndarray) and (ind is None or isinstance(ind, np.ndarray))
+    if not cacheable:
+        return _lib.Mesh(vert, value, ind, grid_shape), True
+    c = _cache
+    if c["mesh"] is not None and c["mesh"]._h and _same(c["vert"], vert) and _same(c["ind"], ind) and c["grid"] == grid_shape:
+        mesh = c["mesh"]
+        if value is not None and not _same(c["value"], value):
+            mesh.set_value(value)                       # sim_image after reverse_proj: only the colours travel
+            c["value"] = _key(value) if isinstance(value, np.ndarray) else None
+        return mesh, False
+    clear_mesh_cache()                                  # before the new upload: both would not have to fit
+    mesh = _lib.Mesh(vert, value, ind, grid_shape)
+    c.update(mesh=mesh, vert=_key(vert), ind=_key(ind), grid=grid_shape,
+             value=_key(value) if isinstance(value, np.ndarray) else None)
+    return mesh, False
+
 __all__ = ["projection_mat", "modelview_mat", "distort", "persp_proj", "sim_image",
-           "reverse_proj", "reverse_proj_device", "ReverseProjection", "rasterize", "to_geotiff", "Mesh"]
+           "reverse_proj", "reverse_proj_device", "ReverseProjection", "rasterize", "to_geotiff", "Mesh",
+           "clear_mesh_cache", "MESH_CACHE"]
 
 Mesh = _lib.Mesh
 
@@ -91,20 +153,36 @@ def persp_proj(vert, value, ind, params, offsets=None, min_distance=None, *, gri
     vert : (N, 3) vertex coordinates in X, Z(vertical), Y order -- or a ``Mesh`` already on
     the device (then ``value`` and ``ind`` are ignored).
     """
+    mesh, owned = _enqueue(vert, value, ind, params, offsets, min_distance, grid_shape)
+    try:
+        return mesh.fetch()
+    finally:
+        if owned:
+            mesh.close()
+
+
+def _enqueue(vert, value, ind, params, offsets, min_distance, grid_shape):
+    """persp_proj up to the finished frame on the device -> (mesh, owned)"""
     pvec = _params_checked(params)
     if isinstance(vert, _lib.Mesh):
-        return vert.render(pvec, offsets, min_distance)
-    vert = np.asarray(vert)
-    same = value is vert
-    with _lib.Mesh(vert, None if same else value, ind, grid_shape) as mesh:
-        return mesh.render(pvec, offsets, min_distance)
+        vert.render_enqueue(pvec, offsets, min_distance)
+        return vert, False
+    same = value is vert or value is None
+    mesh, owned = _resident_mesh(vert, None if same else value, ind, grid_shape)
+    mesh.render_enqueue(pvec, offsets, min_distance, coords=same)
+    return mesh, owned
 
 
 def sim_image(vert, color, ind, params, offsets=None, min_distance=None, *, grid_shape=None):
-    """Simulated landscape image in OpenCV's BGR uint8 layout (reference project.py:296-325)."""
-    raw = persp_proj(vert, color, ind, params, offsets, min_distance=min_distance, grid_shape=grid_shape) * 255
-    raw = raw.astype(np.uint8)
-    return np.ascontiguousarray(raw[:, :, ::-1])          # cv2.COLOR_RGB2BGR
+    """Simulated landscape image in OpenCV's BGR uint8 layout (reference project.py:296-325): the ``* 255``,
+    ``astype(uint8)`` and RGB -> BGR of :322-324 run on the device (alp_render_fetch_u8), a quarter of the bytes
+    of the float32 image cross PCIe."""
+    mesh, owned = _enqueue(vert, color, ind, params, offsets, min_distance, grid_shape)
+    try:
+        return mesh.fetch_u8(255.0, True)
+    finally:
+        if owned:
+            mesh.close()
 
 
 class ReverseProjection:
@@ -174,7 +252,7 @@ def reverse_proj_device(vert, ind, params, offsets=None, *, grid_shape=None):
     if isinstance(vert, _lib.Mesh):
         mesh, owns = vert, False
     else:
-        mesh, owns = _lib.Mesh(np.asarray(vert), None, ind, grid_shape), True
+        mesh, owns = _resident_mesh(vert, None, ind, grid_shape)
     mesh.render_enqueue(pvec, offsets, None, coords=True)
     return ReverseProjection(mesh, offsets, w, h, owns, pvec)
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ALP_ABI_VERSION 2
+#define ALP_ABI_VERSION 3
 
 /* x,y,z,fov,pan,tilt,roll,a1,a2,k1..k6,p1,p2,s1..s4,w,h,cx,cy */
 #define ALP_NPARAM 25
@@ -187,10 +187,13 @@ int alp_loss_uv(const double *observed, const double *projected, int64_t n, int 
 /* ---------------------------------------------------------------- mesh render --------- */
 /* Device-resident triangle mesh: the vbo/cbo/ibo of src/alproj/project.py:213-215.
  *
- * vert   n_vert x 3 float32, X, Z(up), Y order, relative to `offsets`
- *        (src/alproj/surface.py:189-190, :211).
- * value  n_vert x 3 float32 per-vertex values (colours, or the vertices themselves for
- *        reverse_proj, src/alproj/project.py:360); NULL means value == vert.
+ * vert   n_vert x 3, X, Z(up), Y order, relative to `offsets` (src/alproj/surface.py:189-190,
+ *        :211); vert_dtype ALP_F32, or ALP_F64 -- what get_colored_surface returns: the cast of
+ *        src/alproj/project.py:213 (astype("f4"), round to nearest even) then happens on the
+ *        device during the chunked upload, no float32 copy is made on the host.
+ * value  n_vert x 3 per-vertex values (colours, or the vertices themselves for reverse_proj,
+ *        src/alproj/project.py:360), value_dtype ALP_F32 or ALP_F64 (cast of :214 likewise);
+ *        NULL means value == vert.
  * ind    n_tri x 3 indices (ind_dtype ALP_I32 or ALP_I64), or NULL for the implicit
  *        regular grid of src/alproj/surface.py:194-201 with grid_h x grid_w vertices
  *        (n_vert == grid_h * grid_w; vertex id = row * grid_w + col).
@@ -198,13 +201,20 @@ int alp_loss_uv(const double *observed, const double *projected, int64_t n, int 
  *        vertices removed (src/alproj/surface.py:203-205, order kept), is recognised on the
  *        device and rendered by the grid kernels (same result, no 12 B/triangle index reads);
  *        triangle ids reported by alp_render_fetch_visibility stay positions in `ind`.
+ *        Indices outside [0, n_vert) are rejected (ALP_EINVAL; checked on the device).
+ * (ABI 3: vert_dtype / value_dtype added; ABI 2 took float32 pointers only.)
  */
 typedef struct alp_mesh alp_mesh_t;
 
-int alp_mesh_create(const float *vert, const float *value, int64_t n_vert,
-                    const void *ind, int ind_dtype, int64_t n_tri,
+int alp_mesh_create(const void *vert, int vert_dtype, const void *value, int value_dtype,
+                    int64_t n_vert, const void *ind, int ind_dtype, int64_t n_tri,
                     int64_t grid_h, int64_t grid_w, alp_mesh_t **out);
 int alp_mesh_destroy(alp_mesh_t *mesh);
+
+/* Replace (or, with NULL, drop) the stored per-vertex values of a resident mesh: sim_image's
+ * colours for a mesh that reverse_proj created without any, src/alproj/project.py:214.  The
+ * vertices, the index array and the visibility cache (below) are untouched. */
+int alp_mesh_set_value(alp_mesh_t *mesh, const void *value, int value_dtype);
 
 /* What the following renders interpolate: the stored per-vertex values (sim_image,
  * src/alproj/project.py:321) or the vertices themselves (reverse_proj, project.py:360) -- one
@@ -249,10 +259,25 @@ int alp_mesh_fetch(alp_mesh_t *mesh, float *vert, float *value, uint8_t *valid);
  */
 int alp_render(alp_mesh_t *mesh, const double params[ALP_NPARAM], const double *offsets,
                double min_distance, float *out);
-/* Same but leaves the image on the device (for timing); fetch with alp_render_fetch. */
+/* Same but leaves the image on the device (for timing); fetch with alp_render_fetch.
+ *
+ * Visibility cache: the reference renders the same mesh twice at one pose -- sim_image, then
+ * reverse_proj (example.py:28,31; :57,59; :97,103), each a full GL draw
+ * (src/alproj/project.py:276).  Here a render whose view (camera position and angles, fov,
+ * w, h, offsets) equals the previous frame's on the same mesh and mask reuses that frame's
+ * visibility buffer and runs only the resolve stage; value source, lens coefficients and
+ * min_distance may differ.  Bit-identical to a full frame (the raster passes are
+ * deterministic).  alp_mesh_frame_counts reports how many frames took each way:
+ * counts[0] full, counts[1] resolve only. */
 int alp_render_enqueue(alp_mesh_t *mesh, const double params[ALP_NPARAM],
                        const double *offsets, double min_distance);
 int alp_render_fetch(alp_mesh_t *mesh, float *out);
+int alp_mesh_frame_counts(alp_mesh_t *mesh, int64_t counts[2]);
+/* The last frame as h x w x 3 uint8: (image * scale) cast like numpy's astype(uint8)
+ * (truncation toward zero, wrap), channels reversed when reverse_channels != 0 -- the tail of
+ * sim_image(), src/alproj/project.py:322-324 (scale 255, RGB -> BGR), on the device, so that
+ * 1 B instead of 4 B per channel cross PCIe. */
+int alp_render_fetch_u8(alp_mesh_t *mesh, float scale, int reverse_channels, uint8_t *out);
 /* The 64-bit visibility buffer of the last render, h x w, OpenGL window orientation (row 0 =
  * bottom), before the distortion remap: 0 = background, else (float32 bits of 1/depth) << 32 |
  * (0xFFFFFFFF - index of the winning triangle).  For inspection and parity tests. */
