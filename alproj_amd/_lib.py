@@ -47,6 +47,9 @@ _SIGNATURES = {
     "alp_synchronize": [],
     "alp_event_record": [_c_int],
     "alp_event_elapsed_ms": [_c_int, _c_int, _c_fp],
+    "alp_kernel_timing": [_c_int],
+    "alp_kernel_time_ms": [_c_fp, ctypes.POINTER(_c_int)],
+    "alp_build_flags": [],
     "alp_comm_unique_id": [ctypes.c_char_p],
     "alp_comm_init": [ctypes.c_char_p, _c_int, _c_int],
     "alp_comm_destroy": [],
@@ -93,7 +96,7 @@ _SIGNATURES = {
     "alp_distort_image": [_c_fp, _c_i64, _c_i64, _c_i64, _c_dp, _c_fp],
     "alp_distort_map": [_c_i64, _c_i64, _c_dp, _c_fp, _c_fp],
 }
-_RESTYPE = {"alp_last_error": ctypes.c_char_p}
+_RESTYPE = {"alp_last_error": ctypes.c_char_p, "alp_build_flags": ctypes.c_char_p}
 
 _lock = threading.Lock()
 _lib = None
@@ -532,6 +535,21 @@ def distort_map(h, w, coeffs):
 
 def synchronize():
     check(lib().alp_synchronize())
+
+
+def kernel_timing(enable):
+    check(lib().alp_kernel_timing(int(bool(enable))))
+
+
+def kernel_time_ms():
+    """(sum of the kernel sections since the last call in ms, their number); see alp_kernel_timing"""
+    ms, n = ctypes.c_float(), _c_int()
+    check(lib().alp_kernel_time_ms(ctypes.byref(ms), ctypes.byref(n)))
+    return float(ms.value), int(n.value)
+
+
+def build_flags():
+    return (load().alp_build_flags() or b"").decode()
 
 
 def event_record(slot):

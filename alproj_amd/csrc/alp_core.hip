@@ -53,6 +53,29 @@ int scratch_reserve(size_t bytes, void **out) {
     return ALP_OK;
 }
 
+// ------------------------------------------------------------------ kernel-section timer
+namespace {
+constexpr int KT_MAX = 256;
+struct KTimer {
+    bool on = false;
+    int n = 0;               // sections recorded since the last reset
+    bool open = false;
+    hipEvent_t a[KT_MAX] = {}, b[KT_MAX] = {};
+} g_kt;
+}  // namespace
+
+void ktime_begin() {
+    if (!g_kt.on || g_kt.n >= KT_MAX || g_kt.open) return;
+    if (!g_kt.a[g_kt.n] && (hipEventCreate(&g_kt.a[g_kt.n]) != hipSuccess || hipEventCreate(&g_kt.b[g_kt.n]) != hipSuccess)) return;
+    g_kt.open = hipEventRecord(g_kt.a[g_kt.n], ctx().stream) == hipSuccess;
+}
+
+void ktime_end() {
+    if (!g_kt.open) return;
+    g_kt.open = false;
+    if (hipEventRecord(g_kt.b[g_kt.n], ctx().stream) == hipSuccess) ++g_kt.n;
+}
+
 #define ALP_NCCL(expr)                                                                    \
     do {                                                                                  \
         ncclResult_t r__ = (expr);                                                        \
@@ -196,6 +219,12 @@ int alp_shutdown(void) {
         if (ev) hipEventDestroy(ev);
         ev = nullptr;
     }
+    for (int i = 0; i < KT_MAX; ++i) {
+        if (g_kt.a[i]) hipEventDestroy(g_kt.a[i]);
+        if (g_kt.b[i]) hipEventDestroy(g_kt.b[i]);
+        g_kt.a[i] = g_kt.b[i] = nullptr;
+    }
+    g_kt = KTimer();
     hipStreamDestroy(c.stream);
     c.stream = nullptr;
     c.ready = false;
@@ -215,6 +244,36 @@ int alp_device_info(char *name, int len, int *cu_count, int64_t *hbm_bytes) {
     if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
     return ALP_OK;
 }
+
+int alp_kernel_timing(int enable) {
+    if (int rc = require_init()) return rc;
+    ALP_HIP(hipStreamSynchronize(ctx().stream));
+    g_kt.on = enable != 0;
+    g_kt.n = 0;
+    g_kt.open = false;
+    return ALP_OK;
+}
+
+int alp_kernel_time_ms(float *ms, int *sections) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(ms, "ms is NULL");
+    ALP_HIP(hipStreamSynchronize(ctx().stream));
+    float sum = 0;
+    for (int i = 0; i < g_kt.n; ++i) {
+        float t = 0;
+        ALP_HIP(hipEventElapsedTime(&t, g_kt.a[i], g_kt.b[i]));
+        sum += t;
+    }
+    *ms = sum;
+    if (sections) *sections = g_kt.n;
+    g_kt.n = 0;
+    return ALP_OK;
+}
+
+// Development switches compiled into this library, as a comma-separated list ("" = a release build): the
+// translation units of the render keep timing / census / stage-skipping builds behind ALP_DEV_* macros, several
+// of which produce wrong images by design; tests assert that the shipped library reports none.
+const char *alp_build_flags(void) { return raster_dev_flags(); }
 
 int alp_synchronize(void) {
     if (int rc = require_init()) return rc;

@@ -174,6 +174,7 @@ int alp_mesh_from_rasters(const void *dsm, int dsm_dtype, int64_t rows, int64_t 
     const unsigned long long inf_bits = 0x7FF0000000000000ull;
     hipError_t e = hipMemcpyAsync(zmin_dev, &inf_bits, 8, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
+        KTimeScope kt;
         const dim3 grid((unsigned)(ctx().cu_count * 8));
         if (dsm_dtype == ALP_F32)
             hipLaunchKernelGGL(surface_zmin_kernel<float>, grid, dim3(256), 0, st, (const float *)dsm_dev, (long long)n, z_max, zmin_dev);
@@ -186,6 +187,7 @@ int alp_mesh_from_rasters(const void *dsm, int dsm_dtype, int64_t rows, int64_t 
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return bail(fail(ALP_EHIP, "alp_mesh_from_rasters: %s", hipGetErrorString(e)));
     const dim3 grid((unsigned)((n + 255) / 256));
+    ktime_begin();
 #define ALP_BUILD(Z, A)                                                                                              \
     hipLaunchKernelGGL((surface_build_kernel<Z, A>), grid, dim3(256), 0, st, (const Z *)dsm_dev, (const A *)aer_dev, \
                        (const unsigned char *)nod_dev, (long long)rows, (long long)cols, transform[0], transform[2], \
@@ -200,6 +202,7 @@ int alp_mesh_from_rasters(const void *dsm, int dsm_dtype, int64_t rows, int64_t 
         else ALP_BUILD(double, float);
     }
 #undef ALP_BUILD
+    ktime_end();
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return bail(fail(ALP_EHIP, "alp_mesh_from_rasters: %s", hipGetErrorString(e)));

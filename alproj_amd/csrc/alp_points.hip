@@ -200,8 +200,16 @@ int enqueue_popeval(alp_points *p, const double *cand, int64_t P, int loss_kind,
     const int64_t rows = (p->n + 255) / 256;
     if (rows < nblk) nblk = (int)(rows > 0 ? rows : 1);
     if (int rc = ensure_pop_scratch(p, P, nblk)) return rc;
-    if (!p->ev[0])
-        for (auto &e : p->ev) ALP_HIP(hipEventCreate(&e));
+    if (!p->ev[0]) {            // all three or none: a partial failure must not leave ev[1] / ev[2] NULL for good
+        hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+        for (auto &e : ev)
+            if (hipEventCreate(&e) != hipSuccess) {
+                for (auto &d : ev)
+                    if (d) hipEventDestroy(d);
+                return fail(ALP_EHIP, "hipEventCreate failed");
+            }
+        for (int k = 0; k < 3; ++k) p->ev[k] = ev[k];
+    }
     ALP_HIP(hipEventRecord(p->ev[0], ctx().stream));
     hipLaunchKernelGGL(kernels[which], dim3(nblk), dim3(256), 0, ctx().stream, (const T *)p->x, (const T *)p->y,
                        (const T *)p->z, (const T *)p->uo, (const T *)p->vo, p->n, (const PoseRec<T> *)p->cand_dev,
@@ -284,9 +292,11 @@ int residuals_impl(alp_points *p, const double *cand, int64_t B, double *out) {
     ALP_HIP(hipMemcpyAsync(poses_dev, poses.data(), (size_t)B * sizeof(PoseRec<T>), hipMemcpyHostToDevice, st));
     for (int64_t off = 0; off < p->n; off += chunk) {
         const int64_t cnt = p->n - off < chunk ? p->n - off : chunk;
+        ktime_begin();
         hipLaunchKernelGGL(residual_batch_kernel<T>, dim3(stream_grid(cnt)), dim3(256), 0, st, (const T *)p->x + off,
                            (const T *)p->y + off, (const T *)p->z + off, (const T *)p->uo + off, (const T *)p->vo + off,
                            res_dev, cnt, poses_dev, (int)B);
+        ktime_end();
         ALP_HIP(hipGetLastError());
         // row b of the chunk -> out[b][off .. off + cnt)
         ALP_HIP(hipMemcpy2DAsync(out + 2 * off, (size_t)p->n * sizeof(double2), res_dev, (size_t)cnt * sizeof(double2),
@@ -509,9 +519,9 @@ int alp_eval_population_wait(alp_points_t *p, double *loss_out, int64_t *argmin_
     if (int rc = require_init()) return rc;
     ALP_REQUIRE(p, "points handle is NULL");
     if (p->pending_P <= 0) return fail(ALP_ESTATE, "alp_eval_population_wait: nothing enqueued");
-    ALP_HIP(hipStreamSynchronize(ctx().stream));
     const int64_t P = p->pending_P;
-    p->pending_P = 0;
+    p->pending_P = 0;                  // before the sync: a failed wait must not lock the handle (every later enqueue refused)
+    ALP_HIP(hipStreamSynchronize(ctx().stream));
     const double n_total = p->sums_host[P];
     std::vector<double> local;
     double *loss = loss_out;

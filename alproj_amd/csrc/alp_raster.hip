@@ -52,7 +52,74 @@
 #include <type_traits>
 #include <vector>
 
+// ---- development switches ---------------------------------------------------------------------------------
+// Timing / census / stage-skipping builds used while the kernels were tuned (tools/build_variant.sh; DESIGN.md
+// section 5 quotes their results).  Several produce WRONG IMAGES by design, so none of them can get into a
+// library by accident: each needs -DALP_DEV next to it, the library reports what it was built with through
+// alp_build_flags(), and tests/test_abi_symbols.py requires the shipped one to report nothing.  The development
+// environment overrides (ALP_NEAR_PX, ALP_GRID_LANES, ALP_PATCH_NEAR / _FAR) are read by ALP_DEV builds only.
+// ALP_NO_GRID_DETECT, ALP_QUEUE_CAP, ALP_NO_VIS_CACHE, ALP_NO_TILE_CULL and ALP_NO_OCCLUSION stay: they select
+// between paths that produce the same image and are how the tests reach the index kernels, the queue growth,
+// the full-frame path and the exact path without its culling.
+#if defined(ALP_WG_TIMING) || defined(ALP_RASTER_STATS) || defined(VIS_PLAIN_STORE) || defined(VIS_NEVER) || defined(PARK_NOATOMIC) || \
+    defined(PARKED_SKIP_CELLS) || defined(PARKED_SKIP_COOP) || defined(PARKED_SKIP_COOP4) || defined(GRID_STOP_AFTER) ||               \
+    defined(GRID_NO_XCD_SWIZZLE)
+#define ALP_DEV_SWITCHES 1
+#ifndef ALP_DEV
+#error "development switch given without -DALP_DEV: this would build a library that renders wrong images"
+#endif
+#endif
+#if defined(INLINE_LOG2) || defined(FAST_MAX) || defined(COOP_MIN_W) || defined(COOP_MIN_PIX) || defined(GT_W_LOG2) || defined(GT_H_LOG2) || \
+    defined(HIZ_SPAN) || defined(GRID_WAVES_PER_EU) || defined(PATCH_MIN_FAST) || defined(PATCH_WORDS_NEAR) || defined(PATCH_WORDS_FAR) ||    \
+    defined(RASTER_BLOCKS_PER_CU) || defined(RESOLVE_BLOCKS_PER_CU)
+#define ALP_DEV_TUNABLES 1
+#ifndef ALP_DEV
+#error "tuning parameter overridden without -DALP_DEV"
+#endif
+#endif
+
 namespace alp {
+
+const char *raster_dev_flags() {
+    return ""
+#ifdef ALP_DEV
+           "ALP_DEV,"
+#endif
+#ifdef ALP_DEV_TUNABLES
+           "tunables-overridden,"
+#endif
+#ifdef ALP_WG_TIMING
+           "ALP_WG_TIMING,"
+#endif
+#ifdef ALP_RASTER_STATS
+           "ALP_RASTER_STATS,"
+#endif
+#ifdef VIS_PLAIN_STORE
+           "VIS_PLAIN_STORE(wrong image),"
+#endif
+#ifdef VIS_NEVER
+           "VIS_NEVER(wrong image),"
+#endif
+#ifdef PARK_NOATOMIC
+           "PARK_NOATOMIC(wrong image),"
+#endif
+#if defined(PARKED_SKIP_CELLS) || defined(PARKED_SKIP_COOP) || defined(PARKED_SKIP_COOP4)
+           "PARKED_SKIP_*(wrong image),"
+#endif
+#ifdef GRID_STOP_AFTER
+           "GRID_STOP_AFTER(wrong image),"
+#endif
+#ifdef GRID_NO_XCD_SWIZZLE
+           "GRID_NO_XCD_SWIZZLE,"
+#endif
+        ;
+}
+
+#ifdef ALP_DEV
+static const char *dev_getenv(const char *name) { return getenv(name); }
+#else
+static const char *dev_getenv(const char *) { return nullptr; }
+#endif
 
 constexpr int SUB = 256;                     // sub-pixel units per pixel
 constexpr float COORD_LIMIT = 4194304.0f;    // 2^22 px
@@ -139,8 +206,12 @@ __device__ __forceinline__ void to_view(const View &v, float px, float py, float
 // that range), so the specification's "IEEE division"  is met bit for bit at a
 // third of the ~11 instructions of the generic expansion.  Outside [1, 2^60) the generic division runs.
 __device__ __forceinline__ float exact_rcp_unchecked(float x) {       // x in [1, 2^60) -- or the result is not used
+#if defined(__gfx950__)
     const float y = __builtin_amdgcn_rcpf(x);
     return __builtin_fmaf(y, __builtin_fmaf(-x, y, 1.0f), y);
+#else       // the exhaustive check covers this chip's v_rcp_f32 table only: anywhere else, the division itself
+    return 1.0f / x;
+#endif
 }
 __device__ __forceinline__ float exact_rcp(float x) {
     if (__builtin_expect(!(x >= 1.0f && x < 1.0e18f), 0)) return 1.0f / x;
@@ -970,7 +1041,7 @@ static void make_tile_cull(const View &v, TileCull *c) {
     // cells that project to about a pixel or more: vz < focal length in pixels x cell size
     const double focal_px = std::fmax((double)v.fx * v.sx, (double)v.fy * v.sy);
     double near_px = 0.75;     // measured on the 100 M-vertex frame: 0.5 1.17 ms, 0.75 1.11, 1.0 1.20, 1.5 1.22, 2.5 1.36
-    if (const char *e = getenv("ALP_NEAR_PX")) near_px = atof(e);      // development: where the first round ends
+    if (const char *e = dev_getenv("ALP_NEAR_PX")) near_px = atof(e);      // development: where the first round ends
     c->near_limit = (float)(focal_px * near_px);
     c->enabled = 1;
     c->occlusion = 1;
@@ -1064,13 +1135,18 @@ __global__ __launch_bounds__(256) void tile_plan_kernel(const float *__restrict_
             const float d0 = tb[0] - cull.cam[0], d1 = tb[1] - cull.cam[1], d2 = tb[2] - cull.cam[2];
             const float e0 = tb[3], e1 = tb[4], e2 = tb[5];
             const float a0 = fabsf(d0) + e0, a1 = fabsf(d1) + e1, a2 = fabsf(d2) + e2;
+            // absolute part of the margin: d is a float32 difference of a float32 box centre and the float32-rounded
+            // camera position, each off by up to half an ulp of its MAGNITUDE (0.03 m at coordinates of 1e6 without
+            // offsets), which the margin relative to |d| does not see: 4e-7 (> 3 ulp) of |centre| + |camera|
+            const float g0 = fabsf(tb[0]) + fabsf(cull.cam[0]), g1 = fabsf(tb[1]) + fabsf(cull.cam[1]), g2 = fabsf(tb[2]) + fabsf(cull.cam[2]);
             bool outside = false;
             float vz_min = 0.0f;
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
                 const float sd = cull.n[k][0] * d0 + cull.n[k][1] * d1 + cull.n[k][2] * d2;
                 const float rr = cull.an[k][0] * e0 + cull.an[k][1] * e1 + cull.an[k][2] * e2;
-                const float mg = 1e-5f * (cull.am[k][0] * a0 + cull.am[k][1] * a1 + cull.am[k][2] * a2);
+                const float mg = 1e-5f * (cull.am[k][0] * a0 + cull.am[k][1] * a1 + cull.am[k][2] * a2) +
+                                 4e-7f * (cull.am[k][0] * g0 + cull.am[k][1] * g1 + cull.am[k][2] * g2);
                 if (k < 4) outside = outside || (sd - rr > mg);                 // every point beyond a side plane
                 else {
                     outside = outside || (sd + rr < 1.0f - mg - 1e-5f);        // every point behind the near plane
@@ -1218,7 +1294,12 @@ __global__ __launch_bounds__(256) void tile_occlusion_kernel(const float *__rest
             if (px0 > px1 || py0 > py1) {
                 keep = false;                       // nothing of it can reach the viewport
             } else {
-                const float qmax = (1.0f / zmin) * 1.00002f;    // >= every interpolated float32 1/vz of the tile
+                // >= every interpolated float32 1/vz of the tile: 2e-5 relative, and the box corners' own uncertainty
+                // (float32 centre and camera, see tile_plan_kernel) taken off the depth first
+                const float *tb = tile_bounds + 6ull * t;
+                const float zabs = 4e-7f * (fabsf(cull.R[2][0]) * (fabsf(tb[0]) + fabsf(cull.cam[0])) + fabsf(cull.R[2][1]) * (fabsf(tb[1]) + fabsf(cull.cam[1])) +
+                                            fabsf(cull.R[2][2]) * (fabsf(tb[2]) + fabsf(cull.cam[2])));
+                const float qmax = (1.0f / (zmin - zabs)) * 1.00002f;
                 // the finest level that covers the rectangle with at most HIZ_SPAN x HIZ_SPAN texels; hiz_build_kernel
                 // writes levels 0..3 (8..64 pixels); a rectangle too large even for the top level (rare among FAR
                 // tiles) is kept untested
@@ -2333,7 +2414,7 @@ int ensure_frame(alp_mesh *m, int w, int h) {
 
 // development: ALP_PATCH_NEAR / ALP_PATCH_FAR override the patch sizes (words; 0 switches the patches off)
 static int patch_words_env(const char *name, int dflt) {
-    if (const char *e = getenv(name)) {
+    if (const char *e = dev_getenv(name)) {
         const long w = atol(e);
         if (w >= 0 && w <= 5632) return (int)w;
     }
@@ -2388,12 +2469,25 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
             const int tiles_x = (int)((m->grid_w - 1 + GT_W - 1) / GT_W);
             const long long tiles = (long long)tiles_x * ((m->grid_h - 1 + GT_H - 1) / GT_H);
             if (!m->tile_bounds) {      // once per mesh: the vertices never change
-                ALP_HIP(hipMalloc((void **)&m->tile_bounds, (size_t)tiles * 6 * sizeof(float)));
+                // published only when both allocations and the launch succeeded: a half-made plan must not
+                // make the next frame skip this block and read uninitialised boxes
+                float *tb = nullptr;
+                unsigned *tl = nullptr;
+                hipError_t e = hipMalloc((void **)&tb, (size_t)tiles * 6 * sizeof(float));
                 // three tile lists (near, far, far survivors) + their three counters
-                ALP_HIP(hipMalloc((void **)&m->tile_lists, (size_t)(3 * tiles) * sizeof(unsigned)));
-                hipLaunchKernelGGL(tile_bounds_kernel, dim3((unsigned)tiles), dim3(256), 0, st, m->vert, (int)m->grid_h,
-                                   (int)m->grid_w, tiles_x, m->tile_bounds);
-                ALP_HIP(hipGetLastError());
+                if (e == hipSuccess) e = hipMalloc((void **)&tl, (size_t)(3 * tiles) * sizeof(unsigned));
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL(tile_bounds_kernel, dim3((unsigned)tiles), dim3(256), 0, st, m->vert, (int)m->grid_h,
+                                       (int)m->grid_w, tiles_x, tb);
+                    e = hipGetLastError();
+                }
+                if (e != hipSuccess) {
+                    if (tb) hipFree(tb);
+                    if (tl) hipFree(tl);
+                    return fail(ALP_EHIP, "frame plan of the mesh: %s", hipGetErrorString(e));
+                }
+                m->tile_bounds = tb;
+                m->tile_lists = tl;
             }
             unsigned *near_list = m->tile_lists, *far_list = near_list + tiles, *second_list = far_list + tiles,
                      *counts = fcount + 2 * QC_STRIDE;   // [0] near, [1] far, [2] far survivors (cleared with the queue counters)
@@ -2403,7 +2497,7 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
             if (getenv("ALP_NO_OCCLUSION")) cull.occlusion = 0;   // development: frustum culling only, one round
             // vertices are X, Z, Y: columns step X (R[0][0] on screen x), rows step Y (R[0][2])
             int along_rows = std::fabs(v.R[0][2]) > std::fabs(v.R[0][0]);
-            if (const char *e = getenv("ALP_GRID_LANES")) along_rows = e[0] == 'r';   // development override
+            if (const char *e = dev_getenv("ALP_GRID_LANES")) along_rows = e[0] == 'r';   // development override
             const unsigned plan_grid = (unsigned)((tiles + 255) / 256);
             const unsigned grid_wgs = (unsigned)((tiles + 7) / 8 * 8);     // whole turns of the 8 XCDs (see the kernel's phase 0)
             hipLaunchKernelGGL(tile_plan_kernel, dim3(plan_grid), dim3(256), 0, st, m->tile_bounds, (unsigned)tiles, cull,
@@ -2766,7 +2860,7 @@ int alp_render_enqueue(alp_mesh_t *m, const double params[ALP_NPARAM], const dou
     make_view(params, offsets, &v, &rc);
     if (int e = ensure_frame(m, v.w, v.h)) return e;
     // same view as the frame whose visibility buffer is still there: the raster passes would rebuild it bit for bit
-    static const bool no_cache = getenv("ALP_NO_VIS_CACHE") != nullptr;      // tests: force the full frame
+    const bool no_cache = getenv("ALP_NO_VIS_CACHE") != nullptr;      // tests, benchmarks: force the full frame
     const bool cached = m->vis_current && !no_cache && same_view(v, m->last_v);
     return m->implicit ? render_impl<true>(m, v, rc, min_distance, cached) : render_impl<false>(m, v, rc, min_distance, cached);
 }
@@ -2836,6 +2930,7 @@ int alp_render_gather(alp_mesh_t *m, const int32_t *u, const int32_t *v, int64_t
     hipError_t e = hipMemcpyAsync(u_dev, u, uv_bytes, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(v_dev, v, uv_bytes, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
+        KTimeScope kt;
         hipLaunchKernelGGL(gather_pixels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m->image, m->w,
                            m->h, u_dev, v_dev, n, o0, o1, o2, xyz_dev);
         e = hipGetLastError();
@@ -2864,8 +2959,10 @@ int alp_render_valid_count(alp_mesh_t *m, int64_t *count) {
         m->compact_cap = chunks;
     }
     hipStream_t st = ctx().stream;
+    ktime_begin();
     hipLaunchKernelGGL(valid_count_kernel, dim3(chunks), dim3(256), 0, st, m->image, npix, m->compact_counts);
     hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, st, m->compact_counts, chunks, m->compact_offsets);
+    ktime_end();
     ALP_HIP(hipGetLastError());
     unsigned long long total = 0;
     ALP_HIP(hipMemcpyAsync(&total, m->compact_offsets + chunks, sizeof(total), hipMemcpyDeviceToHost, st));
@@ -2892,8 +2989,10 @@ int alp_render_fetch_valid(alp_mesh_t *m, const double *offsets, uint32_t *idx_o
     unsigned *idx_dev = (unsigned *)(dev + xyz_bytes);
     hipStream_t st = ctx().stream;
     const double o0 = offsets ? offsets[0] : 0.0, o1 = offsets ? offsets[1] : 0.0, o2 = offsets ? offsets[2] : 0.0;
+    ktime_begin();
     hipLaunchKernelGGL(valid_write_kernel, dim3(chunks), dim3(256), 0, st, m->image, npix, m->compact_offsets, o0, o1,
                        o2, idx_dev, xyz_dev);
+    ktime_end();
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(xyz_out, xyz_dev, xyz_bytes, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(idx_out, idx_dev, idx_bytes, hipMemcpyDeviceToHost, st);

@@ -339,6 +339,7 @@ extern "C" int alp_rasterize_points(const double *x, const double *y, const doub
     if (e == hipSuccess) e = hipMemcpyAsync(dv, values, pts_bytes * nb, hipMemcpyHostToDevice, st);
     int rc = ALP_OK;
     if (e == hipSuccess) {
+        KTimeScope kt;
         if (agg == ALP_AGG_MEAN)
             rc = run_rasterize<AGG_MEAN>(dx, dy, dv, n, (int)nb, x_min, y_max, resolution, (int)width, (int)height, sweeps,
                                          nodata, acc, cnt, ra, rb, out_dev);

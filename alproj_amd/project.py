@@ -32,6 +32,7 @@ off; an in-place edit of a few vertices between two calls is the one thing the f
 miss -- call ``clear_mesh_cache()`` after such an edit.
 """
 import math
+import time
 import warnings
 import weakref
 import zlib
@@ -155,22 +156,43 @@ def persp_proj(vert, value, ind, params, offsets=None, min_distance=None, *, gri
     """
     mesh, owned = _enqueue(vert, value, ind, params, offsets, min_distance, grid_shape)
     try:
-        return mesh.fetch()
+        t0 = time.perf_counter()
+        out = mesh.fetch()
+        _fetched(t0)
+        return out
     finally:
         if owned:
             mesh.close()
 
 
-def _enqueue(vert, value, ind, params, offsets, min_distance, grid_shape):
+# where the last call spent its time (seconds on the host; `device_ms` = HIP events around the frame's launches):
+# `mesh_s` cache lookup or upload, `enqueue_s` launches, `fetch_s` wait + copy back, `frame_s` DataFrame construction
+LAST_TIMING = {}
+_EV0, _EV1 = 60, 61              # event slots of the library reserved for these wrappers
+
+
+def _enqueue(vert, value, ind, params, offsets, min_distance, grid_shape, coords=None):
     """persp_proj up to the finished frame on the device -> (mesh, owned)"""
     pvec = _params_checked(params)
+    t0 = time.perf_counter()
     if isinstance(vert, _lib.Mesh):
-        vert.render_enqueue(pvec, offsets, min_distance)
-        return vert, False
-    same = value is vert or value is None
-    mesh, owned = _resident_mesh(vert, None if same else value, ind, grid_shape)
+        mesh, owned, same = vert, False, bool(coords)
+    else:
+        same = value is vert or value is None
+        mesh, owned = _resident_mesh(vert, None if same else value, ind, grid_shape)
+    t1 = time.perf_counter()
+    before = mesh.frame_counts()
+    _lib.event_record(_EV0)
     mesh.render_enqueue(pvec, offsets, min_distance, coords=same)
+    _lib.event_record(_EV1)
+    LAST_TIMING.clear()
+    LAST_TIMING.update(mesh_s=t1 - t0, enqueue_s=time.perf_counter() - t1, resident=not owned and before != (0, 0),
+                       resolve_only=mesh.frame_counts()[1] > before[1])
     return mesh, owned
+
+
+def _fetched(t0):
+    LAST_TIMING.update(fetch_s=time.perf_counter() - t0, device_ms=_lib.event_elapsed_ms(_EV0, _EV1))
 
 
 def sim_image(vert, color, ind, params, offsets=None, min_distance=None, *, grid_shape=None):
@@ -179,7 +201,10 @@ def sim_image(vert, color, ind, params, offsets=None, min_distance=None, *, grid
     of the float32 image cross PCIe."""
     mesh, owned = _enqueue(vert, color, ind, params, offsets, min_distance, grid_shape)
     try:
-        return mesh.fetch_u8(255.0, True)
+        t0 = time.perf_counter()
+        out = mesh.fetch_u8(255.0, True)
+        _fetched(t0)
+        return out
     finally:
         if owned:
             mesh.close()
@@ -222,7 +247,9 @@ class ReverseProjection:
                              f"(array is {array.shape[:2]}, the camera image {(self.h, self.w)})")
         # the x > 0 selection (:369), the x,z,y -> x,y,z reorder (:361) and the offsets (:370-373)
         # happen on the device; only the surviving pixels travel back
+        t0 = time.perf_counter()
         idx, xyz = self._current().fetch_valid(self.offsets)
+        t1 = time.perf_counter()
         w = self.w
         data = {"u": (idx % w).astype("int16"), "v": (idx // w).astype("int16"),
                 "x": xyz[:, 0], "y": xyz[:, 1], "z": xyz[:, 2]}
@@ -230,7 +257,9 @@ class ReverseProjection:
         for k, name in enumerate(chnames):
             data[name] = flat[idx, k].astype(np.float64)
         # the reference filters a RangeIndex-ed frame, so the labels are the linear pixel indices
-        return pd.DataFrame(data, index=pd.Index(idx.astype(np.int64)))
+        df = pd.DataFrame(data, index=pd.Index(idx.astype(np.int64)))
+        LAST_TIMING.update(fetch_s=t1 - t0, frame_s=time.perf_counter() - t1)
+        return df
 
     def close(self):
         if self._owns and self.mesh is not None:
@@ -247,14 +276,9 @@ class ReverseProjection:
 def reverse_proj_device(vert, ind, params, offsets=None, *, grid_shape=None):
     """The render half of ``reverse_proj`` (project.py:360): coordinates of the surface seen by
     every pixel, left on the device as a ``ReverseProjection``."""
-    pvec = _params_checked(params)
     h, w = int(params["h"]), int(params["w"])
-    if isinstance(vert, _lib.Mesh):
-        mesh, owns = vert, False
-    else:
-        mesh, owns = _resident_mesh(vert, None, ind, grid_shape)
-    mesh.render_enqueue(pvec, offsets, None, coords=True)
-    return ReverseProjection(mesh, offsets, w, h, owns, pvec)
+    mesh, owns = _enqueue(vert, None, ind, params, offsets, None, grid_shape, coords=True)
+    return ReverseProjection(mesh, offsets, w, h, owns, _lib.params_vector(params))
 
 
 def reverse_proj(array, vert, ind, params, offsets=None, chnames=["B", "G", "R"], *, grid_shape=None):

@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--no-f64", action="store_true")
     ap.add_argument("--no-10m", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the reference-typed sim_image + reverse_proj call pair (9.6 GB of host arrays)")
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the SURVEY 8(f) rows f1-f4 and the full-size pipeline")
     return ap.parse_args()
 
 
@@ -164,7 +166,7 @@ def parity_report(got, ref, w):
 def pmc_traffic(name):
     """HBM bytes per launch measured with rocprofv3 --pmc in separate passes (FETCH_SIZE x2 on gfx950 +
     WRITE_SIZE, as MI355X_MICROARCH.md prescribes); the newest committed round wins."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         f = os.path.join(PROFILES, f"{rnd}_{name}_pmc_traffic.json")
         if os.path.exists(f):
             try:
@@ -204,6 +206,147 @@ def cma_loop(L, CMA, pts, base, targets, bounds_fn, pop, loss_kind, f_scale, see
     return generation, state
 
 
+def best_of(fn, reps=3):
+    best = 1e30
+    for _ in range(reps):
+        t = time.perf_counter()
+        fn()
+        best = min(best, time.perf_counter() - t)
+    return best
+
+
+def dropin_leg(L, syn, surf, n_side, cam):
+    """The reference's own call pair with the reference's own array types (example.py:28,31; project.py:213-215):
+    sim_image(vert f64, col f64, ind int64, params, offsets), then reverse_proj(sim, vert, ind, params, offsets)."""
+    from alproj_amd import project as aproj
+    n_total = n_side * n_side
+    vert64 = surf["vert"].astype(np.float64)             # get_colored_surface returns float64 (surface.py:189-193)
+    col64 = np.random.default_rng(syn.SEED + 1).random((n_total, 3))
+    ind64 = syn.grid_indices(n_side, np.int64)           # 4.8 GB (docs/usage.md:96)
+    nbytes = vert64.nbytes + col64.nbytes + ind64.nbytes
+    aproj.clear_mesh_cache()
+    rec = {"call": "sim_image(vert f64, col f64, ind int64, params, offsets); reverse_proj(sim, vert, ind, params, offsets)",
+           "vertices": n_total, "host_bytes_of_the_three_arrays": nbytes}
+    t = time.perf_counter()
+    sim = aproj.sim_image(vert64, col64, ind64, cam, surf["offsets"])
+    t_sim = time.perf_counter() - t
+    rec["sim_image"] = dict(aproj.LAST_TIMING, total_s=t_sim)
+    t = time.perf_counter()
+    df = aproj.reverse_proj(sim, vert64, ind64, cam, surf["offsets"])
+    t_rev = time.perf_counter() - t
+    rec["reverse_proj"] = dict(aproj.LAST_TIMING, total_s=t_rev, rows=len(df))
+    # the pair once more, everything resident: what the reference's second and third render pairs cost (example.py:57,59; 97,103)
+    t = time.perf_counter()
+    sim2 = aproj.sim_image(vert64, col64, ind64, cam, surf["offsets"])
+    rec["sim_image_again"] = dict(aproj.LAST_TIMING, total_s=time.perf_counter() - t)
+    assert np.array_equal(sim, sim2)
+    pcie = 56e9                                          # B/s, measured pageable H2D rate of this box class (tools/h2d_rate.hip)
+    rec["first_call_ms"] = t_sim * 1e3
+    rec["first_call_pcie_floor_ms"] = nbytes / pcie * 1e3
+    rec["first_call_over_pcie_floor"] = t_sim / (nbytes / pcie)
+    rec["second_call_device_ms"] = rec["reverse_proj"]["device_ms"]
+    rec["second_call_resolve_only"] = bool(rec["reverse_proj"]["resolve_only"])
+    # what the reference does on the host before its own upload (project.py:213-215), same box, one core (numpy)
+    t = time.perf_counter()
+    a, b, c = vert64.astype("f4"), col64.astype("f4"), ind64.astype("i4")
+    rec["reference_host_casts_s"] = time.perf_counter() - t
+    del a, b, c
+    aproj.clear_mesh_cache()
+    return rec, df, sim
+
+
+def next_rows_leg(L, syn, orc, df):
+    """kernel time from HIP events inside the library (alp_kernel_timing), algorithmic bytes
+    over it against the HBM peak, the numpy port of the reference timed beside it on a bounded sample."""
+    from alproj_amd import project as aproj
+    out = {}
+    L.kernel_timing(True)
+    # ---- f1: residuals of D + 1 = 22 poses over 10 M points, one launch per chunk (optimize.py:215-237, 442-539)
+    n10 = syn.grid_side(10_000_000)
+    s10 = syn.surface(n10)
+    x10 = syn.vert_to_xyz_local(s10["vert"])
+    b10 = syn.local_params(syn.standoff_params(n10), s10["offsets"])
+    t10 = syn.local_params(syn.perturbed(syn.standoff_params(n10)), s10["offsets"])
+    n = len(x10)
+    B = 22
+    with L.Points(x10, [b10["x"], b10["y"], b10["z"]], "f64") as p:
+        p.project(L.params_vector(t10))
+        u, v = p.fetch()
+        p.set_observed(np.stack([u, v], 1) + np.random.default_rng(2).normal(0, 1.0, (n, 2)))
+        cand = np.tile(L.params_vector(b10), (B, 1))
+        cand[:, 4] += np.linspace(-0.5, 0.5, B)            # pan: 22 distinct poses
+        p.residuals_batch(cand)                              # warm-up (scratch, first touch of the output pages)
+        L.kernel_time_ms()
+        t = time.perf_counter()
+        res = p.residuals_batch(cand)
+        wall = time.perf_counter() - t
+        k_ms, sections = L.kernel_time_ms()
+    alg = n * (3 * 8 + 2 * 8) + B * n * 16
+    ns = 1_000_000
+    t_cpu = best_of(lambda: orc.residual_vector(x10[:ns].astype(np.float64), np.zeros((ns, 2)), t10), 2)
+    out["f1_residuals_batch"] = {
+        "points": n, "poses": B, "call_ms_incl_3.5GB_fetch": wall * 1e3, "kernel_ms": k_ms, "kernel_launches": sections,
+        "pose_point_residuals_per_s_kernel": n * B / (k_ms / 1e3),
+        "roofline": {"bound": "hbm", "algorithmic_bytes": alg, "achieved": alg / (k_ms / 1e3) / 1e9, "peak": HBM_PEAK / 1e9,
+                     "unit": "GB/s", "frac": alg / (k_ms / 1e3) / HBM_PEAK, "kernel": "residual_batch_kernel<double>"},
+        "cpu_port": {"pose_point_residuals_per_s": ns / t_cpu, "sample": f"oracle.residual_vector, {ns} points, 1 pose, 1 core"}}
+    del res, x10, s10
+    # ---- f3: mesh construction from rasters at 10 000 x 10 000 (surface.py:173-212)
+    n3 = 10_000
+    rng = np.random.default_rng(3)
+    dsm = (1500 + 200 * np.sin(np.arange(n3, dtype=np.float32) / 300.0)[None, :] * np.cos(np.arange(n3, dtype=np.float32) / 200.0)[:, None]).astype(np.float32)
+    aerial = rng.integers(0, 256, (3, n3, n3), dtype=np.uint8)
+    nodata = np.zeros((n3, n3), dtype=np.uint8)
+    nodata[4000:4040, 3000:3600] = 1
+    tr = (1.0, 0.0, 732000.0, 0.0, -1.0, 4048000.0 + n3)
+    L.kernel_time_ms()
+    t = time.perf_counter()
+    mesh3, off3 = L.Mesh.from_rasters(dsm, tr, 3000.0, aerial, 255.0, nodata)
+    wall = time.perf_counter() - t
+    k_ms, sections = L.kernel_time_ms()
+    mesh3.close()
+    nv = n3 * n3
+    alg = nv * (4 + 3 + 1) + nv * 4 + nv * (12 + 12 + 1)        # build kernel in + z-min pass + vert / value / valid out
+    m = 2000
+    t_cpu = best_of(lambda: orc.colored_surface(aerial[:, :m, :m], dsm[:m, :m].astype(np.float64), tr, nodata[:m, :m].astype(bool), np.uint8), 2)
+    out["f3_mesh_from_rasters"] = {
+        "vertices": nv, "call_ms_incl_upload": wall * 1e3, "kernel_ms": k_ms, "kernel_sections": sections,
+        "gvertices_per_s_kernel": nv / (k_ms / 1e3) / 1e9,
+        "roofline": {"bound": "hbm", "algorithmic_bytes": alg, "achieved": alg / (k_ms / 1e3) / 1e9, "peak": HBM_PEAK / 1e9,
+                     "unit": "GB/s", "frac": alg / (k_ms / 1e3) / HBM_PEAK, "kernel": "surface_zmin_kernel + surface_build_kernel"},
+        "cpu_port": {"gvertices_per_s": m * m / t_cpu / 1e9, "sample": f"oracle.colored_surface on a {m}x{m} corner (incl. the index array the reference builds), 1 core"}}
+    del dsm, aerial, nodata
+    # ---- f2: to_geotiff's compute on the reverse_proj table of the 100 M-vertex frame (project.py:434-485)
+    if df is not None:
+        f2 = {"points": len(df), "resolution_m": 1.0, "bands": 3}
+        for agg in ("mean", "median"):
+            aproj.rasterize(df, 1.0, ["B", "G", "R"], True, 1.0, agg)          # warm-up
+            L.kernel_time_ms()
+            t = time.perf_counter()
+            raster, bounds = aproj.rasterize(df, 1.0, ["B", "G", "R"], True, 1.0, agg)
+            wall = time.perf_counter() - t
+            k_ms, _ = L.kernel_time_ms()
+            total = raster.size
+            npts = len(df)
+            alg = npts * (16 + 8 * 3) + total * (2 * 12 + 2 * 8 + 1) if agg == "mean" else None
+            f2[agg] = {"call_ms_incl_transfers": wall * 1e3, "kernel_ms": k_ms, "raster": list(raster.shape),
+                       "mpoints_per_s_kernel": npts / (k_ms / 1e3) / 1e6}
+            if alg:
+                f2[agg]["roofline"] = {"bound": "hbm", "algorithmic_bytes": alg, "achieved": alg / (k_ms / 1e3) / 1e9, "peak": HBM_PEAK / 1e9,
+                                       "unit": "GB/s", "frac": alg / (k_ms / 1e3) / HBM_PEAK,
+                                       "kernel": "rz_scatter_kernel (float64 atomics) + finalize + focal sweep + uint8"}
+        # numpy / pandas port of the reference on a 600 m x 600 m window of the same table (its 3x3 focal pass is a Python lambda per pixel)
+        x0, y0 = df["x"].min(), df["y"].median()
+        win = df[(df["x"] < x0 + 600) & (np.abs(df["y"] - y0) < 300)]
+        if len(win) > 1000:
+            t_cpu = best_of(lambda: orc.rasterize_points(win["x"].to_numpy(), win["y"].to_numpy(), win[["B", "G", "R"]].to_numpy(dtype=np.float64),
+                                                         1.0, True, 1.0, "mean"), 1)
+            f2["cpu_port"] = {"mpoints_per_s": len(win) / t_cpu / 1e6, "sample": f"oracle.rasterize_points (mean) on the {len(win)} rows of a 600 x 600 m window, 1 core"}
+        out["f2_rasterize_points"] = f2
+    L.kernel_timing(False)
+    return out
+
+
 def main():
     args = parse()
     ctl = Control()
@@ -230,6 +373,17 @@ def main():
     adist.init_comm(ctl.rank, ctl.world, ctl.bcast_bytes, ctl.local_rank)
     info = L.device_info()
     comm_rank, comm_world = L.comm_info()
+    # the communicator the LIBRARY reports must be the job: a rank that fell back to a world of its own would add
+    # nothing to the all-reduce and the line would still look plausible
+    print(f"bench.py: rank {ctl.rank}/{ctl.world} on device {ctl.local_rank}: rccl rank {comm_rank} of {comm_world}",
+          file=sys.stderr, flush=True)
+    if comm_world != args.gpus or comm_rank != ctl.rank:
+        print(f"bench.py: RCCL communicator has {comm_world} ranks (this one is {comm_rank}) but --gpus is {args.gpus}",
+              file=sys.stderr, flush=True)
+        sys.exit(3)
+    if L.build_flags():
+        print(f"bench.py: libalproj_hip.so was built with development switches: {L.build_flags()}", file=sys.stderr)
+        sys.exit(4)
 
     # ---------------------------------------------------------------- workload
     n_side = syn.grid_side(args.vertices)
@@ -439,7 +593,14 @@ def main():
             L.synchronize()
             t_mesh = time.perf_counter() - t_mesh        # upload of the mesh + the first frame (incl. one-off tile bounds)
             os.environ.pop("ALP_NO_GRID_DETECT", None)
+            # every timed frame is DRAWN: the library would serve a repeated view from the previous frame's
+            # visibility buffer (reported separately as `same_view_again_ms`)
+            os.environ["ALP_NO_VIS_CACHE"] = "1"
             wall_r, dev_r = timed(ctl, L, lambda: mesh.render_enqueue(pv_cam, surf["offsets"]), k_r, 2)
+            os.environ.pop("ALP_NO_VIS_CACHE", None)
+            full_before = mesh.frame_counts()
+            wall_c, dev_c = timed(ctl, L, lambda: mesh.render_enqueue(pv_cam, surf["offsets"]), k_r, 1)
+            assert mesh.frame_counts() == (full_before[0], full_before[1] + k_r + 1)
             img = mesh.fetch()
             # algorithmic bytes per frame: vertices 12 B (value == vert), indices 12 B per
             # triangle when explicit, visibility 8 B written + 8 B read per pixel, 12 B per pixel out
@@ -451,6 +612,8 @@ def main():
                 "gvertices_per_s": n_total / (wall_r / k_r) / 1e9, "frames_timed": k_r, "triangles": n_tri_v,
                 "covered_fraction": float((img[:, :, 0] > 0).mean()),
                 "upload_inclusive_ms_first_frame": t_mesh * 1e3,
+                # the same view again (sim_image then reverse_proj, example.py:28,31): resolve stage alone
+                "same_view_again_ms": wall_c / k_r * 1e3, "same_view_again_device_ms": dev_c / k_r,
                 "roofline": {"bound": "hbm", "achieved": alg / (dev_r / k_r / 1e3) / 1e9, "peak": HBM_PEAK / 1e9,
                              "unit": "GB/s", "frac": alg / (dev_r / k_r / 1e3) / HBM_PEAK,
                              "algorithmic_bytes_per_frame": alg,
@@ -461,10 +624,49 @@ def main():
             }
             if not explicit:     # also with the distorted ground-truth pose (remap stage on)
                 pv_dist = L.params_vector(syn.truth_params(n_side))
+                os.environ["ALP_NO_VIS_CACHE"] = "1"
                 wall_d, dev_d = timed(ctl, L, lambda: mesh.render_enqueue(pv_dist, surf["offsets"]), k_r, 2)
+                os.environ.pop("ALP_NO_VIS_CACHE", None)
                 out["raster"][name]["distorted_pose_ms_per_frame"] = wall_d / k_r * 1e3
             mesh.close()
             del img, ind
+
+    # ---------------------------------------------------------------- the reference-typed call pair (1 GPU)
+    df_full = None
+    if ctl.world == 1 and not args.no_dropin and not args.no_raster:
+        out["dropin_call"], df_full, _sim = dropin_leg(L, syn, surf, n_side, syn.base_params(n_side))
+        # f4: set_gcp's gather of 1 127 GCPs from the resident coordinate image (gcp.py:644-648)
+        from alproj_amd import project as aproj
+        with aproj.reverse_proj_device(surf["vert"], None, syn.base_params(n_side), surf["offsets"], grid_shape=(n_side, n_side)) as rp:
+            pick = df_full.iloc[:: max(1, len(df_full) // 1127)][:1127]
+            uu, vv = pick["u"].to_numpy(), pick["v"].to_numpy()
+            rp.lookup(uu, vv)
+            L.kernel_timing(True)
+            t_g = best_of(lambda: rp.lookup(uu, vv), 5)
+            k_ms, k_n = L.kernel_time_ms()
+            L.kernel_timing(False)
+            t_join = None
+            if len(df_full) < 30_000_000:
+                import pandas as pd
+                m_df = pd.DataFrame({"u_org": uu, "v_org": vv, "u_sim": uu, "v_sim": vv})
+                t_join = best_of(lambda: pd.merge(m_df, df_full, how="left", left_on=["u_sim", "v_sim"], right_on=["u", "v"]), 1)
+            out["f4_set_gcp_gather"] = {"gcps": len(uu), "call_ms": t_g * 1e3, "kernel_ms": k_ms / max(k_n, 1),
+                                        "reference_merge_with_the_table_ms_same_box": None if t_join is None else t_join * 1e3,
+                                        "note": "launch-latency bound: 1127 x 12 B gathered"}
+        aproj.clear_mesh_cache()
+    if ctl.world == 1 and not args.no_next_rows:
+        out["next_rows"] = next_rows_leg(L, syn, orc, df_full)
+        del df_full
+        # the whole pipeline of examples/pipeline_synthetic.py (= the reference's example.py) at the reference's sizes:
+        # 5616 x 3744 image, 6000 x 6000 = 36 M-vertex surface (distance 3000 m at 1 m, example.py:22,25)
+        sys.path.insert(0, os.path.join(ROOT, "examples"))
+        import pipeline_synthetic as pipe
+        t_p = time.perf_counter()
+        r = pipe.run(n=6000, w=5616, h=3744, generations=150, verbose=False)
+        out["pipeline_full_size"] = {"vertices": 36_000_000, "image": "5616x3744", "total_s": time.perf_counter() - t_p,
+                                     "stage_ms": {k: v * 1e3 for k, v in r["times"].items()}, "gcps": list(r["gcps"]),
+                                     "reproj_px_initial": r["reproj_px_initial"], "reproj_px_final": r["reproj_px_final"],
+                                     "georectified_rows": r["georectified_rows"], "raster_shape": list(r["raster_shape"])}
 
     # ---------------------------------------------------------------- GCP-scale optimiser (1 GPU)
     # the reference's own problem size: 1127 GCPs, pop 50, D = 9, 300 generations, Huber f = 10

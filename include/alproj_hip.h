@@ -83,6 +83,18 @@ int alp_synchronize(void);
 int alp_event_record(int slot);
 int alp_event_elapsed_ms(int slot_start, int slot_stop, float *ms); /* synchronises on stop */
 
+/* Kernel-section timer.  The entry points that mix kernels with PCIe copies (alp_residuals_batch,
+ * alp_rasterize_points, alp_mesh_from_rasters, alp_render_gather, alp_render_valid_count /
+ * _fetch_valid) bracket their kernel sections with HIP events on the library stream while the
+ * timer is on; alp_kernel_time_ms returns (and clears) the sum over the sections since the last
+ * call and their number.  For bench.py's per-kernel roofline figures; off by default. */
+int alp_kernel_timing(int enable);
+int alp_kernel_time_ms(float *ms, int *sections);
+
+/* Development switches this library was compiled with, comma separated; "" for a release build
+ * (see the top of csrc/alp_raster.hip: several of them render wrong images by design). */
+const char *alp_build_flags(void);
+
 /* ---------------------------------------------------------------- multi-GPU (RCCL) ---- */
 /* One process per GPU.  Rank 0 calls alp_comm_unique_id and ships the 128 bytes to the
  * other ranks by any means (the Python side uses the torchrun rendezvous); every rank then
@@ -149,6 +161,10 @@ int alp_residuals_batch(alp_points_t *pts, const double *cand, int64_t B, double
  * argmin_out index of the smallest loss, first index on ties, NaN never wins unless all
  *           are NaN (then 0) -- the contract of solutions[0] after CMA.tell's stable sort,
  *           src/alproj/optimize.py:424-427.
+ * Float32 point sets: when other losses lie within 5e-5 (relative) of the smallest, up to 16
+ * of those candidates are evaluated again in float64 arithmetic on the stored points before
+ * the index is returned (the north star's "argmin bit-exact"); loss_out then holds the
+ * float64 re-evaluations for THOSE candidates and the float32-path losses for all others.
  */
 int alp_eval_population(alp_points_t *pts, const double *cand, int64_t P, int loss_kind,
                         double f_scale, double *loss_out, int64_t *argmin_out);

@@ -40,7 +40,7 @@ def test_ctypes_table_matches_header():
     assert sorted(_lib._SIGNATURES) == header_functions()
     lib = _lib.load()
     version = int(re.search(r"#define ALP_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
-    assert lib.alp_abi_version() == version == 2
+    assert lib.alp_abi_version() == version == 3
 
 
 def test_header_cites_reference_for_each_entry_point():
@@ -88,3 +88,16 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "oracle/" not in text, f
+
+
+def test_shipped_library_has_no_development_switch():
+    """the render translation unit keeps timing / census / stage-skipping builds, several of which draw wrong images
+    by design, behind -DALP_DEV; the library the tests and the bench load must have been compiled with none"""
+    from alproj_amd import _lib
+    assert _lib.build_flags() == ""
+    src = open(os.path.join(ROOT, "alproj_amd", "csrc", "alp_raster.hip")).read()
+    head = src[:src.index("namespace alp {")]
+    for switch in re.findall(r"#\s*if(?:def|ndef)?\s+(?:defined\()?([A-Z][A-Z0-9_]+)", src):
+        if switch.startswith(("ALP_DEV", "__")):
+            continue
+        assert switch in head, f"{switch} is used in alp_raster.hip but not listed in its development-switch guard"

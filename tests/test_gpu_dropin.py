@@ -1,0 +1,175 @@
+"""GPU: the reference-typed call path (project.py:213-215: float64 vert / value, int64 ind from
+surface.py:189-201) and the reference's call pattern (example.py:28,31: sim_image, then reverse_proj with the
+same arrays at the same pose) through the C ABI: typed uploads cast on the device, the visibility cache of
+alp_render_enqueue, the resident-mesh cache of alproj_amd.project."""
+import numpy as np
+import pytest
+
+from oracle import raster as orast
+
+pytestmark = pytest.mark.gpu
+LENS = dict(a1=1.02, a2=0.98, k1=-0.05, k2=0.01, p1=1e-3, p2=-2e-3)
+
+
+@pytest.fixture(scope="module")
+def L():
+    from alproj_amd import _lib
+    _lib.init(0)
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def scene():
+    from alproj_amd import synthetic as syn
+    n = 260
+    s = syn.surface(n)
+    p = dict(syn.base_params(n), w=512, h=340, cx=256.0, cy=170.0, tilt=-9.0)
+    rng = np.random.default_rng(5)
+    vert64 = s["vert"].astype(np.float64) + rng.uniform(-1e-4, 1e-4, s["vert"].shape)    # not float32-representable
+    col64 = rng.random((n * n, 3))
+    return dict(n=n, vert64=vert64, col64=col64, ind64=syn.grid_indices(n, np.int64), offsets=s["offsets"], params=p)
+
+
+def test_float64_int64_mesh_is_cast_on_the_device(L, scene):
+    """alp_mesh_create(ALP_F64, ALP_F64, ALP_I64) == the reference's astype("f4") / astype("i4") then the float32 path"""
+    v32, c32 = scene["vert64"].astype(np.float32), scene["col64"].astype(np.float32)
+    pv = L.params_vector(scene["params"])
+    with L.Mesh(scene["vert64"], scene["col64"], scene["ind64"]) as a, L.Mesh(v32, c32, scene["ind64"].astype(np.int32)) as b:
+        va, ca, _ = a.fetch_arrays()
+        np.testing.assert_array_equal(va, v32)
+        np.testing.assert_array_equal(ca, c32)
+        for coords in (False, True):
+            a.render_enqueue(pv, scene["offsets"], coords=coords)
+            b.render_enqueue(pv, scene["offsets"], coords=coords)
+            np.testing.assert_array_equal(a.fetch_visibility(), b.fetch_visibility())
+            np.testing.assert_array_equal(a.fetch(), b.fetch())
+    # other dtypes go through float64 (numpy semantics of astype("f4") on them)
+    with L.Mesh(scene["vert64"].astype(np.float16), None, None, grid=(scene["n"], scene["n"])) as h:
+        np.testing.assert_array_equal(h.fetch_arrays()[0], scene["vert64"].astype(np.float16).astype(np.float32))
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.int64])
+def test_out_of_range_indices_are_rejected_on_the_device(L, scene, dtype):
+    ind = scene["ind64"][:1000].astype(dtype).copy()
+    ind[777, 1] = scene["n"] ** 2
+    with pytest.raises(L.AlprojHipError, match=r"index \d+ out of range at 2332"):
+        L.Mesh(scene["vert64"], None, ind)
+    ind[777, 1] = -1
+    with pytest.raises(L.AlprojHipError, match="index -1 out of range at 2332"):
+        L.Mesh(scene["vert64"], None, ind)
+
+
+def test_visibility_cache_serves_the_same_view_by_the_resolve_alone(L, scene):
+    """same view -> only resolve_kernel runs; value source, lens coefficients and min_distance may change; the frame
+    equals that of a fresh mesh bit for bit; a new view, a new mask or a loaded image invalidate"""
+    p = scene["params"]
+    grid = (scene["n"], scene["n"])
+    off = scene["offsets"]
+
+    def fresh(pp, coords, md=None, valid=None):
+        with L.Mesh(scene["vert64"], scene["col64"], None, grid) as f:
+            if valid is not None:
+                f.set_valid(valid)
+            f.render_enqueue(L.params_vector(pp), off, md, coords=coords)
+            assert f.frame_counts() == (1, 0)
+            return f.fetch_visibility(), f.fetch()
+
+    with L.Mesh(scene["vert64"], scene["col64"], None, grid) as m:
+        steps = [(p, False, None), (p, True, None), (dict(p, **LENS), False, None), (p, True, 80.0), (dict(p, cx=10.0, cy=7.0), False, None)]
+        for k, (pp, coords, md) in enumerate(steps):
+            m.render_enqueue(L.params_vector(pp), off, md, coords=coords)
+            assert m.frame_counts() == (1, k), (k, m.frame_counts())           # cx, cy do not enter the GL view (quirk Q11)
+            vis, img = fresh(pp, coords, md)
+            np.testing.assert_array_equal(m.fetch_visibility(), vis)
+            np.testing.assert_array_equal(m.fetch(), img)
+        full = 1
+        for change in (dict(pan=p["pan"] + 0.25), dict(x=p["x"] + 1e-3), dict(fov=p["fov"] - 1), dict(w=500)):
+            pp = dict(p, **change)
+            m.render_enqueue(L.params_vector(pp), off, coords=True)
+            full += 1
+            assert m.frame_counts()[0] == full, change
+            np.testing.assert_array_equal(m.fetch(), fresh(pp, True)[1])
+        pp = dict(p, w=500)
+        # same parameters but other offsets = another camera position relative to the mesh
+        m.render_enqueue(L.params_vector(pp), off + np.array([0.5, 0, 0]), coords=True)
+        assert m.frame_counts()[0] == full + 1
+        m.render_enqueue(L.params_vector(pp), off + np.array([0.5, 0, 0]), coords=False)
+        assert m.frame_counts() == (full + 1, len(steps))
+        # a new mask: the cached visibility no longer belongs to the mesh
+        valid = np.ones(scene["n"] ** 2, dtype=np.uint8)
+        valid.reshape(grid)[100:140, 60:200] = 0
+        m.set_valid(valid)
+        m.render_enqueue(L.params_vector(pp), off + np.array([0.5, 0, 0]), coords=False)
+        assert m.frame_counts() == (full + 2, len(steps))
+        with L.Mesh(scene["vert64"], scene["col64"], None, grid) as f:
+            f.set_valid(valid)
+            f.render_enqueue(L.params_vector(pp), off + np.array([0.5, 0, 0]), coords=False)
+            np.testing.assert_array_equal(m.fetch_visibility(), f.fetch_visibility())
+            np.testing.assert_array_equal(m.fetch(), f.fetch())
+        # an installed image has no visibility: the next render is a full one
+        m.load_image(np.zeros((pp["h"], pp["w"], 3), np.float32))
+        m.render_enqueue(L.params_vector(pp), off + np.array([0.5, 0, 0]), coords=False)
+        assert m.frame_counts()[0] == full + 3
+
+
+def test_visibility_cache_survives_a_queue_overflow(L, scene, monkeypatch):
+    """first frame overflows its (tiny) queues and is not fetched; the second, resolve-only frame must still be the
+    full result: finish_frame grows the queues and redoes the raster passes"""
+    monkeypatch.setenv("ALP_QUEUE_CAP", "16")
+    p = dict(scene["params"], z=scene["params"]["z"] - 48.5, tilt=-20.0)       # near-plane crossings, large triangles
+    grid = (scene["n"], scene["n"])
+    with L.Mesh(scene["vert64"], scene["col64"], None, grid) as m:
+        m.render_enqueue(L.params_vector(p), scene["offsets"], coords=False)
+        m.render_enqueue(L.params_vector(p), scene["offsets"], coords=True)
+        vis, img = m.fetch_visibility(), m.fetch()
+    monkeypatch.delenv("ALP_QUEUE_CAP")
+    v32 = scene["vert64"].astype(np.float32)
+    np.testing.assert_array_equal(vis, orast.visibility(v32, None, p, scene["offsets"], grid=grid))
+    np.testing.assert_allclose(img, orast.render(v32, None, None, p, scene["offsets"], grid=grid), rtol=1e-6, atol=1e-6)
+
+
+def test_reference_call_pattern_keeps_the_mesh_resident(L, scene):
+    """example.py:28,31 with the reference's array types: the second call finds the first call's mesh (no upload),
+    renders by the resolve alone, and returns what the uncached path returns"""
+    from alproj_amd import project as aproj
+    p, off = scene["params"], scene["offsets"]
+    vert, col, ind = scene["vert64"], scene["col64"], scene["ind64"]
+    aproj.clear_mesh_cache()
+    sim = aproj.sim_image(vert, col, ind, p, off)
+    mesh = aproj._cache["mesh"]
+    assert mesh is not None and mesh.frame_counts() == (1, 0)
+    df = aproj.reverse_proj(sim, vert, ind, p, off)
+    assert aproj._cache["mesh"] is mesh and mesh.frame_counts() == (1, 1)
+    raw = aproj.persp_proj(vert, col, ind, dict(p, **LENS), off, min_distance=40.0)
+    assert aproj._cache["mesh"] is mesh and mesh.frame_counts() == (1, 2)
+    # reverse_proj first, sim_image second: only the colours are uploaded
+    aproj.clear_mesh_cache()
+    df2 = aproj.reverse_proj(sim, vert, ind, p, off)
+    mesh2 = aproj._cache["mesh"]
+    assert mesh2 is not mesh and not mesh2.has_value
+    sim2 = aproj.sim_image(vert, col, ind, p, off)
+    assert aproj._cache["mesh"] is mesh2 and mesh2.has_value and mesh2.frame_counts() == (1, 1)
+    np.testing.assert_array_equal(sim2, sim)
+    assert df2.equals(df)
+    # the uncached path
+    aproj.clear_mesh_cache()
+    aproj.MESH_CACHE = False
+    try:
+        np.testing.assert_array_equal(aproj.sim_image(vert, col, ind, p, off), sim)
+        assert aproj._cache["mesh"] is None
+        assert aproj.reverse_proj(sim, vert, ind, p, off).equals(df)
+        np.testing.assert_array_equal(aproj.persp_proj(vert, col, ind, dict(p, **LENS), off, min_distance=40.0), raw)
+    finally:
+        aproj.MESH_CACHE = True
+    # other arrays with the same content are another mesh; an edit of the array is noticed by the fingerprint
+    sim3 = aproj.sim_image(vert, col, ind, p, off)
+    first = aproj._cache["mesh"]
+    aproj.sim_image(vert.copy(), col, ind, p, off)
+    assert aproj._cache["mesh"] is not first
+    moved = vert.copy()
+    aproj.sim_image(moved, col, ind, p, off)
+    held = aproj._cache["mesh"]
+    moved[:, 1] += 25.0
+    sim4 = aproj.sim_image(moved, col, ind, p, off)
+    assert aproj._cache["mesh"] is not held and (sim4 != sim3).any()
+    aproj.clear_mesh_cache()

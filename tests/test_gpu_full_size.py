@@ -35,10 +35,17 @@ def test_render_100m_bit_exact_and_idempotent(L, dsm):
         m.render_enqueue(pv, s["offsets"])
         vis = m.fetch_visibility()
         img = m.fetch()
-        m.render_enqueue(pv, s["offsets"])
+        import os
+        os.environ["ALP_NO_VIS_CACHE"] = "1"            # draw the same view again (not the cached visibility)
+        try:
+            m.render_enqueue(pv, s["offsets"])
+        finally:
+            del os.environ["ALP_NO_VIS_CACHE"]
+        assert m.frame_counts() == (2, 0)
         np.testing.assert_array_equal(m.fetch_visibility(), vis)
         pd_ = dict(p, k1=-0.05, k2=0.01, a1=1.02, a2=0.98, p1=1e-3, p2=-2e-3)
         m.render_enqueue(L.params_vector(pd_), s["offsets"])
+        assert m.frame_counts() == (2, 1)               # same view, other lens: the resolve alone
         np.testing.assert_array_equal(m.fetch_visibility(), vis)        # the remap happens after visibility
         dist = m.fetch()
     ref = orast.visibility(s["vert"], None, p, s["offsets"], grid=(n, n))

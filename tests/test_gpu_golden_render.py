@@ -48,6 +48,26 @@ def test_g12_reverse_proj_post_processing_on_the_device(L, tag, otag):
         assert np.isnan(rp.lookup([0], [0])).all()            # raw[0, 0] has x == 0: not in the table
 
 
+def test_g12_sim_image_tail_on_the_device(L):
+    """the reference's sim_image ran unmodified on a seeded colour render (g12): alp_render_fetch_u8 on the same
+    frame returns the same bytes; values outside [0, 1] (never produced by get_colored_surface, surface.py:66)
+    wrap like numpy's astype(uint8) on x86-64"""
+    g = load("g12_wrappers.npz")
+    raw = g["sim_raw"]
+    vert = np.array([[0, 0, 0], [1, 0, 0], [0, 0, 1], [1, 0, 1]], dtype=np.float32)
+    with L.Mesh(vert, None, None, grid=(2, 2)) as m:
+        m.load_image(raw)
+        out = m.fetch_u8(255.0, True)
+        assert out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"]
+        np.testing.assert_array_equal(out, g["sim_bgr"])
+        wild = np.array([[[-0.01, 1.004, 2.5], [300.7, -1.2, 0.5], [np.nan, 1e12, -1e12]]], dtype=np.float32)
+        m.load_image(wild)
+        x = wild * np.float32(255)
+        ok = np.isfinite(x) & (np.abs(x) < 2.0**31)
+        expect = np.where(ok, np.trunc(np.where(ok, x, 0)).astype(np.int64) & 0xFF, 0).astype(np.uint8)
+        np.testing.assert_array_equal(m.fetch_u8(255.0, False), expect)
+
+
 @pytest.mark.parametrize("size", SIZES)
 @pytest.mark.parametrize("name", COEFFS)
 def test_g13_distort_map_on_the_device(L, name, size):

@@ -125,6 +125,7 @@ def test_queue_growth_redoes_the_frame(L, scene, monkeypatch):
     n = scene["n"]
     ref = orast.visibility(scene["vert"], None, p, scene["offsets"], grid=(n, n))
     monkeypatch.setenv("ALP_QUEUE_CAP", "8")
+    monkeypatch.setenv("ALP_NO_VIS_CACHE", "1")        # the second frame is drawn again, not served from the first one's visibility
     for kw in (dict(ind=None, grid=(n, n)), dict(ind=scene["ind"].astype(np.int32), grid=None)):
         if kw["ind"] is not None:
             monkeypatch.setenv("ALP_NO_GRID_DETECT", "1")
@@ -531,11 +532,15 @@ def test_random_poses_culling_and_occlusion_stay_exact(L, seed):
                 tri_ref = 0xFFFFFFFF - (ref[hit] & np.uint64(0xFFFFFFFF)).astype(np.int64)
                 np.testing.assert_array_equal(tri_dev, keep[tri_ref])
             os.environ["ALP_NO_TILE_CULL"] = "1"
+            os.environ["ALP_NO_VIS_CACHE"] = "1"          # same view again: really draw it again
             try:
+                full = m.frame_counts()[0]
                 m.render_enqueue(pv, None)
+                assert m.frame_counts()[0] == full + 1
                 np.testing.assert_array_equal(m.fetch_visibility(), got)
             finally:
                 os.environ.pop("ALP_NO_TILE_CULL", None)
+                os.environ.pop("ALP_NO_VIS_CACHE", None)
 
 
 @pytest.mark.parametrize("seed", range(8))
@@ -585,8 +590,43 @@ def test_mid_field_frames_with_depth_patches_stay_exact(L, seed):
                                           keep[0xFFFFFFFF - (ref[hit] & np.uint64(0xFFFFFFFF)).astype(np.int64)])
         for env in ("ALP_NO_TILE_CULL", "ALP_NO_OCCLUSION"):
             os.environ[env] = "1"
+            os.environ["ALP_NO_VIS_CACHE"] = "1"          # same view again: really draw it again
             try:
+                full = m.frame_counts()[0]
                 m.render_enqueue(pv, None)
+                assert m.frame_counts()[0] == full + 1
                 np.testing.assert_array_equal(m.fetch_visibility(), got)
             finally:
                 os.environ.pop(env, None)
+                os.environ.pop("ALP_NO_VIS_CACHE", None)
+
+
+@pytest.mark.parametrize("pan", [95.0, 200.0, 318.0])
+def test_unoffset_utm_scale_coordinates_stay_exact(L, pan):
+    """vertices and camera at UTM magnitude WITHOUT offsets (float32 ulp 0.06 ... 0.5 m): the tile culling's and the
+    occlusion test's margins carry an absolute term for the rounding of the float32 box centres and camera position,
+    so the culled frame still equals the frozen oracle's and the frame drawn without culling"""
+    from alproj_amd import synthetic as syn
+    n = 700
+    s = syn.surface(n, res=4.0)
+    vert = s["vert"].astype(np.float64)
+    vert[:, 0] += 732000.0
+    vert[:, 2] += 4048000.0
+    vert = vert.astype(np.float32)                          # quantised to the float32 grid at that magnitude
+    p = dict(syn.base_params(n, 4.0), w=800, h=533, cx=400.0, cy=266.5, pan=pan, tilt=-6.0)
+    p.update(x=float(vert[n * (n // 2) + n // 3, 0]), y=float(vert[n * (n // 2) + n // 3, 2]), z=float(vert[n * (n // 2) + n // 3, 1]) + 35.0)
+    ref = orast.visibility(vert, None, p, None, grid=(n, n))
+    assert (ref != 0).mean() > 0.2
+    with L.Mesh(vert, None, None, grid=(n, n)) as m:
+        m.render_enqueue(L.params_vector(p), None)
+        got = m.fetch_visibility()
+        assert_vis_equal(got, ref)
+        for env in ("ALP_NO_TILE_CULL", "ALP_NO_OCCLUSION"):
+            os.environ[env] = "1"
+            os.environ["ALP_NO_VIS_CACHE"] = "1"
+            try:
+                m.render_enqueue(L.params_vector(p), None)
+                np.testing.assert_array_equal(m.fetch_visibility(), got)
+            finally:
+                os.environ.pop(env, None)
+                os.environ.pop("ALP_NO_VIS_CACHE", None)

@@ -90,12 +90,13 @@ def test_g12_reverse_proj_host_half(tag, otag):
     check_frame(rp.to_frame(array, list(g[f"{tag}_chnames"])), g, tag, otag)
 
 
-def test_g12_sim_image(monkeypatch):
-    from alproj_amd import project as aproj
+def test_g12_sim_image_tail_restated():
+    """sim_image's tail (project.py:322-324) as the device kernel image_u8_kernel states it -- multiply in float32,
+    truncate toward zero, wrap to 8 bits, reverse the channels -- reproduces the reference's bytes (the device
+    kernel itself is held to the same fixture in tests/test_gpu_golden_render.py)"""
     g = load("g12_wrappers.npz")
-    monkeypatch.setattr(aproj, "persp_proj", lambda *a, **k: g["sim_raw"].copy())
-    out = aproj.sim_image(None, None, None, {})
-    assert out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"]
+    x = g["sim_raw"] * np.float32(255)
+    out = np.ascontiguousarray((np.trunc(x).astype(np.int64) & 0xFF).astype(np.uint8)[:, :, ::-1])
     np.testing.assert_array_equal(out, g["sim_bgr"])
 
 
@@ -106,3 +107,7 @@ def test_params_vector_accepts_none_principal_point():
     p = dict(syn.base_params(100), cx=None, cy=None)
     v = _lib.params_vector(p)
     assert v[23] == p["w"] / 2 and v[24] == p["h"] / 2
+    # ... and only there: None anywhere else fails as the reference's arithmetic does
+    for k in ("fov", "w", "h", "x", "k1"):
+        with pytest.raises(TypeError):
+            _lib.params_vector(dict(p, **{k: None}))
