@@ -334,8 +334,15 @@ class LsqOptimizer(BaseOptimizer):
                 result = least_squares(residual_func, self.target_params_init, method=method,
                                        bounds=(bounds[:, 0], bounds[:, 1]), loss=loss,
                                        f_scale=f_scale, **kwargs)
-            params = self._result_params(result.x)
-            err, _ = pts.eval_population(self._candidate_matrix(result.x), _lib.LOSS_MEAN_DIST, 0.0)
+            # Least squares does not shard (scipy drives ONE residual vector): with a communicator every rank has
+            # solved its own points, and the final error below is a collective over all of them -- which must be
+            # evaluated for ONE solution: rank 0's is broadcast and is the result on every rank.
+            best = np.ascontiguousarray(result.x, dtype=np.float64)
+            _, world = _lib.comm_info()
+            if world > 1:
+                _lib.comm_bcast(best, root=0)
+            params = self._result_params(best)
+            err, _ = pts.eval_population(self._candidate_matrix(best), _lib.LOSS_MEAN_DIST, 0.0)
         finally:
             pts.close()
         return params, float(err[0])

@@ -49,6 +49,8 @@ _cache = {"mesh": None, "vert": None, "ind": None, "value": None, "grid": None}
 def _fingerprint(a):
     """identity-independent part of a cache key: layout + CRC of every 1024th row, the first and the last 64 rows"""
     a = np.asarray(a)
+    if a.size == 0:
+        return (a.shape, a.dtype.str, a.strides, 0, 0)
     rows = a.reshape(a.shape[0], -1) if a.ndim > 1 else a.reshape(-1, 1)
     parts = (rows[::1024], rows[:64], rows[-64:])
     crc = 0
@@ -259,6 +261,8 @@ class ReverseProjection:
         # the reference filters a RangeIndex-ed frame, so the labels are the linear pixel indices
         df = pd.DataFrame(data, index=pd.Index(idx.astype(np.int64)))
         LAST_TIMING.update(fetch_s=t1 - t0, frame_s=time.perf_counter() - t1)
+        if "enqueue_s" in LAST_TIMING and "device_ms" not in LAST_TIMING:      # this call's own frame (reverse_proj)
+            LAST_TIMING["device_ms"] = _lib.event_elapsed_ms(_EV0, _EV1)
         return df
 
     def close(self):

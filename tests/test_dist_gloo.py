@@ -110,3 +110,37 @@ def test_combine_partials_semantics():
     assert amin == 0
     losses, _ = adist.combine_partials(adist.pack_partials(np.array([0.0]), 0))
     assert np.isnan(losses[0])                          # np.mean of an empty set
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_optimisers_multi_rank_branches_stay_in_lockstep(tmp_path, world):
+    """The multi-rank branches of CMAOptimizer.optimize (seed broadcast before the sampler exists, candidate
+    matrix broadcast every generation, final error as a collective) and of LsqOptimizer.optimize (rank 0's
+    solution broadcast before the final collective) run for real in `world` processes over gloo, each on its
+    shard (tests/_dist_cma_worker.py).  Nobody passes a seed, as in the reference: unless rank 0's entropy and
+    candidates reach every rank, the ranks sample different populations and the all-reduce adds sums of
+    different candidates -- here every rank must end with bit-identical candidates for 20 generations,
+    parameters and error."""
+    port = _free_port()
+    outs = [str(tmp_path / f"c{r}.npz") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_cma_worker.py"), str(r), str(world), port, outs[r]],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    for p in procs:
+        out, _ = p.communicate(timeout=900)
+        assert p.returncode == 0, out.decode()[-3000:]
+    res = [np.load(o) for o in outs]
+    for r in res[1:]:
+        np.testing.assert_array_equal(r["cma_X"], res[0]["cma_X"])
+        np.testing.assert_array_equal(r["cma_params"], res[0]["cma_params"])
+        assert float(r["cma_err"]) == float(res[0]["cma_err"])
+        np.testing.assert_array_equal(r["lsq_params"], res[0]["lsq_params"])
+        assert float(r["lsq_err"]) == float(res[0]["lsq_err"])
+    assert res[0]["cma_X"].shape == (20, 12, 9)
+    # the order of collectives every rank went through: seed, then (candidates, evaluation) x 20, then the final error
+    expect = ["('bcast', 'uint64', (1,))"] + ["('bcast', 'float64', (12, 9))", "('eval', 12)"] * 20 + ["('eval', 1)"]
+    for r in res:
+        assert list(r["cma_log"]) == expect
+        assert list(r["lsq_log"]) == ["('bcast', 'float64', (4,))", "('eval', 1)"]
+    # ... and least squares found the pose (20 generations of 12 do not finish CMA-ES's 9-parameter search, and
+    # its result is the last generation's best, quirk Q9: nothing to assert on its error but that it is finite)
+    assert np.isfinite(float(res[0]["cma_err"])) and float(res[0]["lsq_err"]) < 10.0 < float(res[0]["init_err"])
