@@ -2,6 +2,7 @@
 """Development probe of the render path: N-vertex synthetic DSM onto the 5616x3744 frame.
    python3 tools/probe_raster.py [N] [reps] [explicit|implicit] [distorted]"""
 import os
+os.environ.setdefault("ALP_NO_VIS_CACHE", "1")     # every frame of a probe is drawn (no visibility cache)
 import sys
 import time
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Development: render time with a per-vertex value array (sim_image's colours) next to the coordinate render."""
 import os, sys
+os.environ.setdefault("ALP_NO_VIS_CACHE", "1")     # every frame of a probe is drawn (no visibility cache)
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from alproj_amd import _lib as L

@@ -2,6 +2,7 @@
 """Development: how many tiles of 64 x 16 cells win at least one pixel of the 100 M-vertex bench frame
 (compare with the tiles the frame plan draws: ALP_RASTER_STATS prints those)."""
 import os, sys
+os.environ.setdefault("ALP_NO_VIS_CACHE", "1")     # every frame of a probe is drawn (no visibility cache)
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from alproj_amd import _lib as L

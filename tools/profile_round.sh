@@ -2,7 +2,7 @@
 # Round profile: the rocprofv3 summaries committed under profiles/ (run on the GPU box from the repo root).
 #   tools/profile_round.sh r02
 cd "$(dirname "$0")/.."
-R=${1:-r02}
+R=${1:-r03}
 export TMPDIR=/tmp
 mkdir -p gpurun_out/prof_$R
 # 1. kernel durations of the default bench run (what --stats prints), as csv
