@@ -93,6 +93,9 @@ _SIGNATURES = {
                           _c_dp],
     "alp_rasterize_points": [_c_dp, _c_dp, _c_dp, _c_i64, _c_i64, _c_double, _c_double, _c_double, _c_i64, _c_i64,
                              _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_uint8)],
+    "alp_render_rasterize_plan": [_c_void_p, _c_dp, ctypes.POINTER(_c_i64), _c_dp],
+    "alp_render_rasterize": [_c_void_p, _c_void_p, _c_int, _c_i64, ctypes.POINTER(ctypes.c_int32), _c_i64, _c_double, _c_double,
+                             _c_double, _c_i64, _c_i64, _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_uint8)],
     "alp_distort_image": [_c_fp, _c_i64, _c_i64, _c_i64, _c_dp, _c_fp],
     "alp_distort_map": [_c_i64, _c_i64, _c_dp, _c_fp, _c_fp],
 }
@@ -471,6 +474,32 @@ class Mesh:
         check(self._lib.alp_render_fetch_valid(self._h, None if off is None else as_dp(off),
                                                idx.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), as_dp(xyz)))
         return idx, xyz
+
+    def rasterize_plan(self, offsets=None):
+        """After a render of the vertices themselves: (number of pixels that see the surface, (x_min, y_min, x_max,
+        y_max) of their coordinates); keeps the compacted points on the device for ``rasterize``."""
+        n = _c_i64()
+        b = np.empty(4, dtype=np.float64)
+        off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.float64)
+        check(self._lib.alp_render_rasterize_plan(self._h, None if off is None else as_dp(off), ctypes.byref(n), as_dp(b)))
+        return int(n.value), tuple(float(v) for v in b)
+
+    def rasterize(self, array, band_channel, x_min, y_max, resolution, width, height, agg, sweeps, nodata):
+        """(bands, height, width) uint8 raster of the planned points with band values from ``array`` (h, w, C)."""
+        array = np.ascontiguousarray(array)
+        codes = {np.dtype(np.uint8): ALP_U8, np.dtype(np.uint16): ALP_U16, np.dtype(np.float32): ALP_F32,
+                 np.dtype(np.float64): ALP_F64}
+        if array.dtype not in codes:
+            array = array.astype(np.float64)
+        if array.ndim != 3 or array.shape[:2] != tuple(self.shape[:2]):
+            raise ValueError("array must have shape (h, w, channels) of the rendered frame")
+        bc = np.ascontiguousarray(band_channel, dtype=np.int32)
+        out = np.empty((len(bc), int(height), int(width)), dtype=np.uint8)
+        check(self._lib.alp_render_rasterize(self._h, array.ctypes.data_as(_c_void_p), codes[array.dtype], array.shape[2],
+                                             bc.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), len(bc), float(x_min),
+                                             float(y_max), float(resolution), int(width), int(height), int(agg),
+                                             int(sweeps), int(nodata), out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))))
+        return out
 
     def gather(self, u, v, offsets=None):
         """After a render of the vertices themselves: (n, 3) float64 x, y, z seen by the pixels

@@ -2391,6 +2391,52 @@ int ensure_gqueue(alp_mesh *m, unsigned cap) {
     return ALP_OK;
 }
 
+int finish_frame_of(alp_mesh *m);      // = finish_frame below (anonymous namespace)
+
+// The x > 0 selection of reverse_proj (project.py:369) on the resident frame, in two steps: count + exclusive scan
+// per chunk of the image (frame_valid_count, also waits for the frame and checks its queues), then the order-
+// preserving write of the survivors' pixel index and (x, y, z) = channels (0, 2, 1) + offsets as float64
+// (frame_valid_write; device pointers).  Shared by alp_render_fetch_valid and alp_render_rasterize_*.
+int frame_valid_count(alp_mesh *m, int64_t *count) {
+    if (int e = finish_frame_of(m)) return e;
+    const long long npix = (long long)m->w * m->h;
+    const int chunks = (int)((npix + COMPACT_CHUNK - 1) / COMPACT_CHUNK);
+    if (chunks > m->compact_cap) {
+        if (m->compact_counts) hipFree(m->compact_counts);
+        if (m->compact_offsets) hipFree(m->compact_offsets);
+        m->compact_counts = nullptr;
+        m->compact_offsets = nullptr;
+        m->compact_cap = 0;
+        ALP_HIP(hipMalloc((void **)&m->compact_counts, (size_t)chunks * sizeof(unsigned)));
+        ALP_HIP(hipMalloc((void **)&m->compact_offsets, (size_t)(chunks + 1) * sizeof(unsigned long long)));
+        m->compact_cap = chunks;
+    }
+    hipStream_t st = ctx().stream;
+    ktime_begin();
+    hipLaunchKernelGGL(valid_count_kernel, dim3(chunks), dim3(256), 0, st, m->image, npix, m->compact_counts);
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, st, m->compact_counts, chunks, m->compact_offsets);
+    ktime_end();
+    ALP_HIP(hipGetLastError());
+    unsigned long long total = 0;
+    ALP_HIP(hipMemcpyAsync(&total, m->compact_offsets + chunks, sizeof(total), hipMemcpyDeviceToHost, st));
+    ALP_HIP(hipStreamSynchronize(st));
+    m->valid_total = (int64_t)total;
+    *count = m->valid_total;
+    return ALP_OK;
+}
+
+int frame_valid_write(alp_mesh *m, const double *offsets, unsigned *idx_dev, double *xyz_dev) {
+    const long long npix = (long long)m->w * m->h;
+    const int chunks = (int)((npix + COMPACT_CHUNK - 1) / COMPACT_CHUNK);
+    const double o0 = offsets ? offsets[0] : 0.0, o1 = offsets ? offsets[1] : 0.0, o2 = offsets ? offsets[2] : 0.0;
+    ktime_begin();
+    hipLaunchKernelGGL(valid_write_kernel, dim3(chunks), dim3(256), 0, ctx().stream, m->image, npix, m->compact_offsets, o0, o1,
+                       o2, idx_dev, xyz_dev);
+    ktime_end();
+    ALP_HIP(hipGetLastError());
+    return ALP_OK;
+}
+
 }  // namespace alp
 
 namespace {
@@ -2633,6 +2679,7 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
     m->last_min_distance = min_distance;
     m->unchecked = m->n_tri > 0;
     m->vis_current = true;
+    m->rz_n = -1;                    // a rasterisation plan belongs to the frame it was made for
     ++(resolve_only ? m->frames_resolve_only : m->frames_full);
 #ifdef ALP_RASTER_STATS
     {
@@ -2699,6 +2746,8 @@ int finish_frame(alp_mesh *m) {
 }
 
 }  // namespace
+
+int alp::finish_frame_of(alp_mesh *m) { return finish_frame(m); }
 
 // n x 3 float32 or float64 host array -> n x 3 float32 on the device; float64 is staged through the library
 // scratch in chunks and cast there (no host pass over the array, no float32 copy on the host)
@@ -2843,7 +2892,8 @@ int alp_mesh_destroy(alp_mesh_t *m) {
     for (void *p : {(void *)m->vert, (void *)m->value, (void *)m->ind, (void *)m->valid, (void *)m->valid_derived,
                     (void *)m->tri_present, (void *)m->tri_rank, (void *)m->vis, (void *)m->image,
                     (void *)m->queue, (void *)m->gqueue, (void *)m->qcount_dev, (void *)m->compact_counts, (void *)m->compact_offsets,
-                    (void *)m->tile_bounds, (void *)m->tile_lists, (void *)m->hiz, (void *)m->park_small, (void *)m->park_cell})
+                    (void *)m->tile_bounds, (void *)m->tile_lists, (void *)m->hiz, (void *)m->park_small, (void *)m->park_cell,
+                    (void *)m->rz_points})
         if (p) hipFree(p);
     if (m->qcount_host) hipHostFree(m->qcount_host);
     delete m;
@@ -2945,31 +2995,7 @@ int alp_render_valid_count(alp_mesh_t *m, int64_t *count) {
     if (int rc = require_init()) return rc;
     ALP_REQUIRE(m && count, "NULL argument");
     if (!m->rendered) return fail(ALP_ESTATE, "alp_render_valid_count: nothing rendered yet");
-    if (int e = finish_frame(m)) return e;
-    const long long npix = (long long)m->w * m->h;
-    const int chunks = (int)((npix + COMPACT_CHUNK - 1) / COMPACT_CHUNK);
-    if (chunks > m->compact_cap) {
-        if (m->compact_counts) hipFree(m->compact_counts);
-        if (m->compact_offsets) hipFree(m->compact_offsets);
-        m->compact_counts = nullptr;
-        m->compact_offsets = nullptr;
-        m->compact_cap = 0;
-        ALP_HIP(hipMalloc((void **)&m->compact_counts, (size_t)chunks * sizeof(unsigned)));
-        ALP_HIP(hipMalloc((void **)&m->compact_offsets, (size_t)(chunks + 1) * sizeof(unsigned long long)));
-        m->compact_cap = chunks;
-    }
-    hipStream_t st = ctx().stream;
-    ktime_begin();
-    hipLaunchKernelGGL(valid_count_kernel, dim3(chunks), dim3(256), 0, st, m->image, npix, m->compact_counts);
-    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, st, m->compact_counts, chunks, m->compact_offsets);
-    ktime_end();
-    ALP_HIP(hipGetLastError());
-    unsigned long long total = 0;
-    ALP_HIP(hipMemcpyAsync(&total, m->compact_offsets + chunks, sizeof(total), hipMemcpyDeviceToHost, st));
-    ALP_HIP(hipStreamSynchronize(st));
-    m->valid_total = (int64_t)total;
-    *count = m->valid_total;
-    return ALP_OK;
+    return frame_valid_count(m, count);
 }
 
 int alp_render_fetch_valid(alp_mesh_t *m, const double *offsets, uint32_t *idx_out, double *xyz_out) {
@@ -2980,21 +3006,14 @@ int alp_render_fetch_valid(alp_mesh_t *m, const double *offsets, uint32_t *idx_o
     m->valid_total = -1;
     if (M == 0) return ALP_OK;
     ALP_REQUIRE(idx_out && xyz_out, "output is NULL");
-    const long long npix = (long long)m->w * m->h;
-    const int chunks = (int)((npix + COMPACT_CHUNK - 1) / COMPACT_CHUNK);
     char *dev = nullptr;
     const size_t xyz_bytes = (size_t)M * 3 * sizeof(double), idx_bytes = (size_t)M * sizeof(unsigned);
     if (int rc = scratch_reserve(xyz_bytes + idx_bytes, (void **)&dev)) return rc;
     double *xyz_dev = (double *)dev;
     unsigned *idx_dev = (unsigned *)(dev + xyz_bytes);
     hipStream_t st = ctx().stream;
-    const double o0 = offsets ? offsets[0] : 0.0, o1 = offsets ? offsets[1] : 0.0, o2 = offsets ? offsets[2] : 0.0;
-    ktime_begin();
-    hipLaunchKernelGGL(valid_write_kernel, dim3(chunks), dim3(256), 0, st, m->image, npix, m->compact_offsets, o0, o1,
-                       o2, idx_dev, xyz_dev);
-    ktime_end();
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(xyz_out, xyz_dev, xyz_bytes, hipMemcpyDeviceToHost, st);
+    if (int rc = frame_valid_write(m, offsets, idx_dev, xyz_dev)) return rc;
+    hipError_t e = hipMemcpyAsync(xyz_out, xyz_dev, xyz_bytes, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(idx_out, idx_dev, idx_bytes, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return fail(ALP_EHIP, "alp_render_fetch_valid: %s", hipGetErrorString(e));
@@ -3065,6 +3084,7 @@ int alp_render_load(alp_mesh_t *m, const float *image, int64_t h, int64_t w) {
     if (int e = upload_chunked(m->image, image, (size_t)h * w * 3 * sizeof(float))) return e;
     ALP_HIP(hipMemsetAsync(m->vis, 0, (size_t)h * w * sizeof(unsigned long long), ctx().stream));   // no visibility belongs to it
     m->vis_current = false;
+    m->rz_n = -1;
     m->rendered = true;
     m->valid_total = -1;
     return ALP_OK;

@@ -16,7 +16,10 @@
 // finalize (float32 raster), focal sweep (ping-pong), uint8 conversion.  The 3x3 mean adds its
 // window in numpy's order (pairwise block of 8, then the ninth) so that the float64 sum -- and
 // with it the float32 value and the truncated byte -- match the reference.
-#include "alp_internal.h"
+#include "alp_raster_internal.h"
+
+#include <algorithm>
+#include <cmath>
 
 namespace alp {
 
@@ -306,9 +309,169 @@ static int run_rasterize_median(const double *dx, const double *dy, const double
     return ALP_OK;
 }
 
+// ------------------------------------------------------------------ fed from the resident coordinate image
+// reverse_proj + to_geotiff back to back (example.py:103-106) without the DataFrame in between: the points are the
+// frame's pixels that see the surface, compacted in pixel order (the rows of the reference's table), their x / y the
+// coordinate image's channels 0 / 2 plus the offsets (project.py:361, :370-373), their band values the caller's
+// image array at the same pixel (project.py:364).
+
+// interleaved (x, y, z) of the compaction -> planar x[M], y[M]
+__global__ __launch_bounds__(256) void rz_split_xy_kernel(const double *__restrict__ xyz, long long n, double *__restrict__ x,
+                                                          double *__restrict__ y) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        x[i] = xyz[3 * i];
+        y[i] = xyz[3 * i + 1];
+    }
+}
+
+// min / max of x and y over the M points: ordered-integer atomics on four words (x_min, y_min, x_max, y_max)
+__global__ __launch_bounds__(256) void rz_bounds_kernel(const double *__restrict__ x, const double *__restrict__ y, long long n,
+                                                        unsigned long long *__restrict__ out) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    unsigned long long lo_x = ~0ull, lo_y = ~0ull, hi_x = 0ull, hi_y = 0ull;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const unsigned long long a = d2ord(x[i]), b = d2ord(y[i]);
+        lo_x = a < lo_x ? a : lo_x; hi_x = a > hi_x ? a : hi_x;
+        lo_y = b < lo_y ? b : lo_y; hi_y = b > hi_y ? b : hi_y;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long a = __shfl_xor(lo_x, off), b = __shfl_xor(lo_y, off), c = __shfl_xor(hi_x, off), d = __shfl_xor(hi_y, off);
+        lo_x = a < lo_x ? a : lo_x; lo_y = b < lo_y ? b : lo_y;
+        hi_x = c > hi_x ? c : hi_x; hi_y = d > hi_y ? d : hi_y;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(out + 0, lo_x); atomicMin(out + 1, lo_y);
+        atomicMax(out + 2, hi_x); atomicMax(out + 3, hi_y);
+    }
+}
+
+// values[i][b] = (double) array[pixel idx[i]][band_channel[b]]  (the float64 columns of the reference's table)
+template <typename A>
+__global__ __launch_bounds__(256) void rz_gather_bands_kernel(const A *__restrict__ array, const unsigned *__restrict__ idx, long long n,
+                                                              int channels, int nb, const int *__restrict__ band_channel,
+                                                              double *__restrict__ values) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const A *px = array + (long long)idx[i] * channels;
+        for (int b = 0; b < nb; ++b) values[i * nb + b] = (double)px[band_channel[b]];
+    }
+}
+
 }  // namespace alp
 
 using namespace alp;
+
+extern "C" int alp_render_rasterize_plan(alp_mesh_t *m, const double *offsets, int64_t *n_valid, double bounds[4]) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(m && n_valid && bounds, "NULL argument");
+    if (!m->rendered) return fail(ALP_ESTATE, "alp_render_rasterize_plan: nothing rendered yet");
+    int64_t M = 0;
+    if (int rc = frame_valid_count(m, &M)) return rc;
+    m->valid_total = -1;                         // this count is not an alp_render_fetch_valid in waiting
+    m->rz_n = -1;
+    *n_valid = M;
+    bounds[0] = bounds[1] = bounds[2] = bounds[3] = NAN;
+    if (M == 0) { m->rz_n = 0; return ALP_OK; }
+    const size_t need = (size_t)M * (8 + 8 + 4) + 64;
+    if (need > m->rz_cap) {
+        if (m->rz_points) hipFree(m->rz_points);
+        m->rz_points = nullptr;
+        m->rz_cap = 0;
+        ALP_HIP(hipMalloc((void **)&m->rz_points, need));
+        m->rz_cap = need;
+    }
+    double *x = (double *)m->rz_points, *y = x + M;
+    unsigned *idx = (unsigned *)(y + M);
+    char *dev = nullptr;
+    if (int rc = scratch_reserve((size_t)M * 3 * sizeof(double) + 64, (void **)&dev)) return rc;
+    double *xyz = (double *)dev;
+    unsigned long long *mm = (unsigned long long *)(dev + (size_t)M * 3 * sizeof(double));
+    hipStream_t st = ctx().stream;
+    if (int rc = frame_valid_write(m, offsets, idx, xyz)) return rc;
+    const unsigned long long init[4] = {~0ull, ~0ull, 0ull, 0ull};
+    ALP_HIP(hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, st));
+    const unsigned grid = (unsigned)std::min<long long>((M + 255) / 256, (long long)ctx().cu_count * 8);
+    ktime_begin();
+    hipLaunchKernelGGL(rz_split_xy_kernel, dim3(grid), dim3(256), 0, st, xyz, (long long)M, x, y);
+    hipLaunchKernelGGL(rz_bounds_kernel, dim3(grid), dim3(256), 0, st, x, y, (long long)M, mm);
+    ktime_end();
+    ALP_HIP(hipGetLastError());
+    unsigned long long h[4];
+    ALP_HIP(hipMemcpyAsync(h, mm, sizeof(h), hipMemcpyDeviceToHost, st));
+    ALP_HIP(hipStreamSynchronize(st));
+    for (int k = 0; k < 4; ++k) {
+        const unsigned long long u = (h[k] >> 63) ? (h[k] & 0x7fffffffffffffffull) : ~h[k];     // ord2d on the host
+        memcpy(&bounds[k], &u, 8);
+    }
+    m->rz_n = M;
+    return ALP_OK;
+}
+
+extern "C" int alp_render_rasterize(alp_mesh_t *m, const void *array, int array_dtype, int64_t channels,
+                                    const int32_t *band_channel, int64_t nb, double x_min, double y_max, double resolution,
+                                    int64_t width, int64_t height, int agg, int sweeps, int nodata, uint8_t *out) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(m && array && band_channel && out, "NULL argument");
+    if (m->rz_n < 0) return fail(ALP_ESTATE, "alp_render_rasterize: call alp_render_rasterize_plan for this frame first");
+    ALP_REQUIRE(m->rz_n >= 1, "no pixel of the frame sees the surface");
+    ALP_REQUIRE(array_dtype == ALP_U8 || array_dtype == ALP_U16 || array_dtype == ALP_F32 || array_dtype == ALP_F64,
+                "array_dtype must be ALP_U8, ALP_U16, ALP_F32 or ALP_F64");
+    ALP_REQUIRE(channels >= 1 && channels <= 64 && nb >= 1 && nb <= 64, "channel or band count out of range");
+    for (int64_t b = 0; b < nb; ++b) ALP_REQUIRE(band_channel[b] >= 0 && band_channel[b] < channels, "band_channel out of range");
+    ALP_REQUIRE(width >= 1 && height >= 1 && width * height <= ((int64_t)1 << 31), "raster size out of range");
+    ALP_REQUIRE(resolution > 0, "resolution must be positive");
+    ALP_REQUIRE(agg == ALP_AGG_MEAN || agg == ALP_AGG_MAX || agg == ALP_AGG_MIN || agg == ALP_AGG_MEDIAN,
+                "agg must be ALP_AGG_MEAN, _MAX, _MIN or _MEDIAN");
+    ALP_REQUIRE(sweeps >= 0 && sweeps <= 4096, "sweeps out of range");
+    const int64_t n = m->rz_n;
+    const size_t esize = array_dtype == ALP_U8 ? 1 : array_dtype == ALP_U16 ? 2 : array_dtype == ALP_F32 ? 4 : 8;
+    const size_t npix = (size_t)m->w * m->h, arr_bytes = npix * (size_t)channels * esize;
+    const size_t total = (size_t)width * height * nb;
+    // values | acc (f64) | cnt (u32) | raster a | raster b | out (u8) | band table | the caller's array
+    const size_t bytes = (size_t)n * nb * 8 + total * (8 + 4 + 4 + 4 + 1) + 64 * 4 + 256 + arr_bytes + 64;
+    char *dev = nullptr;
+    ALP_HIP(hipMalloc((void **)&dev, bytes));
+    double *dv = (double *)dev;
+    double *acc = dv + (size_t)n * nb;
+    unsigned *cnt = (unsigned *)(acc + total);
+    float *ra = (float *)(cnt + total), *rb = ra + total;
+    unsigned char *out_dev = (unsigned char *)(rb + total);
+    int *bands_dev = (int *)(((uintptr_t)(out_dev + total) + 15) & ~(uintptr_t)15);
+    char *arr_dev = (char *)(((uintptr_t)(bands_dev + 64) + 255) & ~(uintptr_t)255);
+    const double *dx = (const double *)m->rz_points, *dy = dx + n;
+    const unsigned *idx = (const unsigned *)(dy + n);
+    hipStream_t st = ctx().stream;
+    int rc = upload_chunked(arr_dev, array, arr_bytes);
+    hipError_t e = hipSuccess;
+    if (!rc) e = hipMemcpyAsync(bands_dev, band_channel, (size_t)nb * sizeof(int), hipMemcpyHostToDevice, st);
+    if (!rc && e == hipSuccess) {
+        KTimeScope kt;
+        const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, (long long)ctx().cu_count * 8);
+#define ALP_GATHER(A) hipLaunchKernelGGL(rz_gather_bands_kernel<A>, dim3(grid), dim3(256), 0, st, (const A *)arr_dev, idx, (long long)n, \
+                                         (int)channels, (int)nb, bands_dev, dv)
+        if (array_dtype == ALP_U8) ALP_GATHER(unsigned char);
+        else if (array_dtype == ALP_U16) ALP_GATHER(unsigned short);
+        else if (array_dtype == ALP_F32) ALP_GATHER(float);
+        else ALP_GATHER(double);
+#undef ALP_GATHER
+        if (agg == ALP_AGG_MEAN)
+            rc = run_rasterize<AGG_MEAN>(dx, dy, dv, n, (int)nb, x_min, y_max, resolution, (int)width, (int)height, sweeps, nodata, acc, cnt, ra, rb, out_dev);
+        else if (agg == ALP_AGG_MAX)
+            rc = run_rasterize<AGG_MAX>(dx, dy, dv, n, (int)nb, x_min, y_max, resolution, (int)width, (int)height, sweeps, nodata, acc, cnt, ra, rb, out_dev);
+        else if (agg == ALP_AGG_MIN)
+            rc = run_rasterize<AGG_MIN>(dx, dy, dv, n, (int)nb, x_min, y_max, resolution, (int)width, (int)height, sweeps, nodata, acc, cnt, ra, rb, out_dev);
+        else
+            rc = run_rasterize_median(dx, dy, dv, n, (int)nb, x_min, y_max, resolution, (int)width, (int)height, sweeps, nodata, ra, rb, out_dev);
+    }
+    if (!rc && e == hipSuccess) e = hipMemcpyAsync(out, out_dev, total, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    else hipStreamSynchronize(st);
+    hipFree(dev);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(ALP_EHIP, "alp_render_rasterize: %s", hipGetErrorString(e));
+    return ALP_OK;
+}
 
 extern "C" int alp_rasterize_points(const double *x, const double *y, const double *values, int64_t n, int64_t nb,
                                     double x_min, double y_max, double resolution, int64_t width, int64_t height,

@@ -265,6 +265,48 @@ class ReverseProjection:
             LAST_TIMING["device_ms"] = _lib.event_elapsed_ms(_EV0, _EV1)
         return df
 
+    def rasterize(self, array, chnames=["B", "G", "R"], resolution=1.0, bands=["R", "G", "B"], interpolate=True,
+                  max_dist=1.0, agg_func="mean", nodata=255):
+        """``rasterize(self.to_frame(array, chnames), ...)`` -- the compute part of the reference's ``to_geotiff``
+        (project.py:414-485) on the table ``reverse_proj`` would return (project.py:361-373) -- without building the
+        table: the pixels that see the surface are selected, binned and aggregated on the device straight from the
+        resident coordinate image (alp_render_rasterize_plan / alp_render_rasterize); only ``array`` goes up and
+        the uint8 raster comes back.  Byte-identical to the table path.  Bands must be channel names."""
+        array = np.asarray(array)
+        if array.ndim != 3 or array.shape[2] != len(chnames):
+            raise ValueError("The array has {} channels but chnames has length of {}. Please set chnames correctly."
+                             .format(array.shape[2] if array.ndim == 3 else 1, len(chnames)))
+        if array.shape[0] != self.h or array.shape[1] != self.w:
+            raise ValueError("all the input array dimensions except for the concatenation axis must match exactly "
+                             f"(array is {array.shape[:2]}, the camera image {(self.h, self.w)})")
+        columns = ["u", "v", "x", "y", "z"] + list(chnames)
+        for band in bands:
+            if band not in columns:
+                raise ValueError(f"Band '{band}' not found in DataFrame columns: {columns}")
+        if agg_func not in _AGG:
+            raise ValueError(f"agg_func must be one of {['mean', 'median', 'max', 'min']}")
+        if any(b not in chnames for b in bands):          # a coordinate column as a band: through the table
+            return rasterize(self.to_frame(array, chnames), resolution, bands, interpolate, max_dist, agg_func, nodata)
+        mesh = self._current()
+        n, (x_min, y_min, x_max, y_max) = mesh.rasterize_plan(self.offsets)
+        if n == 0:
+            raise ValueError("zero-size array to reduction operation minimum which has no identity")   # numpy's, as for an empty table
+        width = int(np.ceil((x_max - x_min) / resolution))
+        height = int(np.ceil((y_max - y_min) / resolution))
+        if width <= 0 or height <= 0:
+            raise ValueError(f"Invalid raster dimensions: width={width}, height={height}")
+        sweeps = int(np.ceil(max_dist / resolution)) if (interpolate and max_dist > 0) else 0
+        out = mesh.rasterize(array, [list(chnames).index(b) for b in bands], x_min, y_max, resolution, width, height,
+                             _AGG[agg_func], sweeps, nodata)
+        return out, (x_min, y_min, x_max, y_max, width, height)
+
+    def to_geotiff(self, array, output_path, chnames=["B", "G", "R"], resolution=1.0, crs="EPSG:6690",
+                   bands=["R", "G", "B"], interpolate=True, max_dist=1.0, agg_func="mean", nodata=255):
+        """``to_geotiff(reverse_proj(array, ...), output_path, ...)`` of the reference (example.py:103-106) with the
+        raster computed from the resident coordinate image (``rasterize`` above); the file is written with rasterio."""
+        raster, bounds = self.rasterize(array, chnames, resolution, bands, interpolate, max_dist, agg_func, nodata)
+        _write_geotiff(raster, bounds, output_path, crs, bands, nodata)
+
     def close(self):
         if self._owns and self.mesh is not None:
             self.mesh.close()
@@ -338,8 +380,12 @@ def to_geotiff(df, output_path, resolution=1.0, crs="EPSG:6690", bands=["R", "G"
     """Convert ``reverse_proj`` output to a GeoTIFF (reference project.py:376-503).  The raster
     is computed on the device (``rasterize``); writing the file needs ``rasterio`` like the
     reference does (ImportError otherwise -- use ``rasterize`` to get the arrays)."""
-    raster, (x_min, y_min, x_max, y_max, width, height) = rasterize(
-        df, resolution, bands, interpolate, max_dist, agg_func, nodata)
+    raster, bounds = rasterize(df, resolution, bands, interpolate, max_dist, agg_func, nodata)
+    _write_geotiff(raster, bounds, output_path, crs, bands, nodata)
+
+
+def _write_geotiff(raster, bounds, output_path, crs, bands, nodata):
+    x_min, y_min, x_max, y_max, width, height = bounds
     import rasterio
     from rasterio.transform import from_bounds
     transform = from_bounds(x_min, y_min, x_max, y_max, width, height)

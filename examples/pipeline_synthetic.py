@@ -5,6 +5,7 @@ data with every stage on the GPU through alproj_amd:
   rasters -> colored_surface_mesh -> sim_image -> reverse_proj_device -> (synthetic matches)
   -> set_gcp -> filter_gcp_distance -> CMAOptimizer phase 1 (pose) -> phase 2 (distortion)
   -> LsqOptimizer polish -> reverse_proj of the "photograph" -> rasterize (to_geotiff's raster)
+  (the last two also without the table in between: ReverseProjection.rasterize)
 
 The only step replaced is `image_match` (CNN feature matching, out of scope): the "photograph"
 is a render with a hidden true camera, and a match is made for a pixel of the simulated image
@@ -120,6 +121,12 @@ def run(n=1024, w=1404, h=936, generations=150, seed=1, verbose=True):
     t0 = time.perf_counter()
     raster, bounds = rasterize(geo, resolution=2.0, bands=["R", "G", "B"], interpolate=True, max_dist=2.0)
     tick("rasterize (to_geotiff compute)", t0)
+    # the same two steps without the table in between: the coordinate image stays in HBM and is binned there
+    t0 = time.perf_counter()
+    with reverse_proj_device(mesh, None, p4, offsets) as rp4:
+        raster_dev, bounds_dev = rp4.rasterize(photo, resolution=2.0, bands=["R", "G", "B"], interpolate=True, max_dist=2.0)
+    tick("reverse_proj + rasterize (device)", t0)
+    assert bounds_dev == bounds and np.array_equal(raster_dev, raster)
 
     # ---- quality: reprojection error of clean world points under the estimated camera
     chk = rp2.lookup(rng.integers(0, w, 4000), rng.integers(0, h, 4000))

@@ -329,6 +329,23 @@ int alp_render_gather(alp_mesh_t *mesh, const int32_t *u, const int32_t *v, int6
  * 0 = no interpolation); empty pixels -> nodata, others clipped to [0, 255] and truncated
  * (:483-485). */
 enum alp_agg { ALP_AGG_MEAN = 0, ALP_AGG_MAX = 1, ALP_AGG_MIN = 2, ALP_AGG_MEDIAN = 3 };
+/* The same computation fed from the RESIDENT coordinate image of the last render (values = the
+ * vertices themselves), i.e. reverse_proj() -> to_geotiff() back to back, example.py:103-106,
+ * without the multi-million-row table in between:
+ *   alp_render_rasterize_plan  selects the pixels that see the surface (x > 0,
+ *       src/alproj/project.py:369), keeps their x = channel 0 + offsets[0], y = channel 2 +
+ *       offsets[2] (:361, :370-373) on the device and returns their number and bounds[4] =
+ *       x_min, y_min, x_max, y_max (:420-421) -- from which the caller derives width / height
+ *       exactly as :422-425 does;
+ *   alp_render_rasterize  takes the caller's image `array` (h x w x channels of the frame's size;
+ *       ALP_U8, ALP_U16, ALP_F32 or ALP_F64 -- the table's float64 channel columns, :364-367),
+ *       the channel index of each of the nb output bands, and rasterises like
+ *       alp_rasterize_points.  The plan belongs to the frame it was made for. */
+int alp_render_rasterize_plan(alp_mesh_t *mesh, const double *offsets, int64_t *n_valid, double bounds[4]);
+int alp_render_rasterize(alp_mesh_t *mesh, const void *array, int array_dtype, int64_t channels,
+                         const int32_t *band_channel, int64_t nb, double x_min, double y_max,
+                         double resolution, int64_t width, int64_t height, int agg, int sweeps,
+                         int nodata, uint8_t *out);
 int alp_rasterize_points(const double *x, const double *y, const double *values, int64_t n, int64_t nb,
                          double x_min, double y_max, double resolution, int64_t width, int64_t height,
                          int agg, int sweeps, int nodata, uint8_t *out);

@@ -11,6 +11,8 @@ the reference has no fixture for the render).  What IS checked:
 """
 import warnings
 
+import os
+
 import numpy as np
 import pytest
 
