@@ -442,7 +442,8 @@ __global__ __launch_bounds__(256, Cfg::MINW) void popeval_kernel(
     const int64_t beg = (int64_t)blockIdx.x * rows_per * 256;
     const int64_t end = (beg + rows_per * 256 < n) ? beg + rows_per * 256 : n;
 
-    for (int c0 = 0; c0 < P; c0 += TC) {
+    // gridDim.y > 1 (few candidate tiles, see enqueue_popeval): this workgroup takes every gridDim.y-th tile only
+    for (int c0 = (int)blockIdx.y * TC; c0 < P; c0 += (int)gridDim.y * TC) {
         const int tc = (P - c0 < TC) ? (P - c0) : TC;
         __syncthreads();
         {   // stage tc records (16-byte vectors) and clear the accumulators

@@ -190,14 +190,35 @@ int enqueue_popeval(alp_points *p, const double *cand, int64_t P, int loss_kind,
     // 8: 229, 16: 224, 32: 221, 64: 219, 128: 219; 10 M x 256: 8 per CU (stripes of 19 rows) 3.31
     // ms, 16: 3.46, 32: 3.73.  float64 keeps 4 per CU.
     int nblk = ctx().cu_count * 4;
+    int ytiles = 1;
+    const int64_t rows = (p->n + 255) / 256;
     if (sizeof(T) == 4) {
-        const int64_t want = ((p->n + 255) / 256 + 23) / 24;
+        const int64_t want = (rows + 23) / 24;
         const int64_t lo = (int64_t)ctx().cu_count * 4, hi = (int64_t)ctx().cu_count * 64;
         // whole rounds of the 4 workgroups a CU holds at once while the grid is only a few rounds deep
         const int64_t rounded = (want + lo - 1) / lo * lo;
         nblk = (int)(want < lo ? lo : (want > hi ? hi : (want < 4 * lo ? rounded : want)));
+        // Few candidate tiles and a grid only a few rounds deep (10 M x 256: 2 tiles, 1954 stripes of 20 rows = 1.9
+        // rounds of the 1024 resident workgroups): the last round's idle slots and the rows a stripe leaves over for
+        // the narrow groups (20 = 3 x 6 + 2) cost 10 % against the 100 M x 2048 shape.  Then the grid becomes
+        // stripes x tiles -- a workgroup runs ONE tile of 128 candidates over a stripe of whole groups of V = 6 rows
+        // -- sized for about twelve rounds, so that the dispatcher's greedy order leaves a tail of a few per cent.
+        const int tiles = (int)((P + POP_TC - 1) / POP_TC);
+        if (tiles >= 2 && tiles <= 8 && want * tiles < 8 * lo) {
+            int64_t k = rows * tiles / (6 * 12 * lo);          // groups of 6 rows per stripe
+            if (k < 1) k = 1;
+            if (k > 4) k = 4;
+            const int64_t stripes = (rows + 6 * k - 1) / (6 * k);
+            if (stripes * tiles >= 4 * lo) {
+                nblk = (int)stripes;
+                ytiles = tiles;
+            }
+        }
+        if (const char *e = getenv("ALP_POP_GRID")) {           // tuning hook: "stripes,ytiles" (any value gives the same losses)
+            int a = 0, b = 0;
+            if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && b >= 1 && b <= tiles) { nblk = a; ytiles = b; }
+        }
     }
-    const int64_t rows = (p->n + 255) / 256;
     if (rows < nblk) nblk = (int)(rows > 0 ? rows : 1);
     if (int rc = ensure_pop_scratch(p, P, nblk)) return rc;
     if (!p->ev[0]) {            // all three or none: a partial failure must not leave ev[1] / ev[2] NULL for good
@@ -211,7 +232,7 @@ int enqueue_popeval(alp_points *p, const double *cand, int64_t P, int loss_kind,
         for (int k = 0; k < 3; ++k) p->ev[k] = ev[k];
     }
     ALP_HIP(hipEventRecord(p->ev[0], ctx().stream));
-    hipLaunchKernelGGL(kernels[which], dim3(nblk), dim3(256), 0, ctx().stream, (const T *)p->x, (const T *)p->y,
+    hipLaunchKernelGGL(kernels[which], dim3(nblk, ytiles), dim3(256), 0, ctx().stream, (const T *)p->x, (const T *)p->y,
                        (const T *)p->z, (const T *)p->uo, (const T *)p->vo, p->n, (const PoseRec<T> *)p->cand_dev,
                        (int)P, (T)f_scale, p->partials);
     ALP_HIP(hipGetLastError());
