@@ -201,11 +201,16 @@ int enqueue_popeval(alp_points *p, const double *cand, int64_t P, int loss_kind,
         // Few candidate tiles and a grid only a few rounds deep (10 M x 256: 2 tiles, 1954 stripes of 20 rows = 1.9
         // rounds of the 1024 resident workgroups): the last round's idle slots and the rows a stripe leaves over for
         // the narrow groups (20 = 3 x 6 + 2) cost 10 % against the 100 M x 2048 shape.  Then the grid becomes
-        // stripes x tiles -- a workgroup runs ONE tile of 128 candidates over a stripe of whole groups of V = 6 rows
-        // -- sized for about twelve rounds, so that the dispatcher's greedy order leaves a tail of a few per cent.
+        // stripes x tiles -- a workgroup runs ONE tile of 128 candidates over a stripe of whole groups of V = 6 rows,
+        // about two stripes per resident workgroup slot: short enough for the dispatcher's greedy order to leave a
+        // small tail, long enough to amortise the staging of the tile's records.  Measured at 10 M points
+        // (tools/sweep_popeval_grid.py, ms for P = 256 / 384 / 512): one column of 2048 stripes x all tiles (round 2)
+        // 3.15 / 4.64 / 6.14; stripes of 6 rows x tiles 3.02 / 4.39 / 5.72; 12 rows 2.96 / 4.35 / 5.63; 18 rows
+        // 2.90 / 4.33 / 5.61; 24 rows 2.97 / 4.44 / 5.70; 36 rows 3.10 / 4.37 / 5.64.  The sums do not depend on
+        // the shape: float64 additions of float32 group sums of this magnitude are exact.
         const int tiles = (int)((P + POP_TC - 1) / POP_TC);
         if (tiles >= 2 && tiles <= 8 && want * tiles < 8 * lo) {
-            int64_t k = rows * tiles / (6 * 12 * lo);          // groups of 6 rows per stripe
+            int64_t k = (int64_t)((double)rows / (6.0 * 2.12 * (double)lo) + 0.5);      // groups of 6 rows per stripe
             if (k < 1) k = 1;
             if (k > 4) k = 4;
             const int64_t stripes = (rows + 6 * k - 1) / (6 * k);
