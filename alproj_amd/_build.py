@@ -39,9 +39,8 @@ def _stale(target, deps):
 def build(force=False, verbose=False):
     """Compile every HIP translation unit for gfx950 and link libalproj_hip.so."""
     os.makedirs(BUILD, exist_ok=True)
-    headers = [os.path.join(CSRC, "alp_internal.h"), os.path.join(CSRC, "alp_point_kernels.h"), os.path.join(CSRC, "alp_raster_internal.h"),
-               os.path.join(INCLUDE, "alproj_hip.h"),
-               os.path.abspath(__file__)]
+    headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + \
+              [os.path.join(INCLUDE, "alproj_hip.h"), os.path.abspath(__file__)]
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
              f"-I{INCLUDE}", f"-I{CSRC}"]
     objs = []

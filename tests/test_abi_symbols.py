@@ -95,9 +95,14 @@ def test_shipped_library_has_no_development_switch():
     by design, behind -DALP_DEV; the library the tests and the bench load must have been compiled with none"""
     from alproj_amd import _lib
     assert _lib.build_flags() == ""
-    src = open(os.path.join(ROOT, "alproj_amd", "csrc", "alp_raster.hip")).read()
+    csrc = os.path.join(ROOT, "alproj_amd", "csrc")
+    src = open(os.path.join(csrc, "alp_raster.hip")).read()
     head = src[:src.index("namespace alp {")]
-    for switch in re.findall(r"#\s*if(?:def|ndef)?\s+(?:defined\()?([A-Z][A-Z0-9_]+)", src):
-        if switch.startswith(("ALP_DEV", "__")):
-            continue
-        assert switch in head, f"{switch} is used in alp_raster.hip but not listed in its development-switch guard"
+    stages = re.findall(r'#include "(raster_[a-z]+\.h)"', src)
+    assert len(stages) >= 6
+    for name in ["alp_raster.hip"] + stages:
+        text = open(os.path.join(csrc, name)).read()
+        for switch in re.findall(r"#\s*(?:if|elif)(?:def|ndef)?\s+(?:!?defined\()?([A-Z][A-Z0-9_]+)", text):
+            if switch.startswith(("ALP_DEV", "__")):
+                continue
+            assert switch in head, f"{switch} is used in {name} but not listed in the development-switch guard of alp_raster.hip"
