@@ -696,7 +696,55 @@ int alp_mesh_create(const void *vert, int vert_dtype, const void *value, int val
     if (hipMalloc((void **)&m->qcount_dev, QC_TOTAL * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void **)&m->qcount_host, QC_TOTAL * sizeof(unsigned), hipHostMallocDefault) != hipSuccess)
         return bail(fail(ALP_EHIP, "hipMalloc queue counter"));
-    if (!implicit && n_tri > 0) {
+    const bool detect = !getenv("ALP_NO_GRID_DETECT");       // env: keep the index path (tests, benchmarks)
+    // The index array the reference builds (surface.py:194-201) is the full regular grid unless nodata triangles were
+    // filtered out.  An array with the grid's first triangle and exactly its triangle count is CHECKED WHILE IT
+    // STREAMS through the staging buffer and never stored: no 12 B/triangle buffer is allocated (a fresh 2.4 GB
+    // allocation costs ~20 ms of first-touch at 100 M vertices), nothing is narrowed or written, and the mesh is
+    // rendered by the LDS-tiled grid kernels (same triangle ids, same result, no index traffic).  If a chunk
+    // disagrees -- an array that only starts like the grid -- the general path below uploads it again.
+    bool streamed_grid = false;
+    if (!implicit && detect && n_tri >= 2 && (n_tri & 1) == 0) {
+        long long first[3];
+        for (int k = 0; k < 3; ++k)
+            first[k] = ind_dtype == ALP_I32 ? (long long)((const int *)ind)[k] : ((const long long *)ind)[k];
+        const long long gw = first[1] - first[0];
+        if (first[0] == 0 && gw >= 2 && first[2] == gw + 1 && n_vert % gw == 0) {
+            const long long gh = n_vert / gw;
+            if (gh >= 2 && n_tri == 2 * (gh - 1) * (gw - 1)) {
+                hipStream_t st = ctx().stream;
+                const size_t esize = ind_dtype == ALP_I32 ? 4 : 8;
+                const int64_t total = n_tri * 3;
+                const int64_t CH = (int64_t)(((size_t)192 << 20) / esize) / 3 * 3;      // whole triangles per chunk
+                const int64_t ch = total < CH ? total : CH;
+                void *stage = nullptr;
+                if ((rc = scratch_reserve((size_t)ch * esize, &stage))) return bail(rc);
+                hipError_t e = hipMemsetAsync(m->qcount_dev, 0, sizeof(unsigned), st);
+                for (int64_t off = 0; off < total && e == hipSuccess; off += ch) {
+                    const int64_t cnt = total - off < ch ? total - off : ch;
+                    e = hipMemcpyAsync(stage, (const char *)ind + (size_t)off * esize, (size_t)cnt * esize, hipMemcpyHostToDevice, st);
+                    if (e != hipSuccess) break;
+                    if (ind_dtype == ALP_I32)
+                        hipLaunchKernelGGL(check_grid_chunk_kernel<int>, dim3(4096), dim3(256), 0, st, (const int *)stage, cnt / 3, off / 3, gw, m->qcount_dev);
+                    else
+                        hipLaunchKernelGGL(check_grid_chunk_kernel<long long>, dim3(4096), dim3(256), 0, st, (const long long *)stage, cnt / 3, off / 3, gw,
+                                           m->qcount_dev);
+                    e = hipGetLastError();
+                }
+                if (e == hipSuccess) e = hipMemcpyAsync(m->qcount_host, m->qcount_dev, sizeof(unsigned), hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipStreamSynchronize(st);
+                if (e != hipSuccess) return bail(fail(ALP_EHIP, "grid check: %s", hipGetErrorString(e)));
+                if (*m->qcount_host == 0) {
+                    streamed_grid = true;
+                    m->implicit = true;
+                    m->grid_h = gh;
+                    m->grid_w = gw;
+                }
+            }
+        }
+    }
+    const bool want_ind = !implicit && n_tri > 0 && !streamed_grid;
+    if (want_ind) {
         hipStream_t st = ctx().stream;
         if (hipMalloc((void **)&m->ind, (size_t)n_tri * 12) != hipSuccess) return bail(fail(ALP_EHIP, "hipMalloc ind"));
         if (hipMemsetAsync(m->qcount_dev, 0, sizeof(unsigned), st) != hipSuccess) return bail(fail(ALP_EHIP, "index check: memset"));
@@ -736,37 +784,8 @@ int alp_mesh_create(const void *vert, int vert_dtype, const void *value, int val
     }
     if ((rc = ensure_queue(m, initial_queue_cap()))) return bail(rc);
     if ((rc = ensure_gqueue(m, initial_queue_cap()))) return bail(rc);
-    // The index array the reference builds (surface.py:194-201) is the full regular grid unless
-    // nodata triangles were filtered out: recognise it, drop the 12 B/triangle array and use the
-    // LDS-tiled grid kernel (same triangle ids, same result, no index traffic).
-    if (!implicit && n_tri >= 2 && (n_tri & 1) == 0 && !getenv("ALP_NO_GRID_DETECT")) {   // env: keep the index path (tests, benchmarks)
-        long long first[3];
-        for (int k = 0; k < 3; ++k)
-            first[k] = ind_dtype == ALP_I32 ? (long long)((const int *)ind)[k] : ((const long long *)ind)[k];
-        const long long gw = first[1] - first[0];
-        if (first[0] == 0 && gw >= 2 && first[2] == gw + 1 && n_vert % gw == 0) {
-            const long long gh = n_vert / gw;
-            if (gh >= 2 && n_tri == 2 * (gh - 1) * (gw - 1)) {
-                if (hipMemsetAsync(m->qcount_dev, 0, sizeof(unsigned), ctx().stream) != hipSuccess)
-                    return bail(fail(ALP_EHIP, "grid check: memset"));
-                hipLaunchKernelGGL(check_grid_kernel, dim3(ctx().cu_count * 8), dim3(256), 0, ctx().stream, m->ind,
-                                   (long long)n_tri, gw, m->qcount_dev);
-                hipError_t e = hipMemcpyAsync(m->qcount_host, m->qcount_dev, sizeof(unsigned), hipMemcpyDeviceToHost,
-                                              ctx().stream);
-                if (e == hipSuccess) e = hipStreamSynchronize(ctx().stream);
-                if (e != hipSuccess) return bail(fail(ALP_EHIP, "grid check: %s", hipGetErrorString(e)));
-                if (*m->qcount_host == 0) {
-                    hipFree(m->ind);
-                    m->ind = nullptr;
-                    m->implicit = true;
-                    m->grid_h = gh;
-                    m->grid_w = gw;
-                }
-            }
-        }
-    }
     // ... and when they were (surface.py:203-205), the grid with a vertex mask
-    if (!implicit && !m->implicit && n_tri >= 1 && !getenv("ALP_NO_GRID_DETECT")) {
+    if (!implicit && !m->implicit && n_tri >= 1 && detect) {
         long long first[3];
         for (int k = 0; k < 3; ++k)
             first[k] = ind_dtype == ALP_I32 ? (long long)((const int *)ind)[k] : ((const long long *)ind)[k];

@@ -131,14 +131,16 @@ __global__ __launch_bounds__(256) void valid_write_kernel(const float *__restric
     }
 }
 
-// does an index array spell out exactly the regular grid of surface.py:194-201 with gw columns?
-__global__ __launch_bounds__(256) void check_grid_kernel(const int *__restrict__ ind, long long n_tri, long long gw,
-                                                         unsigned *__restrict__ mismatch) {
+// does an index array spell out exactly the regular grid of surface.py:194-201 with gw columns?  One staged chunk of
+// the caller's array (int32 or int64 as it came): triangles [t0, t0 + n_tri) of the grid.
+template <typename I>
+__global__ __launch_bounds__(256) void check_grid_chunk_kernel(const I *__restrict__ chunk, long long n_tri, long long t0, long long gw,
+                                                               unsigned *__restrict__ mismatch) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     bool bad = false;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n_tri; t += stride) {
-        const Idx3 e = tri_vertices<true>(nullptr, gw, t);
-        bad |= ind[3 * t] != e.a || ind[3 * t + 1] != e.b || ind[3 * t + 2] != e.c;
+        const Idx3 e = tri_vertices<true>(nullptr, gw, t0 + t);
+        bad |= (long long)chunk[3 * t] != e.a || (long long)chunk[3 * t + 1] != e.b || (long long)chunk[3 * t + 2] != e.c;
     }
     if (bad) *mismatch = 1u;
 }
