@@ -40,7 +40,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import gen_golden as gg                # noqa: E402
 import moderngl_standin as mgl         # noqa: E402
 from alproj_amd import synthetic as syn          # noqa: E402
-from tests.render_scenes import GL_SCENES        # noqa: E402
+from tests.render_scenes import GL_SCENES, IMAGE_STRIDE        # noqa: E402
 
 
 def main():
@@ -78,7 +78,8 @@ def main():
         mgl.DEPTH_FUNC, mgl.KEEP_DIAGNOSTICS = None, True
         img = prj.persp_proj(*args)
         assert rec["identity"] and img.dtype == np.float32
-        out[f"{name}_image"] = img
+        st = IMAGE_STRIDE.get(name, 1)
+        out[f"{name}_image"] = np.ascontiguousarray(img[::-1][::st, ::st][::-1]) if st > 1 else img     # strided in WINDOW rows / columns
         out[f"{name}_prim_id"] = mgl.LAST["prim_id"].astype(np.int32)       # window orientation (row 0 = bottom)
         if name == "grid_far_3km":
             out[f"{name}_depth24"] = np.rint(mgl.LAST["depth"].astype(np.float64) * (2 ** 24 - 1)).astype(np.uint32)

@@ -79,10 +79,26 @@ def _coloured():
     return s
 
 
+def _big_cells_scene():
+    """a low camera over coarse terrain on a larger frame: cells of 5 ... 100 px next to sub-pixel ones in one image, so that
+    the HIP path goes through its LDS depth patches, parked cells, parked triangles and the 64 x 64-pixel work items of
+    large triangles (the small scenes above stay on the small-cell paths)"""
+    n, res, w, h = 160, 3.0, 960, 640
+    s = syn.surface(n, res=res)
+    p = dict(syn.base_params(n, res), w=w, h=h, cx=w / 2.0, cy=h / 2.0, tilt=-14.0, fov=62.0, pan=98.0)
+    p["z"] -= 38.0                                   # 12 m above the ground
+    return dict(vert=s["vert"], ind=None, grid=(n, n), params=p, offsets=s["offsets"])
+
+
+# scenes whose fixture keeps gl_PrimitiveID for every pixel but GL's image only on every IMAGE_STRIDE-th pixel of both
+# axes (the frame is large; the values are asserted on that subset)
+IMAGE_STRIDE = {"grid_big_cells": 4}
+
 GL_SCENES = dict(SCENES)
 GL_SCENES.update({
     "grid_colours": _coloured,                                                # sim_image's call (project.py:322)
     "grid_min_distance": _with("grid_tilted", min_distance=60.0),             # project.py:235,247
     "grid_nodata_indices": _nodata_scene,
     "grid_far_3km": _far_scene,
+    "grid_big_cells": _big_cells_scene,
 })
