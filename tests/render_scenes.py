@@ -81,12 +81,12 @@ def _coloured():
 
 def _big_cells_scene():
     """a low camera over coarse terrain on a larger frame: cells of 5 ... 100 px next to sub-pixel ones in one image, so that
-    the HIP path goes through its LDS depth patches, parked cells, parked triangles and the 64 x 64-pixel work items of
-    large triangles (the small scenes above stay on the small-cell paths)"""
-    n, res, w, h = 160, 3.0, 960, 640
+    the HIP path goes through its LDS depth patches, FAST cells, parked cells and parked triangles in one frame (the small
+    scenes above stay on the small-cell paths)"""
+    n, res, w, h = 400, 2.0, 960, 640
     s = syn.surface(n, res=res)
-    p = dict(syn.base_params(n, res), w=w, h=h, cx=w / 2.0, cy=h / 2.0, tilt=-14.0, fov=62.0, pan=98.0)
-    p["z"] -= 38.0                                   # 12 m above the ground
+    p = dict(syn.base_params(n, res), w=w, h=h, cx=w / 2.0, cy=h / 2.0, tilt=-12.0, fov=62.0, pan=98.0)
+    p["z"] -= 22.0                                   # 28 m above the ground
     return dict(vert=s["vert"], ind=None, grid=(n, n), params=p, offsets=s["offsets"])
 
 
