@@ -61,7 +61,7 @@ def build(force=False, verbose=False):
                 raise RuntimeError(f"hipcc failed on {src}")
     if force or _stale(LIB, objs):
         cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + \
-              ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+              ["-L/opt/rocm/lib", "-lrccl", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -74,6 +74,7 @@ _SIGNATURES = {
     "alp_mesh_create": [_c_void_p, _c_int, _c_void_p, _c_int, _c_i64, _c_void_p, _c_int, _c_i64, _c_i64, _c_i64,
                         ctypes.POINTER(_c_void_p)],
     "alp_mesh_destroy": [_c_void_p],
+    "alp_mesh_info": [_c_void_p, ctypes.POINTER(_c_i64)],
     "alp_render": [_c_void_p, _c_dp, _c_dp, _c_double, _c_fp],
     "alp_render_enqueue": [_c_void_p, _c_dp, _c_dp, _c_double],
     "alp_render_fetch": [_c_void_p, _c_fp],
@@ -344,6 +345,12 @@ class Mesh:
                 raise ValueError("value must have shape (n_vert, 3)")
             check(self._lib.alp_mesh_set_value(self._h, value.ctypes.data_as(_c_void_p), dtype_code(value)))
         self.has_value = value is not None
+
+    def info(self):
+        """dict(implicit, grid_h, grid_w, n_tri): how the library holds the mesh (alp_mesh_info)"""
+        c = (_c_i64 * 4)()
+        check(self._lib.alp_mesh_info(self._h, c))
+        return dict(implicit=bool(c[0]), grid_h=int(c[1]), grid_w=int(c[2]), n_tri=int(c[3]))
 
     def frame_counts(self):
         """(full frames, frames served from the visibility cache by the resolve stage alone)"""

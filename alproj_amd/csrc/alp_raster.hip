@@ -46,9 +46,11 @@
 #include "alp_raster_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstdlib>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -659,6 +661,67 @@ int alp::upload_f32(float *dst, const void *src, int dtype, int64_t n_vert) {
     return ALP_OK;
 }
 
+// Is a host index array exactly the regular grid of surface.py:194-201 with gw columns?  Answered by a few host threads
+// WHILE the vertices and colours cross PCIe: a full-grid array then never crosses it at all (4.8 GB of int64 at 100 M
+// vertices = 86 ms of PCIe time, a third of the reference-typed first call).  Each thread walks whole grid rows of its
+// share of the cells (a streaming compare against a + {0, gw, gw+1, 0, gw+1, 1}); the first mismatch stops everybody.
+namespace {
+template <typename I>
+void grid_rows_check(const I *ind, long long gw, long long row0, long long row1, std::atomic<bool> *bad) {
+    const long long gc = gw - 1;
+    for (long long r = row0; r < row1 && !bad->load(std::memory_order_relaxed); ++r) {
+        const I *p = ind + (size_t)r * gc * 6;
+        long long a = r * gw;
+        bool diff = false;
+        for (long long c = 0; c < gc; ++c, ++a, p += 6)
+            diff |= (long long)p[0] != a || (long long)p[1] != a + gw || (long long)p[2] != a + gw + 1 || (long long)p[3] != a ||
+                    (long long)p[4] != a + gw + 1 || (long long)p[5] != a + 1;
+        if (diff) bad->store(true, std::memory_order_relaxed);
+    }
+}
+
+struct HostGridCheck {
+    std::vector<std::thread> threads;
+    std::atomic<bool> bad{false};
+    bool started = false;
+    void start(const void *ind, int ind_dtype, long long gh, long long gw, int n_threads) {
+        const long long rows = gh - 1;
+        const int T = (int)std::min<long long>(n_threads, rows);
+        try {
+            for (int t = 0; t < T; ++t) {
+                const long long r0 = rows * t / T, r1 = rows * (t + 1) / T;
+                if (ind_dtype == ALP_I32) threads.emplace_back(grid_rows_check<int>, (const int *)ind, gw, r0, r1, &bad);
+                else threads.emplace_back(grid_rows_check<long long>, (const long long *)ind, gw, r0, r1, &bad);
+            }
+            started = true;
+        } catch (...) {               // no threads to be had: the caller falls back to the check on the device
+            bad.store(true);
+            join();
+            bad.store(false);
+            started = false;
+        }
+    }
+    void join() {
+        for (auto &t : threads)
+            if (t.joinable()) t.join();
+        threads.clear();
+    }
+    bool is_grid() {                   // joins
+        join();
+        return started && !bad.load();
+    }
+    ~HostGridCheck() { bad.store(true); join(); }
+};
+
+// host threads for HostGridCheck: ALP_HOST_THREADS (0 = check on the device instead), else up to 8 of the machine's
+int host_check_threads(int64_t n_tri) {
+    if (const char *e = getenv("ALP_HOST_THREADS")) return std::max(0, std::min(64, atoi(e)));     // tests: either path at any size
+    if (n_tri < (1 << 18)) return 0;           // small arrays: the staged check costs nothing
+    const unsigned hc = std::thread::hardware_concurrency();
+    return hc >= 4 ? (int)std::min(8u, hc / 2) : 0;
+}
+}  // namespace
+
 extern "C" {
 
 int alp_mesh_create(const void *vert, int vert_dtype, const void *value, int value_dtype, int64_t n_vert, const void *ind,
@@ -687,6 +750,25 @@ int alp_mesh_create(const void *vert, int vert_dtype, const void *value, int val
     m->implicit = implicit;
     int rc = ALP_OK;
     auto bail = [&](int code) { alp_mesh_destroy(m); return code; };
+    // The index array the reference builds (surface.py:194-201) is the full regular grid unless nodata triangles were
+    // filtered out: an array with the grid's first triangle and exactly its triangle count is a candidate
+    const bool detect = !getenv("ALP_NO_GRID_DETECT");       // env: keep the index path (tests, benchmarks)
+    long long cand_gh = 0, cand_gw = 0;
+    if (!implicit && detect && n_tri >= 2 && (n_tri & 1) == 0) {
+        long long first[3];
+        for (int k = 0; k < 3; ++k)
+            first[k] = ind_dtype == ALP_I32 ? (long long)((const int *)ind)[k] : ((const long long *)ind)[k];
+        const long long gw = first[1] - first[0];
+        if (first[0] == 0 && gw >= 2 && first[2] == gw + 1 && n_vert % gw == 0) {
+            const long long gh = n_vert / gw;
+            if (gh >= 2 && n_tri == 2 * (gh - 1) * (gw - 1)) { cand_gh = gh; cand_gw = gw; }
+        }
+    }
+    HostGridCheck host_check;                 // its destructor joins on every way out of this function
+    if (cand_gw) {
+        const int T = host_check_threads(n_tri);
+        if (T > 0) host_check.start(ind, ind_dtype, cand_gh, cand_gw, T);
+    }
     if (hipMalloc((void **)&m->vert, (size_t)n_vert * 12) != hipSuccess) return bail(fail(ALP_EHIP, "hipMalloc vert"));
     if ((rc = upload_f32(m->vert, vert, vert_dtype, n_vert))) return bail(rc);
     if (value) {
@@ -696,51 +778,45 @@ int alp_mesh_create(const void *vert, int vert_dtype, const void *value, int val
     if (hipMalloc((void **)&m->qcount_dev, QC_TOTAL * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void **)&m->qcount_host, QC_TOTAL * sizeof(unsigned), hipHostMallocDefault) != hipSuccess)
         return bail(fail(ALP_EHIP, "hipMalloc queue counter"));
-    const bool detect = !getenv("ALP_NO_GRID_DETECT");       // env: keep the index path (tests, benchmarks)
-    // The index array the reference builds (surface.py:194-201) is the full regular grid unless nodata triangles were
-    // filtered out.  An array with the grid's first triangle and exactly its triangle count is CHECKED WHILE IT
-    // STREAMS through the staging buffer and never stored: no 12 B/triangle buffer is allocated (a fresh 2.4 GB
-    // allocation costs ~20 ms of first-touch at 100 M vertices), nothing is narrowed or written, and the mesh is
-    // rendered by the LDS-tiled grid kernels (same triangle ids, same result, no index traffic).  If a chunk
-    // disagrees -- an array that only starts like the grid -- the general path below uploads it again.
+    // ... checked by the host threads started above while the vertices were uploaded -- then the array never crosses
+    // PCIe -- or, where there are no threads to spare, WHILE IT STREAMS through the staging buffer; either way a full
+    // grid is never stored: no 12 B/triangle buffer is allocated, nothing is narrowed or written, and the mesh is
+    // rendered by the LDS-tiled grid kernels (same triangle ids, same result, no index traffic).  An array that only
+    // starts like the grid takes the general path below.
     bool streamed_grid = false;
-    if (!implicit && detect && n_tri >= 2 && (n_tri & 1) == 0) {
-        long long first[3];
-        for (int k = 0; k < 3; ++k)
-            first[k] = ind_dtype == ALP_I32 ? (long long)((const int *)ind)[k] : ((const long long *)ind)[k];
-        const long long gw = first[1] - first[0];
-        if (first[0] == 0 && gw >= 2 && first[2] == gw + 1 && n_vert % gw == 0) {
-            const long long gh = n_vert / gw;
-            if (gh >= 2 && n_tri == 2 * (gh - 1) * (gw - 1)) {
-                hipStream_t st = ctx().stream;
-                const size_t esize = ind_dtype == ALP_I32 ? 4 : 8;
-                const int64_t total = n_tri * 3;
-                const int64_t CH = (int64_t)(((size_t)192 << 20) / esize) / 3 * 3;      // whole triangles per chunk
-                const int64_t ch = total < CH ? total : CH;
-                void *stage = nullptr;
-                if ((rc = scratch_reserve((size_t)ch * esize, &stage))) return bail(rc);
-                hipError_t e = hipMemsetAsync(m->qcount_dev, 0, sizeof(unsigned), st);
-                for (int64_t off = 0; off < total && e == hipSuccess; off += ch) {
-                    const int64_t cnt = total - off < ch ? total - off : ch;
-                    e = hipMemcpyAsync(stage, (const char *)ind + (size_t)off * esize, (size_t)cnt * esize, hipMemcpyHostToDevice, st);
-                    if (e != hipSuccess) break;
-                    if (ind_dtype == ALP_I32)
-                        hipLaunchKernelGGL(check_grid_chunk_kernel<int>, dim3(4096), dim3(256), 0, st, (const int *)stage, cnt / 3, off / 3, gw, m->qcount_dev);
-                    else
-                        hipLaunchKernelGGL(check_grid_chunk_kernel<long long>, dim3(4096), dim3(256), 0, st, (const long long *)stage, cnt / 3, off / 3, gw,
-                                           m->qcount_dev);
-                    e = hipGetLastError();
-                }
-                if (e == hipSuccess) e = hipMemcpyAsync(m->qcount_host, m->qcount_dev, sizeof(unsigned), hipMemcpyDeviceToHost, st);
-                if (e == hipSuccess) e = hipStreamSynchronize(st);
-                if (e != hipSuccess) return bail(fail(ALP_EHIP, "grid check: %s", hipGetErrorString(e)));
-                if (*m->qcount_host == 0) {
-                    streamed_grid = true;
-                    m->implicit = true;
-                    m->grid_h = gh;
-                    m->grid_w = gw;
-                }
+    if (cand_gw) {
+        const long long gh = cand_gh, gw = cand_gw;
+        if (host_check.started) {
+            streamed_grid = host_check.is_grid();
+        } else {
+            hipStream_t st = ctx().stream;
+            const size_t esize = ind_dtype == ALP_I32 ? 4 : 8;
+            const int64_t total = n_tri * 3;
+            const int64_t CH = (int64_t)(((size_t)192 << 20) / esize) / 3 * 3;      // whole triangles per chunk
+            const int64_t ch = total < CH ? total : CH;
+            void *stage = nullptr;
+            if ((rc = scratch_reserve((size_t)ch * esize, &stage))) return bail(rc);
+            hipError_t e = hipMemsetAsync(m->qcount_dev, 0, sizeof(unsigned), st);
+            for (int64_t off = 0; off < total && e == hipSuccess; off += ch) {
+                const int64_t cnt = total - off < ch ? total - off : ch;
+                e = hipMemcpyAsync(stage, (const char *)ind + (size_t)off * esize, (size_t)cnt * esize, hipMemcpyHostToDevice, st);
+                if (e != hipSuccess) break;
+                if (ind_dtype == ALP_I32)
+                    hipLaunchKernelGGL(check_grid_chunk_kernel<int>, dim3(4096), dim3(256), 0, st, (const int *)stage, cnt / 3, off / 3, gw, m->qcount_dev);
+                else
+                    hipLaunchKernelGGL(check_grid_chunk_kernel<long long>, dim3(4096), dim3(256), 0, st, (const long long *)stage, cnt / 3, off / 3, gw,
+                                       m->qcount_dev);
+                e = hipGetLastError();
             }
+            if (e == hipSuccess) e = hipMemcpyAsync(m->qcount_host, m->qcount_dev, sizeof(unsigned), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) return bail(fail(ALP_EHIP, "grid check: %s", hipGetErrorString(e)));
+            streamed_grid = *m->qcount_host == 0;
+        }
+        if (streamed_grid) {
+            m->implicit = true;
+            m->grid_h = gh;
+            m->grid_w = gw;
         }
     }
     const bool want_ind = !implicit && n_tri > 0 && !streamed_grid;
@@ -792,6 +868,15 @@ int alp_mesh_create(const void *vert, int vert_dtype, const void *value, int val
         if ((rc = try_subgrid(m, first))) return bail(rc);
     }
     *out = m;
+    return ALP_OK;
+}
+
+int alp_mesh_info(alp_mesh_t *m, int64_t info[4]) {
+    ALP_REQUIRE(m && info, "NULL argument");
+    info[0] = m->implicit ? 1 : 0;
+    info[1] = m->grid_h;
+    info[2] = m->grid_w;
+    info[3] = m->n_tri;
     return ALP_OK;
 }
 

@@ -214,8 +214,10 @@ int alp_loss_uv(const double *observed, const double *projected, int64_t n, int 
  *        regular grid of src/alproj/surface.py:194-201 with grid_h x grid_w vertices
  *        (n_vert == grid_h * grid_w; vertex id = row * grid_w + col).
  *        An index array that IS that grid, or that grid with the triangles of nodata
- *        vertices removed (src/alproj/surface.py:203-205, order kept), is recognised on the
- *        device and rendered by the grid kernels (same result, no 12 B/triangle index reads);
+ *        vertices removed (src/alproj/surface.py:203-205, order kept), is recognised and
+ *        rendered by the grid kernels (same result, no 12 B/triangle index reads); the full
+ *        grid is recognised by host threads while the vertices are uploaded (or, without
+ *        threads to spare, while it streams through the staging buffer) and is never stored;
  *        triangle ids reported by alp_render_fetch_visibility stay positions in `ind`.
  *        Indices outside [0, n_vert) are rejected (ALP_EINVAL; checked on the device).
  * (ABI 3: vert_dtype / value_dtype added; ABI 2 took float32 pointers only.)
@@ -226,6 +228,11 @@ int alp_mesh_create(const void *vert, int vert_dtype, const void *value, int val
                     int64_t n_vert, const void *ind, int ind_dtype, int64_t n_tri,
                     int64_t grid_h, int64_t grid_w, alp_mesh_t **out);
 int alp_mesh_destroy(alp_mesh_t *mesh);
+/* How the mesh is held: info[0] = 1 when it is rendered as the implicit regular grid (given as
+ * one, or an index array recognised as one -- possibly with a derived vertex mask), 0 when
+ * through its index array; info[1], info[2] = grid rows, columns (0 for index meshes);
+ * info[3] = number of triangles the kernels enumerate. */
+int alp_mesh_info(alp_mesh_t *mesh, int64_t info[4]);
 
 /* Replace (or, with NULL, drop) the stored per-vertex values of a resident mesh: sim_image's
  * colours for a mesh that reverse_proj created without any, src/alproj/project.py:214.  The

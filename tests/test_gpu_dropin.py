@@ -173,3 +173,38 @@ def test_reference_call_pattern_keeps_the_mesh_resident(L, scene):
     sim4 = aproj.sim_image(moved, col, ind, p, off)
     assert aproj._cache["mesh"] is not held and (sim4 != sim3).any()
     aproj.clear_mesh_cache()
+
+
+@pytest.mark.parametrize("threads", ["0", "1", "5"], ids=["checked_on_the_device", "one_host_thread", "five_host_threads"])
+@pytest.mark.parametrize("dtype", [np.int32, np.int64])
+def test_full_grid_index_arrays_are_recognised_and_never_stored(L, scene, dtype, threads, monkeypatch):
+    """the index array the reference builds (surface.py:194-201) is recognised as the regular grid -- by host threads
+    while the vertices cross PCIe (then it never crosses it), or while it streams through the staging buffer -- and the
+    mesh is held without it; an array that differs from the grid in ONE index, anywhere, keeps its index path and is
+    drawn as it is written; either way the frame is the oracle's for that array"""
+    monkeypatch.setenv("ALP_HOST_THREADS", threads)
+    n = scene["n"]
+    v32 = scene["vert64"].astype(np.float32)
+    p = scene["params"]
+    pv = L.params_vector(p)
+    ind = scene["ind64"].astype(dtype)
+    ref = orast.visibility(v32, None, p, scene["offsets"], grid=(n, n))
+    with L.Mesh(scene["vert64"], None, ind) as m:
+        assert m.info() == dict(implicit=True, grid_h=n, grid_w=n, n_tri=2 * (n - 1) ** 2)
+        m.render_enqueue(pv, scene["offsets"])
+        np.testing.assert_array_equal(m.fetch_visibility(), ref)
+    rng = np.random.default_rng(3)
+    for where in (1, len(ind) // 2 + 7, len(ind) - 1):            # second triangle, the middle, the very last
+        bad = ind.copy()
+        bad[where, rng.integers(0, 3)] = rng.integers(0, n * n)      # still a valid vertex, no longer the grid
+        if np.array_equal(bad, ind):
+            continue
+        with L.Mesh(scene["vert64"], None, bad) as m:
+            assert not m.info()["implicit"] and m.info()["n_tri"] == len(bad)
+            m.render_enqueue(pv, scene["offsets"])
+            np.testing.assert_array_equal(m.fetch_visibility(), orast.visibility(v32, bad, p, scene["offsets"]))
+    # the first triangle decides whether an array is a candidate at all; a permuted one is not
+    swapped = ind.copy()
+    swapped[[0, 5]] = swapped[[5, 0]]
+    with L.Mesh(scene["vert64"], None, swapped) as m:
+        assert not m.info()["implicit"]
