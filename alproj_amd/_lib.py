@@ -90,6 +90,7 @@ _SIGNATURES = {
     "alp_render_load": [_c_void_p, _c_fp, _c_i64, _c_i64],
     "alp_render_valid_count": [_c_void_p, ctypes.POINTER(_c_i64)],
     "alp_render_fetch_valid": [_c_void_p, _c_dp, ctypes.POINTER(ctypes.c_uint32), _c_dp],
+    "alp_render_fetch_valid_planes": [_c_void_p, _c_dp, ctypes.POINTER(ctypes.c_uint32), _c_dp, _c_dp, _c_dp],
     "alp_render_gather": [_c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), _c_i64, _c_dp,
                           _c_dp],
     "alp_rasterize_points": [_c_dp, _c_dp, _c_dp, _c_i64, _c_i64, _c_double, _c_double, _c_double, _c_i64, _c_i64,
@@ -507,6 +508,20 @@ class Mesh:
                                              float(y_max), float(resolution), int(width), int(height), int(agg),
                                              int(sweeps), int(nodata), out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))))
         return out
+
+    def fetch_valid_block(self, offsets=None, extra_rows=0):
+        """Like ``fetch_valid`` but as (idx (M,), block (3 + extra_rows, M) float64): rows 0..2 = x, y, z, each contiguous
+        (the layout of a DataFrame's float64 block); the extra rows are left for the caller's channel columns."""
+        n = _c_i64()
+        check(self._lib.alp_render_valid_count(self._h, ctypes.byref(n)))
+        M = int(n.value)
+        idx = np.empty(M, dtype=np.uint32)
+        block = np.empty((3 + int(extra_rows), M), dtype=np.float64)
+        off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.float64)
+        check(self._lib.alp_render_fetch_valid_planes(self._h, None if off is None else as_dp(off),
+                                                      idx.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                                                      as_dp(block[0]), as_dp(block[1]), as_dp(block[2])))
+        return idx, block
 
     def gather(self, u, v, offsets=None):
         """After a render of the vertices themselves: (n, 3) float64 x, y, z seen by the pixels

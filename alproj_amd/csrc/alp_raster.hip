@@ -317,13 +317,13 @@ int frame_valid_count(alp_mesh *m, int64_t *count) {
     return ALP_OK;
 }
 
-int frame_valid_write(alp_mesh *m, const double *offsets, unsigned *idx_dev, double *xyz_dev) {
+int frame_valid_write(alp_mesh *m, const double *offsets, unsigned *idx_dev, double *xyz_dev, bool planar) {
     const long long npix = (long long)m->w * m->h;
     const int chunks = (int)((npix + COMPACT_CHUNK - 1) / COMPACT_CHUNK);
     const double o0 = offsets ? offsets[0] : 0.0, o1 = offsets ? offsets[1] : 0.0, o2 = offsets ? offsets[2] : 0.0;
     ktime_begin();
     hipLaunchKernelGGL(valid_write_kernel, dim3(chunks), dim3(256), 0, ctx().stream, m->image, npix, m->compact_offsets, o0, o1,
-                       o2, idx_dev, xyz_dev);
+                       o2, idx_dev, xyz_dev, planar ? 1ll : 3ll, planar ? (long long)m->valid_total_planes : 1ll);
     ktime_end();
     ALP_HIP(hipGetLastError());
     return ALP_OK;
@@ -1006,11 +1006,36 @@ int alp_render_fetch_valid(alp_mesh_t *m, const double *offsets, uint32_t *idx_o
     double *xyz_dev = (double *)dev;
     unsigned *idx_dev = (unsigned *)(dev + xyz_bytes);
     hipStream_t st = ctx().stream;
-    if (int rc = frame_valid_write(m, offsets, idx_dev, xyz_dev)) return rc;
+    if (int rc = frame_valid_write(m, offsets, idx_dev, xyz_dev, false)) return rc;
     hipError_t e = hipMemcpyAsync(xyz_out, xyz_dev, xyz_bytes, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(idx_out, idx_dev, idx_bytes, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return fail(ALP_EHIP, "alp_render_fetch_valid: %s", hipGetErrorString(e));
+    return ALP_OK;
+}
+
+int alp_render_fetch_valid_planes(alp_mesh_t *m, const double *offsets, uint32_t *idx_out, double *x_out, double *y_out, double *z_out) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(m, "mesh handle is NULL");
+    if (m->valid_total < 0) return fail(ALP_ESTATE, "alp_render_fetch_valid_planes: call alp_render_valid_count first");
+    const int64_t M = m->valid_total;
+    m->valid_total = -1;
+    if (M == 0) return ALP_OK;
+    ALP_REQUIRE(idx_out && x_out && y_out && z_out, "output is NULL");
+    char *dev = nullptr;
+    const size_t plane = (size_t)M * sizeof(double), idx_bytes = (size_t)M * sizeof(unsigned);
+    if (int rc = scratch_reserve(3 * plane + idx_bytes, (void **)&dev)) return rc;
+    double *xyz_dev = (double *)dev;
+    unsigned *idx_dev = (unsigned *)(dev + 3 * plane);
+    hipStream_t st = ctx().stream;
+    m->valid_total_planes = M;
+    if (int rc = frame_valid_write(m, offsets, idx_dev, xyz_dev, true)) return rc;
+    hipError_t e = hipMemcpyAsync(x_out, xyz_dev, plane, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(y_out, xyz_dev + M, plane, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(z_out, xyz_dev + 2 * M, plane, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(idx_out, idx_dev, idx_bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return fail(ALP_EHIP, "alp_render_fetch_valid_planes: %s", hipGetErrorString(e));
     return ALP_OK;
 }
 

@@ -89,6 +89,7 @@ struct alp_mesh {
     unsigned long long *compact_offsets = nullptr;
     int compact_cap = 0;
     int64_t valid_total = -1;
+    int64_t valid_total_planes = 0;     // plane length of the planar form of frame_valid_write
     // alp_render_rasterize_plan -> alp_render_rasterize: the compacted points of the current frame (device):
     // x[M] | y[M] float64, then the pixel index idx[M] uint32
     char *rz_points = nullptr;
@@ -107,7 +108,7 @@ constexpr int QC_STRIDE = 8;           // counters per round
 constexpr int QC_TOTAL = 2 * QC_STRIDE + 8;   // two rounds of queue counters, three tile-list counters (+1), the FAR tiles' screen region (4)
 unsigned initial_queue_cap();
 int frame_valid_count(alp_mesh *m, int64_t *count);
-int frame_valid_write(alp_mesh *m, const double *offsets, unsigned *idx_dev, double *xyz_dev);
+int frame_valid_write(alp_mesh *m, const double *offsets, unsigned *idx_dev, double *xyz_dev, bool planar);
 // valid = (mask implied by a filtered grid index array) AND `user` (host, n_vert bytes; NULL = all ones)
 int apply_derived_mask(alp_mesh *m, const unsigned char *user);
 }  // namespace alp

@@ -433,7 +433,7 @@ extern "C" int alp_render_rasterize_plan(alp_mesh_t *m, const double *offsets, i
     double *xyz = (double *)dev;
     unsigned long long *mm = (unsigned long long *)(dev + (size_t)M * 3 * sizeof(double));
     hipStream_t st = ctx().stream;
-    if (int rc = frame_valid_write(m, offsets, idx, xyz)) return rc;
+    if (int rc = frame_valid_write(m, offsets, idx, xyz, false)) return rc;
     const unsigned long long init[4] = {~0ull, ~0ull, 0ull, 0ull};
     ALP_HIP(hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, st));
     const unsigned grid = (unsigned)std::min<long long>((M + 255) / 256, (long long)ctx().cu_count * 8);

@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void valid_write_kernel(const float *__restric
                                                           const unsigned long long *__restrict__ offsets,
                                                           double o0, double o1, double o2,
                                                           unsigned *__restrict__ idx_out,
-                                                          double *__restrict__ xyz_out) {
+                                                          double *__restrict__ xyz_out, long long elem_stride,
+                                                          long long plane_stride) {      // (3, 1): rows of x, y, z; (1, M): three planes
     __shared__ unsigned s_wave[4];
     const long long base = (long long)blockIdx.x * COMPACT_CHUNK;
     unsigned long long out = offsets[blockIdx.x];
@@ -122,9 +123,9 @@ __global__ __launch_bounds__(256) void valid_write_kernel(const float *__restric
         if (valid) {
             const unsigned long long o = out + wbase + before;
             idx_out[o] = (unsigned)p;
-            xyz_out[o * 3 + 0] = (double)c0 + o0;        // x  (channel 0 + offsets[0])
-            xyz_out[o * 3 + 1] = (double)c2 + o2;        // y  (channel 2 + offsets[2])
-            xyz_out[o * 3 + 2] = (double)c1 + o1;        // z  (channel 1 + offsets[1])
+            xyz_out[o * elem_stride] = (double)c0 + o0;                        // x  (channel 0 + offsets[0])
+            xyz_out[o * elem_stride + plane_stride] = (double)c2 + o2;         // y  (channel 2 + offsets[2])
+            xyz_out[o * elem_stride + 2 * plane_stride] = (double)c1 + o1;     // z  (channel 1 + offsets[1])
         }
         out += total;
         __syncthreads();

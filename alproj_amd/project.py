@@ -250,16 +250,26 @@ class ReverseProjection:
         # the x > 0 selection (:369), the x,z,y -> x,y,z reorder (:361) and the offsets (:370-373)
         # happen on the device; only the surviving pixels travel back
         t0 = time.perf_counter()
-        idx, xyz = self._current().fetch_valid(self.offsets)
+        mesh = self._current()
+        C = len(chnames)
+        if hasattr(mesh, "fetch_valid_block"):
+            # x, y, z arrive as three contiguous rows of the (3 + C, M) float64 array that BECOMES the DataFrame's block
+            # (pandas keeps a block as columns x rows): no stacking or transposing copy of the ~0.5 GB
+            idx, block = mesh.fetch_valid_block(self.offsets, C)
+        else:                                   # a host stand-in of the mesh (tests of this host half)
+            idx, xyz = mesh.fetch_valid(self.offsets)
+            block = np.empty((3 + C, len(idx)), dtype=np.float64)
+            block[:3] = xyz.T
         t1 = time.perf_counter()
         w = self.w
-        data = {"u": (idx % w).astype("int16"), "v": (idx // w).astype("int16"),
-                "x": xyz[:, 0], "y": xyz[:, 1], "z": xyz[:, 2]}
         flat = array.reshape(-1, array.shape[2])
-        for k, name in enumerate(chnames):
-            data[name] = flat[idx, k].astype(np.float64)
+        if C:
+            block[3:] = flat[idx].T             # one gather of the surviving pixels' channels, cast on assignment
+        df = pd.DataFrame(block.T, columns=["x", "y", "z"] + list(chnames), copy=False)
+        df.insert(0, "u", (idx % w).astype("int16"))
+        df.insert(1, "v", (idx // w).astype("int16"))
         # the reference filters a RangeIndex-ed frame, so the labels are the linear pixel indices
-        df = pd.DataFrame(data, index=pd.Index(idx.astype(np.int64)))
+        df.index = pd.Index(idx.astype(np.int64))
         LAST_TIMING.update(fetch_s=t1 - t0, frame_s=time.perf_counter() - t1)
         if "enqueue_s" in LAST_TIMING and "device_ms" not in LAST_TIMING:      # this call's own frame (reverse_proj)
             LAST_TIMING["device_ms"] = _lib.event_elapsed_ms(_EV0, _EV1)

@@ -319,6 +319,10 @@ int alp_render_fetch_visibility(alp_mesh_t *mesh, uint64_t *out);
 int alp_render_load(alp_mesh_t *mesh, const float *image, int64_t h, int64_t w);
 int alp_render_valid_count(alp_mesh_t *mesh, int64_t *count);
 int alp_render_fetch_valid(alp_mesh_t *mesh, const double *offsets, uint32_t *idx_out, double *xyz_out);
+/* The same survivors as three contiguous columns x_out[M], y_out[M], z_out[M] -- the layout a DataFrame keeps its
+ * float64 columns in, so that the table of reverse_proj() is assembled without a transposing copy. */
+int alp_render_fetch_valid_planes(alp_mesh_t *mesh, const double *offsets, uint32_t *idx_out, double *x_out,
+                                  double *y_out, double *z_out);
 
 /* set_gcp(), src/alproj/gcp.py:644-648, without the reverse_proj table: for n pixels (u[i], v[i])
  * of the last render (values = the vertices themselves) write xyz_out[i] = (x, y, z) as
