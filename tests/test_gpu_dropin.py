@@ -208,3 +208,51 @@ def test_full_grid_index_arrays_are_recognised_and_never_stored(L, scene, dtype,
     swapped[[0, 5]] = swapped[[5, 0]]
     with L.Mesh(scene["vert64"], None, swapped) as m:
         assert not m.info()["implicit"]
+
+
+def test_new_entry_points_report_misuse(L, scene):
+    """the ABI-3 entry points refuse what they cannot do instead of reading garbage"""
+    import ctypes
+    n = scene["n"]
+    lib = L.lib()
+    with L.Mesh(scene["vert64"], None, None, grid=(n, n)) as m:
+        m.shape = (4, 4, 3)
+        with pytest.raises(L.AlprojHipError, match="nothing rendered yet"):
+            m.fetch_u8()
+        with pytest.raises(L.AlprojHipError, match="nothing rendered yet"):
+            m.rasterize_plan()
+        with pytest.raises(ValueError, match="shape"):
+            m.set_value(np.zeros((5, 3)))
+        assert lib.alp_mesh_set_value(m._h, scene["col64"].ctypes.data_as(ctypes.c_void_p), 7) != 0          # not a float dtype code
+        assert "value_dtype" in lib.alp_last_error().decode()
+        m.set_value(scene["col64"].astype(np.float32))
+        m.set_value(None)
+        assert not m.has_value and m.frame_counts() == (0, 0) and m.info()["implicit"]
+        m.render_enqueue(L.params_vector(scene["params"]), scene["offsets"], coords=True)
+        cnt, bounds = m.rasterize_plan(scene["offsets"])
+        assert cnt > 1000 and bounds[0] < bounds[2] and bounds[1] < bounds[3]
+        photo = np.zeros((m.shape[0], m.shape[1], 3), np.uint8)
+        with pytest.raises(L.AlprojHipError, match="band_channel out of range"):
+            m.rasterize(photo, [3], bounds[0], bounds[3], 1.0, 8, 8, 0, 0, 255)
+        with pytest.raises(L.AlprojHipError, match="raster size"):
+            m.rasterize(photo, [0], bounds[0], bounds[3], 1.0, 0, 8, 0, 0, 255)
+        with pytest.raises(ValueError, match="shape"):
+            m.rasterize(photo[:5], [0], bounds[0], bounds[3], 1.0, 8, 8, 0, 0, 255)
+        out = m.rasterize(photo, [2, 0], bounds[0], bounds[3], 4.0, 16, 16, 0, 1, 9)
+        assert out.shape == (2, 16, 16) and set(np.unique(out)) <= {0, 9}
+    # dtype codes of the mesh itself
+    h = ctypes.c_void_p()
+    v = np.zeros((4, 3), np.float32)
+    assert lib.alp_mesh_create(v.ctypes.data_as(ctypes.c_void_p), 9, None, 0, 4, None, 2, 0, 2, 2, ctypes.byref(h)) != 0
+    assert "vert_dtype" in lib.alp_last_error().decode()
+    assert lib.alp_mesh_info(None, None) != 0
+    # the kernel-section timer: off by default, sums sections when on
+    L.kernel_timing(True)
+    with L.Mesh(scene["vert64"], None, None, grid=(n, n)) as m:
+        m.render_enqueue(L.params_vector(scene["params"]), scene["offsets"], coords=True)
+        m.gather([5, 6], [7, 8])
+        ms, sections = L.kernel_time_ms()
+        assert sections == 1 and 0 < ms < 5
+        assert L.kernel_time_ms() == (0.0, 0)
+    L.kernel_timing(False)
+    assert L.build_flags() == ""
