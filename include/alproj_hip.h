@@ -79,7 +79,8 @@ int alp_device_info(char *name, int len, int *cu_count, int64_t *hbm_bytes);
 int alp_synchronize(void);
 
 /* HIP-event timer slots on the library stream (what bench.py brackets kernels with).
- * slot in [0, 64). */
+ * slot in [0, 64); the package's own wrappers (alproj_amd.project: LAST_TIMING) record into
+ * slots 60 and 61. */
 int alp_event_record(int slot);
 int alp_event_elapsed_ms(int slot_start, int slot_stop, float *ms); /* synchronises on stop */
 
