@@ -201,7 +201,6 @@ int alp_init(int device) {
     ALP_HIP(hipGetDeviceProperties(&prop, device));
     c.cu_count = prop.multiProcessorCount;
     ALP_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    ALP_HIP(hipStreamCreateWithFlags(&c.aux_stream, hipStreamNonBlocking));
     for (auto &ev : c.events) ALP_HIP(hipEventCreate(&ev));
     c.device = device;
     c.ready = true;
@@ -226,9 +225,6 @@ int alp_shutdown(void) {
         g_kt.a[i] = g_kt.b[i] = nullptr;
     }
     g_kt = KTimer();
-    hipStreamSynchronize(c.aux_stream);
-    hipStreamDestroy(c.aux_stream);
-    c.aux_stream = nullptr;
     hipStreamDestroy(c.stream);
     c.stream = nullptr;
     c.ready = false;
@@ -282,7 +278,6 @@ const char *alp_build_flags(void) { return raster_dev_flags(); }
 int alp_synchronize(void) {
     if (int rc = require_init()) return rc;
     ALP_HIP(hipStreamSynchronize(ctx().stream));
-    ALP_HIP(hipStreamSynchronize(ctx().aux_stream));
     return ALP_OK;
 }
 

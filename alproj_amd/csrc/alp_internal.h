@@ -35,7 +35,6 @@ struct Context {
     int device = -1;
     int cu_count = 0;
     hipStream_t stream = nullptr;
-    hipStream_t aux_stream = nullptr;      // work that may run beside the frame: clearing the spare visibility buffer
     hipEvent_t events[64] = {};
     // grow-only device scratch shared by the entry points that stage data for ONE call and
     // synchronise before they return (alp_residuals*, alp_loss_uv, alp_render_gather, ...): no

@@ -335,29 +335,12 @@ namespace {
 
 int ensure_frame(alp_mesh *m, int w, int h) {
     if (m->w == w && m->h == h && m->vis) return ALP_OK;
-    if (m->vis || m->vis_spare) {            // frames of the old size may still be in flight on either stream
-        ALP_HIP(hipStreamSynchronize(ctx().stream));
-        ALP_HIP(hipStreamSynchronize(ctx().aux_stream));
-    }
     if (m->vis) hipFree(m->vis);
-    if (m->vis_spare) hipFree(m->vis_spare);
     if (m->image) hipFree(m->image);
     m->vis = nullptr;
-    m->vis_spare = nullptr;
-    m->spare_clearing = false;
     m->image = nullptr;
     m->vis_current = false;
-    const size_t vis_bytes = (size_t)w * h * sizeof(unsigned long long) + QC_TOTAL * sizeof(unsigned);   // + the frame's counters
-    ALP_HIP(hipMalloc((void **)&m->vis, vis_bytes));
-    // the spare is a convenience: without it (no memory, or ALP_NO_VIS_SPARE) every frame clears its own buffer first
-    if (!getenv("ALP_NO_VIS_SPARE") && hipMalloc((void **)&m->vis_spare, vis_bytes) != hipSuccess) {
-        (void)hipGetLastError();
-        m->vis_spare = nullptr;
-    }
-    if (!m->spare_ready) {
-        ALP_HIP(hipEventCreateWithFlags(&m->spare_ready, hipEventDisableTiming));
-        ALP_HIP(hipEventCreateWithFlags(&m->frame_done, hipEventDisableTiming));
-    }
+    ALP_HIP(hipMalloc((void **)&m->vis, (size_t)w * h * sizeof(unsigned long long) + QC_TOTAL * sizeof(unsigned)));   // + the frame's counters
     ALP_HIP(hipMalloc((void **)&m->image, (size_t)w * h * 3 * sizeof(float)));
     if (m->hiz) hipFree(m->hiz);
     m->hiz = nullptr;
@@ -385,29 +368,11 @@ template <bool IMPLICIT>
 int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_distance, bool resolve_only = false) {
     hipStream_t st = ctx().stream;
     const int cu = ctx().cu_count;
-    m->vis_current = false;          // until every launch below has been accepted
-    // one fill clears the visibility buffer AND the frame's queue / list counters, which live right behind it -- here, or
-    // (when the spare buffer's clear is under way on the auxiliary stream) beside the PREVIOUS frame: then the buffers swap
-    const size_t vis_bytes = (size_t)v.w * v.h * sizeof(unsigned long long) + QC_TOTAL * sizeof(unsigned);
-    if (!resolve_only) {
-        if (m->vis_spare && m->spare_clearing) {
-            ALP_HIP(hipStreamWaitEvent(st, m->spare_ready, 0));
-            std::swap(m->vis, m->vis_spare);
-            m->spare_clearing = false;
-        } else {
-            ALP_HIP(hipMemsetAsync(m->vis, 0, vis_bytes, st));
-        }
-        if (m->vis_spare) {
-            // the buffer left behind (the previous frame's, or never used): cleared for the next full frame once everything
-            // queued so far -- the previous frame's resolve reads it -- has run
-            ALP_HIP(hipEventRecord(m->frame_done, st));
-            ALP_HIP(hipStreamWaitEvent(ctx().aux_stream, m->frame_done, 0));
-            ALP_HIP(hipMemsetAsync(m->vis_spare, 0, vis_bytes, ctx().aux_stream));
-            ALP_HIP(hipEventRecord(m->spare_ready, ctx().aux_stream));
-            m->spare_clearing = true;
-        }
-    }
     unsigned *const fcount = (unsigned *)(m->vis + (size_t)v.w * v.h);
+    m->vis_current = false;          // until every launch below has been accepted
+    // one fill clears the visibility buffer AND the frame's queue / list counters, which live right behind it
+    if (!resolve_only)
+        ALP_HIP(hipMemsetAsync(m->vis, 0, (size_t)v.w * v.h * sizeof(unsigned long long) + QC_TOTAL * sizeof(unsigned), st));
     if (m->n_tri > 0 && !resolve_only) {
         // queue counters, four per round: [0] work items, [1] general entries, [2] small parked, [3] large parked
         // the consumers of one round: (a) the rare cases (near-plane crossings, 64 px and more), (b) what
@@ -917,13 +882,7 @@ int alp_mesh_info(alp_mesh_t *m, int64_t info[4]) {
 
 int alp_mesh_destroy(alp_mesh_t *m) {
     if (!m) return ALP_OK;
-    if (ctx().ready) {
-        hipStreamSynchronize(ctx().stream);
-        hipStreamSynchronize(ctx().aux_stream);
-    }
-    if (m->vis_spare) hipFree(m->vis_spare);
-    if (m->spare_ready) hipEventDestroy(m->spare_ready);
-    if (m->frame_done) hipEventDestroy(m->frame_done);
+    if (ctx().ready) hipStreamSynchronize(ctx().stream);
     for (void *p : {(void *)m->vert, (void *)m->value, (void *)m->ind, (void *)m->valid, (void *)m->valid_derived,
                     (void *)m->tri_present, (void *)m->tri_rank, (void *)m->vis, (void *)m->image,
                     (void *)m->queue, (void *)m->gqueue, (void *)m->qcount_dev, (void *)m->compact_counts, (void *)m->compact_offsets,

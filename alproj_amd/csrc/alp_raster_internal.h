@@ -60,13 +60,6 @@ struct alp_mesh {
     // per-render state (sized on first use)
     int w = 0, h = 0;
     unsigned long long *vis = nullptr;
-    // Second visibility buffer (+ counters), cleared on the auxiliary stream WHILE the next frame is drawn into the other
-    // one: the 168 MB fill that used to open every frame (23 us at 100 M vertices) leaves the frame's critical path.
-    // A full frame takes the spare if its clear has been enqueued (and waits for that clear on the stream), draws into
-    // it, and sends the buffer it leaves behind to be cleared -- after the work already queued that still reads it.
-    unsigned long long *vis_spare = nullptr;
-    bool spare_clearing = false;             // a clear of vis_spare has been enqueued (spare_ready is recorded behind it)
-    hipEvent_t spare_ready = nullptr, frame_done = nullptr;
     float *image = nullptr;
     alp::WorkItem *queue = nullptr;
     unsigned qcap = 0;
