@@ -152,3 +152,35 @@ def test_cma_argument_checks():
         CMA(mean=np.zeros(3), sigma=1.0, bounds=np.zeros((2, 2)))
     with pytest.raises(ValueError):
         CMA(mean=np.zeros(3), sigma=1.0, population_size=0)
+
+
+def test_resident_mesh_cache_keys():
+    """alproj_amd.project keeps the last mesh for the reference's call pair (sim_image then reverse_proj with the same
+    arrays): the key is the array object + layout + a content fingerprint (every 1024th row, head, tail)"""
+    import gc
+    import numpy as np
+    from alproj_amd import project as aproj
+    rng = np.random.default_rng(0)
+    vert = rng.random((50_000, 3))
+    key = aproj._key(vert)
+    assert aproj._same(key, vert)
+    assert not aproj._same(key, vert.copy())                      # other object, same content: another mesh
+    assert not aproj._same(key, None) and aproj._same(None, None) and not aproj._same(None, vert)
+    vert[0, 0] += 1.0                                              # head row
+    assert not aproj._same(key, vert)
+    vert[0, 0] -= 1.0
+    assert aproj._same(key, vert)
+    vert[2048, 1] = -5.0                                           # a sampled row
+    assert not aproj._same(key, vert)
+    key = aproj._key(vert)
+    vert += 1e-9                                                   # a global edit
+    assert not aproj._same(key, vert)
+    key = aproj._key(vert)
+    view = vert[::2]
+    assert not aproj._same(key, view)                              # another layout
+    ind = np.arange(30, dtype=np.int64).reshape(10, 3)
+    k2 = aproj._key(ind)
+    assert aproj._same(k2, ind) and aproj._fingerprint(np.zeros((0, 3), np.int64))[4] == 0
+    del vert
+    gc.collect()
+    assert key[0]() is None and not aproj._same(key, view)         # the array is gone: the weak reference says so
