@@ -181,6 +181,7 @@ def test_resident_mesh_cache_keys():
     ind = np.arange(30, dtype=np.int64).reshape(10, 3)
     k2 = aproj._key(ind)
     assert aproj._same(k2, ind) and aproj._fingerprint(np.zeros((0, 3), np.int64))[4] == 0
-    del vert
+    other = view.copy()
+    del vert, view
     gc.collect()
-    assert key[0]() is None and not aproj._same(key, view)         # the array is gone: the weak reference says so
+    assert key[0]() is None and not aproj._same(key, other)        # the array is gone: the weak reference says so
