@@ -266,8 +266,9 @@ class ReverseProjection:
         if C:
             block[3:] = flat[idx].T             # one gather of the surviving pixels' channels, cast on assignment
         df = pd.DataFrame(block.T, columns=["x", "y", "z"] + list(chnames), copy=False)
-        df.insert(0, "u", (idx % w).astype("int16"))
-        df.insert(1, "v", (idx // w).astype("int16"))
+        v_pix, u_pix = np.divmod(idx, np.uint32(w))          # one pass: row and column of the linear pixel index
+        df.insert(0, "u", u_pix.astype("int16"))
+        df.insert(1, "v", v_pix.astype("int16"))
         # the reference filters a RangeIndex-ed frame, so the labels are the linear pixel indices
         df.index = pd.Index(idx.astype(np.int64))
         LAST_TIMING.update(fetch_s=t1 - t0, frame_s=time.perf_counter() - t1)
