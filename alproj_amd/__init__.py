@@ -13,4 +13,6 @@ Sub-modules mirror the reference package layout for the functions on the path:
 All per-point work goes through ``libalproj_hip.so`` (ctypes; see include/alproj_hip.h);
 there is no CPU fallback.
 """
-__version__ = "0.1.0"
+__version__ = "0.3.0"
+
+from .gcp import filter_gcp_distance      # noqa: E402,F401  (the reference's package re-exports it: src/alproj/__init__.py:1)
