@@ -158,23 +158,50 @@ __device__ __forceinline__ long long subgrid_id(const int *__restrict__ ind, lon
     if (b == a + gw && c == a + gw + 1) type = 0;
     else if (b == a + gw + 1 && c == a + 1) type = 1;
     else return -1;
-    const long long row = a / gw, col = a - row * gw;
-    if (a < 0 || row >= gh - 1 || col >= gw - 1) return -1;
-    return 2 * (row * (gw - 1) + col) + type;
+    if (a < 0) return -1;
+    const unsigned row = (unsigned)a / (unsigned)gw, col = (unsigned)a - row * (unsigned)gw;      // fewer than 2^31 vertices: 32-bit division
+    if ((long long)row >= gh - 1 || (long long)col >= gw - 1) return -1;
+    return 2 * ((long long)row * (gw - 1) + col) + type;
 }
 
+// One lane per triangle of the array, consecutive lanes = consecutive triangles: the predecessor's id comes from the
+// neighbouring lane, and because the ids of a valid array increase, the lanes that fall into one 32-bit word of `present`
+// are a contiguous run -- its bits are OR-ed inside the wave and the run's first lane sends ONE atomic (the version with an
+// atomic per triangle spent 10.8 ms on the 2e8 triangles of a 100 M-vertex DSM with nodata, 32 atomics per word).
 __global__ __launch_bounds__(256) void subgrid_mark_kernel(const int *__restrict__ ind, long long n_tri, long long gw, long long gh,
                                                            unsigned *__restrict__ present, unsigned char *__restrict__ mark,
                                                            unsigned *__restrict__ mismatch) {
     const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long rounds = (n_tri + stride - 1) / stride;              // every lane makes every round: the shuffles are wave-wide
+    const int lane = (int)(threadIdx.x & 63);
     bool bad = false;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n_tri; t += stride) {
-        const long long id = subgrid_id(ind, t, gw, gh);
-        if (id < 0 || (t > 0 && subgrid_id(ind, t - 1, gw, gh) >= id)) { bad = true; continue; }
-        atomicOr(&present[id >> 5], 1u << (id & 31));
-        mark[ind[3 * t]] = 1;
-        mark[ind[3 * t + 1]] = 1;
-        mark[ind[3 * t + 2]] = 1;
+    for (long long k = 0; k < rounds; ++k) {
+        const long long t = k * stride + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool in = t < n_tri;
+        const long long id = in ? subgrid_id(ind, t, gw, gh) : -1;
+        long long prev = __shfl_up(id, 1);
+        if (lane == 0) prev = (in && t > 0) ? subgrid_id(ind, t - 1, gw, gh) : -1;
+        const bool ok = in && id >= 0 && !(t > 0 && prev >= id);
+        bad |= in && !ok;
+        // runs of equal word index among the lanes (lanes that are out or invalid: runs of their own, nothing to store)
+        const long long word = ok ? (id >> 5) : (-1 - lane);
+        const long long wprev = __shfl_up(word, 1);
+        const bool head = lane == 0 || wprev != word;
+        const unsigned long long heads = __ballot(head);
+        const int run = __popcll(heads & (~0ull >> (63 - lane)));
+        unsigned bits = ok ? (1u << (id & 31)) : 0u;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const unsigned b2 = __shfl_down(bits, 1 << j);
+            const int r2 = __shfl_down(run, 1 << j);
+            if ((lane + (1 << j) < 64) && r2 == run) bits |= b2;
+        }
+        if (ok) {
+            if (head) atomicOr(&present[word], bits);
+            mark[ind[3 * t]] = 1;
+            mark[ind[3 * t + 1]] = 1;
+            mark[ind[3 * t + 2]] = 1;
+        }
     }
     if (bad) *mismatch = 1u;
 }
