@@ -120,3 +120,25 @@ def test_g14_lsq_optimizer_matches_the_reference_run(L, case):
             assert abs(params[k] - want[k]) <= tol, (jac, k, params[k], want[k])
         assert err == pytest.approx(float(g[f"{case}_error"]), rel=5e-5)
         assert err < 2.5
+
+
+@pytest.mark.parametrize("tag", ["a", "c"])
+def test_g12_table_free_rasterize_equals_rasterizing_the_references_table(L, tag):
+    """reverse_proj -> to_geotiff without the table (ReverseProjection.rasterize) against the rasterisation of the table the
+    REFERENCE's reverse_proj returned for the same frame (g12): same bytes, same bounds, for every aggregate"""
+    from alproj_amd import project as aproj
+    g = load("g12_wrappers.npz")
+    raw, array = g[f"{tag}_raw"], g[f"{tag}_array"]
+    chn = list(g[f"{tag}_chnames"])
+    h, w = raw.shape[:2]
+    ref_table = pd.DataFrame(g[f"{tag}_off_values"], columns=list(g[f"{tag}_off_columns"]), index=g[f"{tag}_off_index"])
+    vert = np.array([[0, 0, 0], [1, 0, 0], [0, 0, 1], [1, 0, 1]], dtype=np.float32)
+    with L.Mesh(vert, None, None, grid=(2, 2)) as m:
+        m.load_image(raw)
+        rp = aproj.ReverseProjection(m, g["offsets"], w, h, False, None)
+        for agg in ("mean", "median", "max", "min"):
+            bands = chn[:3][::-1]
+            want, wb = aproj.rasterize(ref_table, resolution=40.0, bands=bands, max_dist=80.0, agg_func=agg)
+            got, gb = rp.rasterize(array, chn, resolution=40.0, bands=bands, max_dist=80.0, agg_func=agg)
+            assert gb == wb
+            np.testing.assert_array_equal(got, want)
