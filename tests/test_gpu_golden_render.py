@@ -132,6 +132,14 @@ def test_g12_table_free_rasterize_equals_rasterizing_the_references_table(L, tag
     chn = list(g[f"{tag}_chnames"])
     h, w = raw.shape[:2]
     ref_table = pd.DataFrame(g[f"{tag}_off_values"], columns=list(g[f"{tag}_off_columns"]), index=g[f"{tag}_off_index"])
+    # g12 plants x = inf at pixel (1, 1) for the x > 0 filter; a raster has no extent for it (the reference's to_geotiff
+    # overflows on it, and so do both paths here): that one coordinate becomes finite in the frame AND in the reference's row
+    assert np.isinf(raw[1, 1, 0]) and np.isinf(ref_table.loc[w + 1, "x"])
+    raw = raw.copy()
+    raw[1, 1, 0] = np.float32(77.0)
+    ref_table.loc[w + 1, "x"] = 77.0 + g["offsets"][0]
+    with pytest.raises(OverflowError):
+        aproj.rasterize(pd.DataFrame(g[f"{tag}_off_values"], columns=list(g[f"{tag}_off_columns"])), resolution=40.0, bands=chn[:1])
     vert = np.array([[0, 0, 0], [1, 0, 0], [0, 0, 1], [1, 0, 1]], dtype=np.float32)
     with L.Mesh(vert, None, None, grid=(2, 2)) as m:
         m.load_image(raw)
