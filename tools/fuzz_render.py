@@ -27,6 +27,18 @@ while time.time() < t_end:
     res = float(rng.choice([0.5, 1.0, 2.0, 4.0]))
     s = syn.surface(n, res=res, seed=int(rng.integers(1, 1 << 30)))
     vert = s["vert"]
+    gh = gw = n
+    if rng.random() < 0.35:                    # a non-square part of the grid (vertex id = row * gw + col)
+        gh, gw = int(rng.integers(2, n + 1)), int(rng.integers(2, n + 1))
+        vert = np.ascontiguousarray(vert.reshape(n, n, 3)[:gh, :gw].reshape(-1, 3))
+
+    def rect_indices(dtype):
+        a = (np.arange(gh - 1, dtype=np.int64)[:, None] * gw + np.arange(gw - 1, dtype=np.int64)[None, :]).reshape(-1)
+        out = np.empty((len(a), 2, 3), dtype=np.int64)
+        out[:, 0] = np.stack([a, a + gw, a + gw + 1], 1)
+        out[:, 1] = np.stack([a, a + gw + 1, a + 1], 1)
+        return out.reshape(-1, 3).astype(dtype)
+
     w = int(rng.integers(48, 1300)); h = int(rng.integers(40, 900))
     p = dict(syn.base_params(n, res), w=w, h=h, cx=w / 2.0, cy=h / 2.0)
     L_ = n * res
@@ -47,29 +59,29 @@ while time.time() < t_end:
     ind = grid = valid = None
     ref_ind = None
     if kind == "implicit":
-        grid = (n, n)
+        grid = (gh, gw)
     elif kind.startswith("full"):
-        ind = syn.grid_indices(n, np.int32 if kind == "full_i32" else np.int64)
+        ind = rect_indices(np.int32 if kind == "full_i32" else np.int64)
         os.environ["ALP_HOST_THREADS"] = "0" if kind == "full_i64_dev" else "3"
     elif kind == "nodata":
-        full = syn.grid_indices(n, np.int64)
-        bad = rng.random(n * n) < 0.01
+        full = rect_indices(np.int64)
+        bad = rng.random(gh * gw) < 0.01
         ind = ref_ind = full[~bad[full].any(axis=1)]
         if len(ind) < 2:
             continue
     elif kind == "shuffled":
-        full = syn.grid_indices(n, np.int32)
+        full = rect_indices(np.int32)
         ind = ref_ind = full[rng.permutation(len(full))[: max(2, len(full) // 2)]]
     else:
-        grid = (n, n)
-        valid = rng.random(n * n) > 0.02
-        full = syn.grid_indices(n, np.int64)
+        grid = (gh, gw)
+        valid = rng.random(gh * gw) > 0.02
+        full = rect_indices(np.int64)
         ref_ind = full[valid[full].all(axis=1)]
-    col = syn.colors(n * n, seed=7)
+    col = syn.colors(gh * gw, seed=7)
     md = float(rng.uniform(5, 200)) if rng.random() < 0.3 else None
-    ref_vis = orast.visibility(vert, ref_ind, p, offsets, grid=None if ref_ind is not None else (n, n))
-    ref_img = orast.render(vert, col, ref_ind, p, offsets, md, grid=None if ref_ind is not None else (n, n))
-    ref_crd = orast.render(vert, None, ref_ind, p, offsets, None, grid=None if ref_ind is not None else (n, n))
+    ref_vis = orast.visibility(vert, ref_ind, p, offsets, grid=None if ref_ind is not None else (gh, gw))
+    ref_img = orast.render(vert, col, ref_ind, p, offsets, md, grid=None if ref_ind is not None else (gh, gw))
+    ref_crd = orast.render(vert, None, ref_ind, p, offsets, None, grid=None if ref_ind is not None else (gh, gw))
     with L.Mesh(vert.astype(np.float64) if rng.random() < 0.5 else vert, col, ind, grid) as m:
         if valid is not None:
             m.set_valid(valid)
@@ -88,6 +100,6 @@ while time.time() < t_end:
     n_pixels += w * h
     kinds[kind] = kinds.get(kind, 0) + 1
     if not ok:
-        print(f"MISMATCH: kind {kind} n {n} res {res} frame {w}x{h} md {md} offsets {offsets is not None} counts {counts}\n  params {p}", flush=True)
+        print(f"MISMATCH: kind {kind} n {n} grid {gh}x{gw} res {res} frame {w}x{h} md {md} offsets {offsets is not None} counts {counts}\n  params {p}", flush=True)
         sys.exit(1)
 print(f"fuzz_render: {n_cases} random scenes, {n_pixels / 1e6:.1f} M pixels, all identical to the oracle; by kind {kinds}")
