@@ -19,11 +19,17 @@
  *   project.py:111-143  distort(): source map from _distort with inverted coefficients
  *                       (optimize.py:98-120), nearest-neighbour gather, zero border
  *
- * PARITY UNPINNED against real OpenGL / cv2: moderngl 5.12.0, glcontext 3.0.0, the GL driver
- * and opencv-python 4.13.0.90 are not part of the reference checkout and are not installed;
- * the reference holds no fixture for this path.  OpenGL leaves sub-pixel snapping, the
- * tie-break on shared edges and depth-buffer precision to the implementation; this file fixes
- * them as follows (the GPU path follows the same written specification):
+ * PARITY.  The render is PINNED BY A REAL OpenGL since round 3: the reference's own persp_proj
+ * ran unmodified on Mesa 23.2 llvmpipe in the build container (tests/golden/gen_golden_gl.py ->
+ * g15_gl_render.npz) and tests/test_oracle_gl.py holds this file to what it returned: the same
+ * triangle, background, min_distance mask and value on every pixel where a conformant GL has no
+ * freedom.  (Rounds 1-2 had no GL and said "parity unpinned" here; this comment is
+ * the only thing that changed since -- oracle/raster_ref.code.sha256 is the digest of the code with
+ * comments stripped and is still the round-2 one.)  STILL UNPINNED: cv2's nearest rounding and
+ * border rule (opencv-python 4.13.0.90 is not installed and the reference holds no fixture).
+ * OpenGL leaves sub-pixel snapping, the tie-break on shared edges and depth-buffer precision to
+ * the implementation; this file fixes them as follows (the GPU path follows the same written
+ * specification):
  *   - vertices in front of the near plane are projected in float32 and snapped to 1/256 px;
  *     coverage uses exact 64-bit integer edge functions at pixel centres, a pixel on an edge
  *     belongs to the triangle whose edge has dy < 0, or dy == 0 and dx > 0 (watertight);

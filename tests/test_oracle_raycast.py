@@ -25,6 +25,15 @@ def test_raster_oracle_is_frozen():
     first passes the ray-cast check below; the recorded digest makes any other edit fail here."""
     digest = hashlib.sha256(open(os.path.join(ROOT, "oracle", "raster_ref.c"), "rb").read()).hexdigest()
     assert digest == open(os.path.join(ROOT, "oracle", "raster_ref.sha256")).read().strip()
+    # ... and its CODE (comments and blank lines stripped) is still what round 2 froze: the digest below was taken from the
+    # round-2 file before round 3 rewrote the header's parity paragraph (the render is pinned by a real OpenGL since)
+    import re
+    text = open(os.path.join(ROOT, "oracle", "raster_ref.c")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    text = "\n".join(line.rstrip() for line in text.split("\n") if line.strip())
+    assert hashlib.sha256(text.encode()).hexdigest() == open(os.path.join(ROOT, "oracle", "raster_ref.code.sha256")).read().strip() \
+        == "653a04f58ec47e8919960c2a7b9e054c57384403ef9da57fff5d5922436fb5e9"
 
 
 @pytest.mark.parametrize("name", list(SCENES))
