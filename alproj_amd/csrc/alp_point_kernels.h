@@ -259,7 +259,7 @@ template <> struct PopCfg<double> : PopCfgT<double, POP_VD, 128, 1> {};
 // Instruction count per point-candidate (float, Huber): 9 fma (folded transform) + 2 mul
 // (perspective) + 3 (x^2, y^2, r2) + 4 fma (radial numerator/denominator polynomials) + 4 fma
 // (+1, +1+a1, +1, +1+a2) + 13 (tangential/prism terms with shared 2p1xy and 2p2r2, ratios) +
-// 4 (residuals, squared distance) + 4 (Huber as 0.5 c (2r - c), c = min(r, f), fused into the
+// 4 (residuals, squared distance) + 3 (Huber as c (2r - c), c = min(r, f), halved once per group of V, fused into the
 // accumulation) = 43 full-rate + 4 quarter-rate (1/Z, two denominators, sqrt) in float64; the
 // float32 form shares ONE reciprocal between the two denominators (3 multiplies instead of a
 // quarter-rate v_rcp_f32) and folds 2 p2 r2 into the thin-prism Horner form: 45 + 3.
@@ -373,7 +373,7 @@ __device__ __forceinline__ T group_loss_sum(const T *r, const T (&qx)[V], const 
             const T c = __builtin_fminf(dist[j], f_scale);
             const T t = N::fma((T)2, dist[j], -c);
             if (MASKED && !ok[j]) continue;
-            acc = N::fma((T)0.5 * c, t, acc);
+            acc = N::fma(c, t, acc);                      // twice the loss: halved once below (exact: a power of two)
         } else {
             const T quad = (T)0.5 * (dist[j] * dist[j]);
             const T lin = N::fma(f_scale, dist[j], -half_f2);
@@ -381,6 +381,7 @@ __device__ __forceinline__ T group_loss_sum(const T *r, const T (&qx)[V], const 
             acc += (MASKED && !ok[j]) ? (T)0 : ((dist[j] <= f_scale) ? quad : lin);
         }
     }
+    if constexpr (LOSS != ALP_LOSS_MEAN_DIST && sizeof(T) == 4) acc *= (T)0.5;      // one multiply per V evaluations instead of one each
     return acc;
 }
 
