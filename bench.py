@@ -40,7 +40,7 @@ HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.
 VALU_PEAK = 157.3e12       # flop/s fp32 vector (MI355X_MICROARCH.md)
 VALU_PEAK_F64 = 78.6e12    # flop/s fp64 vector (MI355X_MICROARCH.md)
 BYTES_PER_VERTEX = {"f32": 20, "f64": 40}     # 3 coordinates in + 2 pixel coordinates out
-EVAL_FLOPS = 77            # flop per point-candidate evaluation (Huber): 30 fma + 13 + 4 transcendental, DESIGN.md section 4 (K2)
+EVAL_FLOPS = 76            # flop per point-candidate evaluation (Huber): 30 fma + 12 + 4 transcendental (+ 1/6 multiply), DESIGN.md section 4 (K2)
 PROFILES = os.path.join(ROOT, "profiles")
 
 
