@@ -129,3 +129,23 @@ def report(name, kind, r):
     print(f"[g15] {name} ({kind}): all {r['safe']} safe pixels of {r['pixels']} show OpenGL's triangle; unsafe {r['unsafe']}: "
           f"{r['unsafe_same']} equal ({r['unsafe_same'] / max(r['unsafe'], 1):.4f}); whole frame {r['all_same_rate']:.6f}; "
           f"values: max |d|/max(|GL|,1) {r['max_rel']:.1e}, {r['frac_rel_le_1e5']:.4f} within 1e-5, worst {r['max_ratio']:.2f} of the sub-pixel tolerance")
+
+
+def lens_source(params):
+    """(sy, sx, inside): the source pixel of every output pixel of distort() (project.py:128-141): the float32 maps the
+    reference computes (restated in oracle.ref_numpy.distort_maps, pinned bit for bit by g13), rounded half to even,
+    zero outside the image"""
+    w, h = int(params["w"]), int(params["h"])
+    mx, my = orc.distort_maps(w, h, [params[k] for k in orc.DIST_KEYS])
+    sx, sy = np.rint(mx.astype(np.float64)).astype(np.int64), np.rint(my.astype(np.float64)).astype(np.int64)
+    inside = (sx >= 0) & (sx < w) & (sy >= 0) & (sy < h)
+    return np.clip(sy, 0, h - 1), np.clip(sx, 0, w - 1), inside
+
+
+def check_lens_composition(with_lens, without_lens, params):
+    """persp_proj ends with flipud (project.py:281) and then distort (:292): the image with the lens must be the nearest gather
+    of the image without it, exactly (the raster passes do not see the lens)"""
+    sy, sx, inside = lens_source(params)
+    want = np.where(inside[..., None], without_lens[sy, sx], 0.0).astype(np.float32)
+    np.testing.assert_array_equal(with_lens, want)
+    assert 0.5 < inside.mean() < 1.0 and (sx != np.arange(sx.shape[1])[None, :]).mean() > 0.5      # a real lens: most pixels move

@@ -40,7 +40,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import gen_golden as gg                # noqa: E402
 import moderngl_standin as mgl         # noqa: E402
 from alproj_amd import synthetic as syn          # noqa: E402
-from tests.render_scenes import GL_SCENES, IMAGE_STRIDE        # noqa: E402
+from tests.render_scenes import GL_LENS_SCENES, GL_SCENES, IMAGE_STRIDE        # noqa: E402
 
 
 def main():
@@ -90,6 +90,16 @@ def main():
         mgl.DEPTH_FUNC = None
         print(f"{name}: {img.shape[1]}x{img.shape[0]}, {len(ind)} triangles, covered {np.mean(mgl.LAST['prim_id'] >= 0):.3f}, "
               f"GL_LEQUAL would change {changed} pixels")
+    # a lens: the remap stand-in sees a non-identity map (the composition flipud -> distort of project.py:281,292)
+    for name, make in GL_LENS_SCENES.items():
+        s = make()
+        vert = s["vert"].astype(np.float64)
+        ind = syn.grid_indices(s["grid"][0], np.int64)
+        mgl.DEPTH_FUNC, mgl.KEEP_DIAGNOSTICS = None, False
+        img = prj.persp_proj(vert, vert, ind, s["params"], s["offsets"])
+        assert not rec["identity"]
+        out[f"{name}_image"] = img
+        print(f"{name}: {img.shape[1]}x{img.shape[0]}, through the lens")
     # the reference's wrappers through the same GL: the render pair of example.py:28,31 at one pose
     s = GL_SCENES["grid_colours"]()
     n = s["grid"][0]

@@ -94,6 +94,18 @@ def _big_cells_scene():
 # axes (the frame is large; the values are asserted on that subset)
 IMAGE_STRIDE = {"grid_big_cells": 4}
 
+LENS = dict(a1=1.03, a2=0.97, k1=-0.06, k2=0.012, k3=0.002, k4=0.004, k5=-0.001, k6=0.0005, p1=0.0015, p2=-0.002,
+            s1=0.0006, s2=-0.0002, s3=-0.0004, s4=0.0001)
+
+
+def _lens_scene():
+    """grid_tilt_roll through a lens: the reference's persp_proj ends with flipud (project.py:281) and distort (:292) --
+    the one scene whose fixture went through the remap stand-in with a non-identity map (the COMPOSITION is what it pins)"""
+    s = SCENES["grid_tilt_roll"]()
+    s["params"] = dict(s["params"], **LENS)
+    return s
+
+
 GL_SCENES = dict(SCENES)
 GL_SCENES.update({
     "grid_colours": _coloured,                                                # sim_image's call (project.py:322)
@@ -102,3 +114,4 @@ GL_SCENES.update({
     "grid_far_3km": _far_scene,
     "grid_big_cells": _big_cells_scene,
 })
+GL_LENS_SCENES = {"grid_tilt_roll_lens": _lens_scene}          # compared by their own test (tests/test_oracle_gl.py, test_gpu_gl.py)

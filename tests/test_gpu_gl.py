@@ -71,3 +71,23 @@ def test_reference_render_pair_through_opengl(L, g15):
     print(f"[g15] render pair: sim_image identical on {(d == 0).mean():.5f} of the bytes (max level difference {d.max()}); reverse_proj "
           f"{len(df)} rows vs OpenGL's {len(ref)}, {len(common)} common; max |dxyz| on safe common rows {err.max():.3e} m")
     assert err.max() < 0.05           # metres; cells are 1 m, the sub-pixel spread is asserted per pixel in the scene tests
+
+
+def test_hip_lens_composition_equals_the_references(L, g15):
+    """the fused remap of resolve_kernel composes like the reference's flipud + distort did through the real GL
+    (tests/test_oracle_gl.py checks the reference's own pair of images): image with the lens = nearest gather of the
+    image without it through distort()'s maps -- and what that gather delivers is GL's image where GL has no freedom"""
+    from tests.render_scenes import GL_LENS_SCENES
+    s = GL_LENS_SCENES["grid_tilt_roll_lens"]()
+    with L.Mesh(s["vert"], None, None, s["grid"]) as m:
+        plain = m.render(L.params_vector(dict(s["params"], **glc.NO_LENS)), s["offsets"])
+        lens = m.render(L.params_vector(s["params"]), s["offsets"])
+        assert m.frame_counts() == (1, 1)                           # the lens is applied by the resolve alone
+    glc.check_lens_composition(lens, plain, s["params"])
+    # against GL's own lens image: equal wherever the SOURCE pixel is one on which GL and the HIP path agree to 1e-5
+    gl_plain, gl_lens = g15["grid_tilt_roll_image"], g15["grid_tilt_roll_lens_image"]
+    sy, sx, inside = glc.lens_source(s["params"])
+    agree = (np.abs(plain - gl_plain) <= 1e-5 * np.maximum(np.abs(gl_plain), 1.0)).all(axis=2)
+    ok = inside & agree[sy, sx]
+    assert ok.mean() > 0.6
+    assert (np.abs(lens[ok] - gl_lens[ok]) <= 1e-5 * np.maximum(np.abs(gl_lens[ok]), 1.0)).all()

@@ -38,3 +38,16 @@ def test_oracle_sim_image_matches_the_reference_through_opengl(g15):
     safe = oray.safe_mask(rc, depth24_steps=glc.DEPTH24_STEPS)[::-1]
     d = np.abs(sim.astype(np.int16) - g15["pair_sim_image"].astype(np.int16))
     assert d[safe].max() <= 1 and (d[safe] == 0).mean() > 0.99
+
+
+def test_lens_composition_of_the_reference_through_opengl(g15):
+    """g15 holds grid_tilt_roll twice as the reference's persp_proj returned it through the real GL: without a lens and
+    with one (the only fixture that went through the remap stand-in with a non-identity map).  (1) the reference's own
+    pair obeys image_lens = nearest gather of image_plain through the maps of distort() -- i.e. flipud comes BEFORE the
+    remap and the maps are applied as restated; (2) so does the raster oracle's pair."""
+    from tests.render_scenes import GL_LENS_SCENES
+    s = GL_LENS_SCENES["grid_tilt_roll_lens"]()
+    glc.check_lens_composition(g15["grid_tilt_roll_lens_image"], g15["grid_tilt_roll_image"], s["params"])
+    plain = orast.render(s["vert"], None, None, dict(s["params"], **glc.NO_LENS), s["offsets"], grid=s["grid"])
+    lens = orast.render(s["vert"], None, None, s["params"], s["offsets"], grid=s["grid"])
+    glc.check_lens_composition(lens, plain, s["params"])
