@@ -53,7 +53,8 @@ while time.time() < t_end:
     with np.errstate(all="ignore"):
         ref_l, ref_amin = orc.population_losses(xyz, uv, init, targets, bounds, X, fs)
     kind = L.LOSS_MEAN_DIST if fs is None else L.LOSS_HUBER
-    dens = np.array([orc.conditioning(xyz, orc.vector_to_params(c))[1] for c in cand])
+    cond = np.array([orc.conditioning(xyz, orc.vector_to_params(c)) for c in cand])
+    dens = np.where(cond[:, 0] >= 0.05, cond[:, 1], 0.0)      # a point next to the candidate's camera plane (|Z| < 5 % of its distance) is a pole too: 1 / Z
     # ... and whose projections stay within two image sizes of the image (the rational model far outside the image is
     # a difference of large polynomial terms: ill-conditioned in float32 without any pole nearby)
     with np.errstate(all="ignore"):
