@@ -25,6 +25,13 @@ namespace alp {
 
 enum { AGG_MEAN = 0, AGG_MAX = 1, AGG_MIN = 2 };
 
+// ALP_RZ_SEPARATE_PASSES=1: finalize / sweep / conversion as separate kernels whatever the sweep count (the path for more than
+// RZ_SMAX sweeps); the tests run both and compare bytes
+static bool rz_separate_passes() {
+    const char *e = getenv("ALP_RZ_SEPARATE_PASSES");
+    return e && e[0] == '1';
+}
+
 // order-preserving map double -> uint64 (so that integer atomicMax/Min order like the doubles)
 __device__ __forceinline__ unsigned long long d2ord(double d) {
     const unsigned long long u = (unsigned long long)__double_as_longlong(d);
@@ -181,6 +188,145 @@ __global__ __launch_bounds__(256) void rz_to_u8_kernel(const float *__restrict__
     }
 }
 
+// ------------------------------------------------------------------ fused tail
+// finalize + up to RZ_SMAX focal sweeps + uint8 in ONE pass over the raster: a workgroup owns a tile of RZ_TW x RZ_TH cells,
+// forms the float32 raster of the tile and a halo of S cells in LDS (a cell S sweeps later depends on the cells within S of
+// it, nothing else), sweeps there -- each sweep is valid on a region one cell smaller all round -- and writes bytes only.
+// Every value is formed by the expressions of the separate kernels above (which stay as the path for more sweeps), so the
+// bytes are the same; the raster no longer crosses HBM as float32 three times (finalize, sweep, conversion: 2.24 ms of the
+// 3.79 ms of the 3 x 8088 x 9786 raster of bench.py's f2 leg), and a tile whose cells and halo are all empty -- most of a
+// georectified photograph's bounding box -- skips its sweeps.
+constexpr int RZ_TW = 64, RZ_TH = 32, RZ_SMAX = 8;
+enum { AGG_MEDIAN_FOCAL = 3 };
+
+template <int AGG>
+__device__ __forceinline__ float rz_window_value(const float *__restrict__ s, int lw, int at) {
+    const float nan = __int_as_float(0x7fc00000);
+    if constexpr (AGG == AGG_MEDIAN_FOCAL) {
+        float w[9];
+        int have = 0;
+#pragma unroll
+        for (int dr = -1; dr <= 1; ++dr)
+#pragma unroll
+            for (int dc = -1; dc <= 1; ++dc) {
+                const float val = s[at + dr * lw + dc];
+                if (val != val) continue;
+                int k = have++;                                   // insertion sort of at most 9 values
+                while (k > 0 && w[k - 1] > val) { w[k] = w[k - 1]; --k; }
+                w[k] = val;
+            }
+        if (!have) return nan;
+        return (have & 1) ? w[have / 2] : (float)(((double)w[have / 2 - 1] + (double)w[have / 2]) / 2);
+    } else {
+        double w[9];
+        int k = 0, have = 0;
+#pragma unroll
+        for (int dr = -1; dr <= 1; ++dr)
+#pragma unroll
+            for (int dc = -1; dc <= 1; ++dc, ++k) {
+                const float val = s[at + dr * lw + dc];
+                const bool ok = val == val;
+                have += ok;
+                if constexpr (AGG == AGG_MEAN) w[k] = ok ? (double)val : 0.0;
+                else if constexpr (AGG == AGG_MAX) w[k] = ok ? (double)val : -INFINITY;
+                else w[k] = ok ? (double)val : INFINITY;
+            }
+        if (!have) return nan;
+        if constexpr (AGG == AGG_MEAN) {
+            const double sum = (((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]))) + w[8];     // numpy's order, as above
+            return (float)(sum / (double)have);
+        } else {
+            double m = w[0];
+#pragma unroll
+            for (int j = 1; j < 9; ++j) m = (AGG == AGG_MAX) ? fmax(m, w[j]) : fmin(m, w[j]);
+            return (float)m;
+        }
+    }
+}
+
+// AGG_MEAN / _MAX / _MIN read the scatter's accumulators, AGG_MEDIAN_FOCAL the float32 raster the median runs wrote
+template <int AGG>
+__global__ __launch_bounds__(256) void rz_tail_kernel(const double *__restrict__ acc, const unsigned *__restrict__ cnt,
+                                                      const float *__restrict__ raster, int width, int height, int S,
+                                                      int nodata, int tiles_x, int tiles_y, unsigned char *__restrict__ out) {
+    __shared__ float buf[2][(RZ_TH + 2 * RZ_SMAX) * (RZ_TW + 2 * RZ_SMAX)];
+    __shared__ int s_any;
+    const float nan = __int_as_float(0x7fc00000);
+    const int tid = (int)threadIdx.x;
+    const long long hw = (long long)width * height;
+    int t = (int)blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const long long band_base = (long long)(t / tiles_y) * hw;
+    const int x0 = tx * RZ_TW - S, y0 = ty * RZ_TH - S;        // raster position of LDS cell (0, 0)
+    const int lw = RZ_TW + 2 * S, lh = RZ_TH + 2 * S;
+    const float inv_lw = 1.0f / (float)lw;                       // idx / lw through (idx + 0.5) * (1 / lw): idx < 3840, exact
+    if (tid == 0) s_any = 0;
+    __syncthreads();
+    bool any = false;
+    for (int idx = tid; idx < lw * lh; idx += 256) {
+        const int r = (int)(((float)idx + 0.5f) * inv_lw), c = idx - r * lw;
+        const int gr = y0 + r, gc = x0 + c;
+        float v = nan;                                           // outside the raster: NaN, in every sweep
+        if (gr >= 0 && gr < height && gc >= 0 && gc < width) {
+            const long long g = band_base + (long long)gr * width + gc;
+            if constexpr (AGG == AGG_MEDIAN_FOCAL) {
+                v = raster[g];
+            } else {
+                const unsigned n = cnt[g];
+                if (n) {
+                    if constexpr (AGG == AGG_MEAN) v = (float)(acc[g] / (double)n);
+                    else v = (float)ord2d(reinterpret_cast<const unsigned long long *>(acc)[g]);
+                }
+            }
+        }
+        buf[0][idx] = v;
+        any |= (v == v);
+    }
+    if (any) s_any = 1;
+    __syncthreads();
+    int cur = 0;
+    if (s_any) {
+        for (int s = 0; s < S; ++s) {
+            const int rw = lw - 2 * (s + 1), rh = lh - 2 * (s + 1);
+            const float inv_rw = 1.0f / (float)rw;
+            for (int idx = tid; idx < rw * rh; idx += 256) {
+                int r = (int)(((float)idx + 0.5f) * inv_rw), c = idx - r * rw;
+                r += s + 1;
+                c += s + 1;
+                const int at = r * lw + c;
+                float o = buf[cur][at];
+                if (o != o) {
+                    const int gr = y0 + r, gc = x0 + c;
+                    if (gr >= 0 && gr < height && gc >= 0 && gc < width) o = rz_window_value<AGG>(buf[cur], lw, at);
+                }
+                buf[cur ^ 1][at] = o;
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    for (int idx = tid; idx < RZ_TW * RZ_TH; idx += 256) {
+        const int r = idx / RZ_TW, c = idx % RZ_TW;
+        const int gr = y0 + S + r, gc = x0 + S + c;
+        if (gr >= height || gc >= width) continue;
+        const float v = buf[cur][(r + S) * lw + c + S];
+        unsigned char o;
+        if (v != v) o = (unsigned char)nodata;
+        else o = (unsigned char)(v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v));      // clip, then truncate
+        out[band_base + (long long)gr * width + gc] = o;
+    }
+}
+
+template <int AGG>
+static void launch_tail(const double *acc, const unsigned *cnt, const float *raster, int nb, int width, int height, int sweeps,
+                        int nodata, unsigned char *out_dev) {
+    const int tiles_x = (width + RZ_TW - 1) / RZ_TW, tiles_y = (height + RZ_TH - 1) / RZ_TH;
+    hipLaunchKernelGGL((rz_tail_kernel<AGG>), dim3((unsigned)((long long)tiles_x * tiles_y * nb)), dim3(256), 0, ctx().stream, acc,
+                       cnt, raster, width, height, sweeps, nodata, tiles_x, tiles_y, out_dev);
+}
+
 template <int AGG>
 static int run_rasterize(const double *dx, const double *dy, const double *dv, long long n, int nb, double x_min,
                          double y_max, double res, int width, int height, int sweeps, int nodata, double *acc,
@@ -201,6 +347,11 @@ static int run_rasterize(const double *dx, const double *dy, const double *dv, l
     ALP_HIP(hipMemsetAsync(cnt, 0, (size_t)total * sizeof(unsigned), st));
     hipLaunchKernelGGL((rz_scatter_kernel<AGG>), dim3(grid(n)), dim3(256), 0, st, dx, dy, dv, n, nb, x_min, y_max, res,
                        width, height, acc, cnt);
+    if (sweeps <= RZ_SMAX && !rz_separate_passes()) {
+        launch_tail<AGG>(acc, cnt, nullptr, nb, width, height, sweeps, nodata, out_dev);
+        ALP_HIP(hipGetLastError());
+        return ALP_OK;
+    }
     hipLaunchKernelGGL((rz_finalize_kernel<AGG>), dim3(grid(total)), dim3(256), 0, st, acc, cnt, total, ra);
     float *cur = ra, *nxt = rb;
     for (int s = 0; s < sweeps; ++s) {
@@ -338,6 +489,14 @@ static int run_rasterize_median(const double *dx, const double *dy, const double
         e = rocprim::radix_sort_pairs(sort_tmp, t, cell_s, cell_s2, idx2, idx, count, 0u, 32u, st);   // stably by pixel
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(rz_median_runs_kernel, dim3(grid(n)), dim3(256), 0, st, cell_s2, idx, dv, n, nb, b, ra + b * hw);
+    }
+    if (e == hipSuccess && sweeps <= RZ_SMAX && !rz_separate_passes()) {
+        launch_tail<AGG_MEDIAN_FOCAL>(nullptr, nullptr, ra, nb, width, height, sweeps, nodata, out_dev);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);          // scratch is freed below
+        hipFree(scratch);
+        if (e != hipSuccess) return fail(ALP_EHIP, "median rasterisation: %s", hipGetErrorString(e));
+        return ALP_OK;
     }
     float *cur = ra, *nxt = rb;
     for (int s = 0; s < sweeps && e == hipSuccess; ++s) {
