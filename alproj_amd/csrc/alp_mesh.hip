@@ -47,6 +47,9 @@ __global__ __launch_bounds__(256) void surface_build_kernel(const Z *__restrict_
                                                             double ox, double oz, double oy,
                                                             float *__restrict__ vert, float *__restrict__ value,
                                                             unsigned char *__restrict__ valid) {
+    // (measured, not kept: the workgroup's 768 + 768 floats staged in LDS and stored as whole float4 lines instead of the
+    // 12-byte-strided dword stores below -- 0.90 against 0.82 ms for zmin + build at 100 M vertices: L2 merges the strided
+    // stores into whole lines anyway, the staging only adds a barrier)
     const long long n = rows * cols;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void residual_batch_kernel(const T *__restrict
             T xd, yd, u, v;
             project_norm<T>(poses[b].v, qx, qy, qz, xd, yd);
             to_pixels<T>(poses[b].v, xd, yd, u, v);
-            out[(int64_t)b * n + i] = make_double2((double)(ou - u), (double)(ov - v));
+            Num<double>::nt_store(make_double2((double)(ou - u), (double)(ov - v)), out + ((int64_t)b * n + i));    // written once, read by the copy engine
         }
     }
 }
