@@ -93,6 +93,7 @@ _SIGNATURES = {
     "alp_render_fetch_valid_planes": [_c_void_p, _c_dp, ctypes.POINTER(ctypes.c_uint32), _c_dp, _c_dp, _c_dp],
     "alp_render_gather": [_c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), _c_i64, _c_dp,
                           _c_dp],
+    "alp_distance_mask": [_c_dp, _c_i64, _c_dp, _c_double, _c_double, ctypes.POINTER(ctypes.c_uint8)],
     "alp_rasterize_points": [_c_dp, _c_dp, _c_dp, _c_i64, _c_i64, _c_double, _c_double, _c_double, _c_i64, _c_i64,
                              _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_uint8)],
     "alp_render_rasterize_plan": [_c_void_p, _c_dp, ctypes.POINTER(_c_i64), _c_dp],
@@ -536,6 +537,21 @@ class Mesh:
         check(self._lib.alp_render_gather(self._h, u.ctypes.data_as(ip), v.ctypes.data_as(ip), len(u),
                                           None if off is None else as_dp(off), as_dp(xyz)))
         return xyz
+
+
+def distance_mask(xyz, camera, min_distance=None, max_distance=None):
+    """Boolean mask of the rows of xyz (n, 3) float64 whose distance from ``camera`` (x, y, z) lies in
+    [min_distance, max_distance] (None = no bound); rows with a NaN coordinate are False (gcp.py:711-724)."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+    if xyz.ndim != 2 or xyz.shape[1] != 3:
+        raise ValueError("xyz must be (n, 3)")
+    cam = np.ascontiguousarray(camera, dtype=np.float64)
+    keep = np.zeros(len(xyz), dtype=np.uint8)
+    check(lib().alp_distance_mask(as_dp(xyz), len(xyz), as_dp(cam),
+                                  float("nan") if min_distance is None else float(min_distance),
+                                  float("nan") if max_distance is None else float(max_distance),
+                                  keep.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))))
+    return keep.astype(bool)
 
 
 def distort_image(img, coeffs):

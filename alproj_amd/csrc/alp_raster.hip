@@ -987,6 +987,32 @@ int alp_render_gather(alp_mesh_t *m, const int32_t *u, const int32_t *v, int64_t
     return ALP_OK;
 }
 
+int alp_distance_mask(const double *xyz, int64_t n, const double camera[3], double min_distance, double max_distance,
+                      uint8_t *keep) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(n >= 0, "n is negative");
+    if (n == 0) return ALP_OK;
+    ALP_REQUIRE(xyz && camera && keep, "NULL argument");
+    ALP_REQUIRE(!(min_distance < 0), "min_distance must be non-negative");
+    ALP_REQUIRE(!(max_distance < min_distance), "max_distance must be >= min_distance");
+    char *dev = nullptr;
+    const size_t xyz_bytes = (size_t)n * 3 * sizeof(double);
+    if (int rc = scratch_reserve(xyz_bytes + (size_t)n, (void **)&dev)) return rc;
+    unsigned char *keep_dev = (unsigned char *)(dev + xyz_bytes);
+    hipStream_t st = ctx().stream;
+    hipError_t e = hipMemcpyAsync(dev, xyz, xyz_bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        KTimeScope kt;
+        hipLaunchKernelGGL(distance_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double *)dev,
+                           (long long)n, camera[0], camera[1], camera[2], min_distance, max_distance, keep_dev);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(keep, keep_dev, (size_t)n, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return fail(ALP_EHIP, "alp_distance_mask: %s", hipGetErrorString(e));
+    return ALP_OK;
+}
+
 int alp_render_valid_count(alp_mesh_t *m, int64_t *count) {
     if (int rc = require_init()) return rc;
     ALP_REQUIRE(m && count, "NULL argument");

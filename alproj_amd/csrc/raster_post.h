@@ -55,6 +55,22 @@ __global__ __launch_bounds__(256) void gather_pixels_kernel(const float *__restr
     xyz[3 * i + 2] = z;
 }
 
+// filter_gcp_distance, src/alproj/gcp.py:711-724: rows with a NaN coordinate are dropped, the others kept when their
+// distance from the camera -- sqrt(dx^2 + dy^2 + dz^2) in numpy's order, no contraction -- lies in [lo, hi] (a NaN bound
+// is an absent one; a NaN distance fails every comparison, like numpy's)
+__global__ __launch_bounds__(256) void distance_mask_kernel(const double *__restrict__ xyz, long long n, double cx, double cy,
+                                                            double cz, double lo, double hi, unsigned char *__restrict__ keep) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = xyz[3 * i + 0], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    bool k = x == x && y == y && z == z;
+    const double dx = x - cx, dy = y - cy, dz = z - cz;
+    const double d = sqrt(dx * dx + dy * dy + dz * dz);
+    if (lo == lo) k = k && d >= lo;
+    if (hi == hi) k = k && d <= hi;
+    keep[i] = k ? 1 : 0;
+}
+
 __global__ __launch_bounds__(256) void valid_count_kernel(const float *__restrict__ img, long long npix,
                                                           unsigned *__restrict__ counts) {
     __shared__ unsigned s[4];

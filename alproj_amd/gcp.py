@@ -13,6 +13,7 @@ workload and stays with the reference.  ``set_gcp`` accepts, besides the referen
 import numpy as np
 import pandas as pd
 
+from . import _lib
 from .project import ReverseProjection
 
 __all__ = ["set_gcp", "filter_gcp_distance"]
@@ -39,7 +40,8 @@ def set_gcp(match, rev_proj):
 def filter_gcp_distance(gcp, params, min_distance=None, max_distance=None):
     """Keep the GCPs whose 3-D distance from the camera position lies in
     [min_distance, max_distance] (reference gcp.py:651-726): same validation and messages, rows
-    with NaN coordinates dropped, index reset; a copy when there is nothing to filter."""
+    with NaN coordinates dropped, index reset; a copy when there is nothing to filter.  The mask is
+    formed on the device (``alp_distance_mask``), next to the gather that made the coordinates."""
     for key in ("x", "y", "z"):
         if key not in params:
             raise KeyError(f"params must contain '{key}' key")
@@ -49,12 +51,7 @@ def filter_gcp_distance(gcp, params, min_distance=None, max_distance=None):
         raise ValueError("max_distance must be >= min_distance")
     if len(gcp) == 0 or (min_distance is None and max_distance is None):
         return gcp.copy()
-    valid = gcp.dropna(subset=["x", "y", "z"])
-    d = np.sqrt((valid["x"].values - params["x"]) ** 2 + (valid["y"].values - params["y"]) ** 2 +
-                (valid["z"].values - params["z"]) ** 2)
-    keep = np.ones(len(valid), dtype=bool)
-    if min_distance is not None:
-        keep &= d >= min_distance
-    if max_distance is not None:
-        keep &= d <= max_distance
-    return valid[keep].reset_index(drop=True)
+    xyz = np.column_stack([gcp["x"].to_numpy(dtype=np.float64), gcp["y"].to_numpy(dtype=np.float64),
+                           gcp["z"].to_numpy(dtype=np.float64)])
+    keep = _lib.distance_mask(xyz, [params["x"], params["y"], params["z"]], min_distance, max_distance)
+    return gcp[keep].reset_index(drop=True)

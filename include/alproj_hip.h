@@ -332,6 +332,14 @@ int alp_render_fetch_valid_planes(alp_mesh_t *mesh, const double *offsets, uint3
 int alp_render_gather(alp_mesh_t *mesh, const int32_t *u, const int32_t *v, int64_t n,
                       const double *offsets, double *xyz_out);
 
+/* filter_gcp_distance(), src/alproj/gcp.py:711-724: keep[i] = 1 for the rows of xyz[n][3] (x, y, z as alp_render_gather
+ * writes them) without a NaN coordinate whose distance from camera[3] (params x, y, z) is >= min_distance and
+ * <= max_distance, 0 otherwise.  A NaN bound is an absent one (the reference's None); the distance is formed as numpy
+ * forms it (sqrt(dx**2 + dy**2 + dz**2), float64, no contraction), so the mask is the reference's.  Validation as
+ * gcp.py:699-703 (negative minimum, maximum below minimum: ALP_EINVAL). */
+int alp_distance_mask(const double *xyz, int64_t n, const double camera[3], double min_distance,
+                      double max_distance, uint8_t *keep);
+
 /* Compute part of to_geotiff(), src/alproj/project.py:376-503 (the GeoTIFF file itself is
  * written by the caller): n points (x, y, values[n][nb]) -> uint8 raster out[nb][height][width].
  * Pixel of a point: col = int((x - x_min) / resolution), row = int((y_max - y) / resolution),

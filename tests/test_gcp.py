@@ -1,7 +1,9 @@
 """set_gcp / filter_gcp_distance against vectors captured from the
 reference's own functions (tests/golden/gen_golden_gcp.py), plus the behaviours the
-reference's tests/test_gcp.py::TestFilterGcpDistance pins.  The DataFrame path runs on the
-CPU; the device path (ReverseProjection -> alp_render_gather) is in the gpu-marked tests."""
+reference's tests/test_gcp.py::TestFilterGcpDistance pins.  set_gcp's DataFrame join and the
+validation / nothing-to-filter returns of filter_gcp_distance run on the CPU; the device paths
+(ReverseProjection -> alp_render_gather, the distance mask alp_distance_mask) are in the gpu-marked
+tests/test_gpu_gcp.py and tests/test_gpu_raster.py."""
 import os
 
 import numpy as np
@@ -35,31 +37,12 @@ def test_set_gcp_frame_matches_reference(key, exp):
     np.testing.assert_array_equal(out.to_numpy(dtype=np.float64), G[f"{exp}_values"])
 
 
-def test_filter_matches_reference():
-    g = pd.DataFrame(G["filt_input"], columns=["u", "v", "x", "y", "z"], index=G["filt_input_index"])
-    cam = dict(zip("xyz", G["cam"]))
-    for k, (lo, hi) in enumerate(G["filt_cases"]):
-        out = filter_gcp_distance(g, cam, None if np.isnan(lo) else lo, None if np.isnan(hi) else hi)
-        np.testing.assert_array_equal(out.to_numpy(dtype=np.float64), G[f"filt{k}_values"])
-        np.testing.assert_array_equal(out.index.to_numpy(), G[f"filt{k}_index"])
-
-
 def _three(xs=(100, 200, 300)):
     n = len(xs)
     return pd.DataFrame({"u": list(xs), "v": list(xs), "x": list(xs), "y": [0] * n, "z": [0] * n})
 
 
 ORIGIN = {"x": 0, "y": 0, "z": 0}
-
-
-def test_filter_min_max_and_boundaries():
-    assert filter_gcp_distance(_three(), ORIGIN, min_distance=150)["x"].tolist() == [200, 300]
-    assert filter_gcp_distance(_three(), ORIGIN, max_distance=250)["x"].tolist() == [100, 200]
-    r = filter_gcp_distance(_three((100, 200, 300, 400)), ORIGIN, min_distance=150, max_distance=350)
-    assert r["x"].tolist() == [200, 300] and list(r.index) == [0, 1]
-    p = pd.DataFrame({"u": [1], "v": [1], "x": [3], "y": [4], "z": [0]})
-    assert len(filter_gcp_distance(p, ORIGIN, min_distance=5)) == 1        # distance exactly 5 is kept
-    assert len(filter_gcp_distance(p, ORIGIN, min_distance=5.1)) == 0
 
 
 def test_filter_empty_copy_nan():
@@ -70,9 +53,6 @@ def test_filter_empty_copy_nan():
     r = filter_gcp_distance(g, ORIGIN)
     r.iloc[0, 0] = 999
     assert g.iloc[0, 0] == 100                                              # a copy, not a view
-    g = _three()
-    g["x"] = [100, np.nan, 300]
-    assert filter_gcp_distance(g, ORIGIN, min_distance=0)["x"].tolist() == [100, 300]
 
 
 def test_filter_validation():
