@@ -48,8 +48,8 @@ __global__ __launch_bounds__(256) void surface_build_kernel(const Z *__restrict_
                                                             float *__restrict__ vert, float *__restrict__ value,
                                                             unsigned char *__restrict__ valid) {
     // (measured, not kept: the workgroup's 768 + 768 floats staged in LDS and stored as whole float4 lines instead of the
-    // 12-byte-strided dword stores below -- 0.90 against 0.82 ms for zmin + build at 100 M vertices: L2 merges the strided
-    // stores into whole lines anyway, the staging only adds a barrier)
+    // 12-byte-strided dword stores below -- 0.895-0.898 against 0.882-0.903 ms for zmin + build at 100 M vertices, alternating
+    // on one box: L2 merges the strided stores into whole lines anyway)
     const long long n = rows * cols;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
