@@ -2,7 +2,7 @@
 """Development: randomised differential test of to_geotiff's compute (alp_rasterize_points through
 alproj_amd.project.rasterize, and the device-fed ReverseProjection.rasterize) against the pandas / scipy restatement of the
 reference (oracle.ref_numpy.rasterize_points): clustered points (long runs of one raster cell inside a wave, runs across
-wave and workgroup boundaries), NaN values, 1-4 bands, all four aggregates, 0-3 focal sweeps, several resolutions.
+wave and workgroup boundaries), NaN values, 1-4 bands, all four aggregates, 0-9 focal sweeps, several resolutions.
 Byte-exact.   python3 tools/fuzz_rasterize.py [seconds] [seed]"""
 import os
 import sys
@@ -40,7 +40,7 @@ while time.time() < t_end:
     res = float(rng.choice([0.5, 1.0, 2.0, 3.3]))
     agg = str(rng.choice(["mean", "max", "min", "median"]))
     interp = bool(rng.random() < 0.7)
-    max_dist = float(rng.choice([0.5, 1.0, 2.0, 3.0])) * res
+    max_dist = float(rng.choice([0.5, 1.0, 2.0, 3.0, 3.0, 8.0, 9.0])) * res      # 8 sweeps: the fused tail's last; 9: the separate passes
     nodata = int(rng.choice([255, 0, 7]))
     df = pd.DataFrame({"x": x, "y": y, **{names[b]: vals[:, b] for b in range(nb)}})
     bands = [names[b] for b in rng.permutation(nb)]
