@@ -93,6 +93,8 @@ _SIGNATURES = {
     "alp_render_fetch_valid_planes": [_c_void_p, _c_dp, ctypes.POINTER(ctypes.c_uint32), _c_dp, _c_dp, _c_dp],
     "alp_render_gather": [_c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), _c_i64, _c_dp,
                           _c_dp],
+    "alp_render_fetch_valid_table": [_c_void_p, _c_dp, _c_void_p, _c_int, _c_i64, ctypes.POINTER(ctypes.c_int64),
+                                     ctypes.POINTER(ctypes.c_int16), ctypes.POINTER(ctypes.c_int16), _c_dp],
     "alp_distance_mask": [_c_dp, _c_i64, _c_dp, _c_double, _c_double, ctypes.POINTER(ctypes.c_uint8)],
     "alp_rasterize_points": [_c_dp, _c_dp, _c_dp, _c_i64, _c_i64, _c_double, _c_double, _c_double, _c_i64, _c_i64,
                              _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_uint8)],
@@ -523,6 +525,30 @@ class Mesh:
                                                       idx.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
                                                       as_dp(block[0]), as_dp(block[1]), as_dp(block[2])))
         return idx, block
+
+    TABLE_DTYPES = {np.dtype(np.uint8): ALP_U8, np.dtype(np.uint16): ALP_U16, np.dtype(np.float32): ALP_F32,
+                    np.dtype(np.float64): ALP_F64}
+
+    def fetch_valid_table(self, array, offsets=None):
+        """The columns of reverse_proj's table for the pixels that see the surface, formed on the device: (labels int64 (M,),
+        u int16 (M,), v int16 (M,), block (3 + C, M) float64 = x, y, z and the C channels of ``array`` (h, w, C) at those
+        pixels).  ``array.dtype`` must be one of TABLE_DTYPES."""
+        array = np.ascontiguousarray(array)
+        code = self.TABLE_DTYPES[array.dtype]
+        C = int(array.shape[2])
+        n = _c_i64()
+        check(self._lib.alp_render_valid_count(self._h, ctypes.byref(n)))
+        M = int(n.value)
+        labels = np.empty(M, dtype=np.int64)
+        u = np.empty(M, dtype=np.int16)
+        v = np.empty(M, dtype=np.int16)
+        block = np.empty((3 + C, M), dtype=np.float64)
+        off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.float64)
+        i16 = ctypes.POINTER(ctypes.c_int16)
+        check(self._lib.alp_render_fetch_valid_table(self._h, None if off is None else as_dp(off), array.ctypes.data_as(_c_void_p),
+                                                     code, C, labels.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                                     u.ctypes.data_as(i16), v.ctypes.data_as(i16), as_dp(block)))
+        return labels, u, v, block
 
     def gather(self, u, v, offsets=None):
         """After a render of the vertices themselves: (n, 3) float64 x, y, z seen by the pixels

@@ -1067,6 +1067,58 @@ int alp_render_fetch_valid_planes(alp_mesh_t *m, const double *offsets, uint32_t
     return ALP_OK;
 }
 
+int alp_render_fetch_valid_table(alp_mesh_t *m, const double *offsets, const void *array, int array_dtype, int64_t channels,
+                                 int64_t *index_out, int16_t *u_out, int16_t *v_out, double *block_out) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(m, "mesh handle is NULL");
+    if (m->valid_total < 0) return fail(ALP_ESTATE, "alp_render_fetch_valid_table: call alp_render_valid_count first");
+    const int64_t M = m->valid_total;
+    m->valid_total = -1;
+    if (M == 0) return ALP_OK;
+    ALP_REQUIRE(index_out && u_out && v_out && block_out, "output is NULL");
+    ALP_REQUIRE(channels >= 0 && channels <= 64, "channel count out of range");
+    ALP_REQUIRE(channels == 0 || array, "array is NULL");
+    ALP_REQUIRE(array_dtype == ALP_U8 || array_dtype == ALP_U16 || array_dtype == ALP_F32 || array_dtype == ALP_F64,
+                "array_dtype must be ALP_U8, ALP_U16, ALP_F32 or ALP_F64");
+    const size_t esize = array_dtype == ALP_U8 ? 1 : array_dtype == ALP_U16 ? 2 : array_dtype == ALP_F32 ? 4 : 8;
+    const size_t npix = (size_t)m->w * m->h, arr_bytes = npix * (size_t)channels * esize;
+    // block (x | y | z | channels: float64 rows of M) | labels (int64) | pixel index (u32) | u | v (int16) | the caller's array
+    const size_t plane = (size_t)M * sizeof(double);
+    const size_t block_bytes = (3 + (size_t)channels) * plane;
+    const size_t small = (size_t)M * (8 + 4 + 2 + 2);
+    char *dev = nullptr;
+    if (int rc = scratch_reserve(block_bytes + small + 256 + arr_bytes + 256, (void **)&dev)) return rc;
+    double *block_dev = (double *)dev;
+    long long *index_dev = (long long *)(dev + block_bytes);
+    unsigned *idx_dev = (unsigned *)(index_dev + M);
+    short *u_dev = (short *)(idx_dev + M), *v_dev = u_dev + M;
+    char *arr_dev = (char *)(((uintptr_t)(v_dev + M) + 255) & ~(uintptr_t)255);
+    hipStream_t st = ctx().stream;
+    if (arr_bytes)
+        if (int rc = upload_chunked(arr_dev, array, arr_bytes)) return rc;
+    m->valid_total_planes = M;
+    if (int rc = frame_valid_write(m, offsets, idx_dev, block_dev, true)) return rc;
+    {
+        KTimeScope kt;
+        const dim3 grid((unsigned)((M + 255) / 256));
+#define ALP_COLUMNS(A) hipLaunchKernelGGL(table_columns_kernel<A>, grid, dim3(256), 0, st, idx_dev, (long long)M, m->w, (const A *)arr_dev, \
+                                          (int)channels, index_dev, u_dev, v_dev, block_dev + 3 * M)
+        if (array_dtype == ALP_U8) ALP_COLUMNS(unsigned char);
+        else if (array_dtype == ALP_U16) ALP_COLUMNS(unsigned short);
+        else if (array_dtype == ALP_F32) ALP_COLUMNS(float);
+        else ALP_COLUMNS(double);
+#undef ALP_COLUMNS
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(block_out, block_dev, block_bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(index_out, index_dev, (size_t)M * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(u_out, u_dev, (size_t)M * 2, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(v_out, v_dev, (size_t)M * 2, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return fail(ALP_EHIP, "alp_render_fetch_valid_table: %s", hipGetErrorString(e));
+    return ALP_OK;
+}
+
 int alp_render(alp_mesh_t *m, const double params[ALP_NPARAM], const double *offsets, double min_distance, float *out) {
     if (int rc = alp_render_enqueue(m, params, offsets, min_distance)) return rc;
     return alp_render_fetch(m, out);

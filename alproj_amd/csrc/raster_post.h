@@ -55,6 +55,24 @@ __global__ __launch_bounds__(256) void gather_pixels_kernel(const float *__restr
     xyz[3 * i + 2] = z;
 }
 
+// The remaining columns of reverse_proj's table (project.py:361-368) for the M surviving pixels idx[i]: the table's labels (the
+// linear pixel index, int64), u = column and v = row as int16 (the reference's meshgrid().astype("int16"), wrapping like
+// numpy's cast), and the caller's image channels at that pixel as float64 rows chan[c][i] (numpy's cast on assignment).
+template <typename A>
+__global__ __launch_bounds__(256) void table_columns_kernel(const unsigned *__restrict__ idx, long long M, int w, const A *__restrict__ array,
+                                                            int channels, long long *__restrict__ index64, short *__restrict__ u16,
+                                                            short *__restrict__ v16, double *__restrict__ chan) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const unsigned p = idx[i];
+    const unsigned v = p / (unsigned)w, u = p - v * (unsigned)w;
+    index64[i] = (long long)p;
+    u16[i] = (short)u;
+    v16[i] = (short)v;
+    const A *px = array + (long long)p * channels;
+    for (int c = 0; c < channels; ++c) chan[(long long)c * M + i] = (double)px[c];
+}
+
 // filter_gcp_distance, src/alproj/gcp.py:711-724: rows with a NaN coordinate are dropped, the others kept when their
 // distance from the camera -- sqrt(dx^2 + dy^2 + dz^2) in numpy's order, no contraction -- lies in [lo, hi] (a NaN bound
 // is an absent one; a NaN distance fails every comparison, like numpy's)

@@ -252,25 +252,33 @@ class ReverseProjection:
         t0 = time.perf_counter()
         mesh = self._current()
         C = len(chnames)
-        if hasattr(mesh, "fetch_valid_block"):
-            # x, y, z arrive as three contiguous rows of the (3 + C, M) float64 array that BECOMES the DataFrame's block
-            # (pandas keeps a block as columns x rows): no stacking or transposing copy of the ~0.5 GB
-            idx, block = mesh.fetch_valid_block(self.offsets, C)
-        else:                                   # a host stand-in of the mesh (tests of this host half)
-            idx, xyz = mesh.fetch_valid(self.offsets)
-            block = np.empty((3 + C, len(idx)), dtype=np.float64)
-            block[:3] = xyz.T
-        t1 = time.perf_counter()
-        w = self.w
-        flat = array.reshape(-1, array.shape[2])
-        if C:
-            block[3:] = flat[idx].T             # one gather of the surviving pixels' channels, cast on assignment
-        df = pd.DataFrame(block.T, columns=["x", "y", "z"] + list(chnames), copy=False)
-        v_pix, u_pix = np.divmod(idx, np.uint32(w))          # one pass: row and column of the linear pixel index
-        df.insert(0, "u", u_pix.astype("int16"))
-        df.insert(1, "v", v_pix.astype("int16"))
+        cols = ["x", "y", "z"] + list(chnames)
+        if hasattr(mesh, "fetch_valid_table") and C and array.dtype in mesh.TABLE_DTYPES:
+            # every column is formed on the device (alp_render_fetch_valid_table): x, y, z and the channels arrive as the
+            # contiguous rows of the (3 + C, M) float64 array that BECOMES the DataFrame's block (pandas keeps a block as
+            # columns x rows), u, v and the labels as their own arrays -- the host gathers, casts and divides nothing
+            labels, u_pix, v_pix, block = mesh.fetch_valid_table(array, self.offsets)
+            t1 = time.perf_counter()
+            df = pd.DataFrame(block.T, columns=cols, copy=False)
+        else:
+            if hasattr(mesh, "fetch_valid_block"):
+                idx, block = mesh.fetch_valid_block(self.offsets, C)
+            else:                               # a host stand-in of the mesh (tests of this host half)
+                idx, xyz = mesh.fetch_valid(self.offsets)
+                block = np.empty((3 + C, len(idx)), dtype=np.float64)
+                block[:3] = xyz.T
+            t1 = time.perf_counter()
+            flat = array.reshape(-1, array.shape[2])
+            if C:
+                block[3:] = flat[idx].T         # one gather of the surviving pixels' channels, cast on assignment
+            df = pd.DataFrame(block.T, columns=cols, copy=False)
+            v_pix, u_pix = np.divmod(idx, np.uint32(self.w))     # one pass: row and column of the linear pixel index
+            u_pix, v_pix = u_pix.astype("int16"), v_pix.astype("int16")
+            labels = idx.astype(np.int64)
+        df.insert(0, "u", u_pix)
+        df.insert(1, "v", v_pix)
         # the reference filters a RangeIndex-ed frame, so the labels are the linear pixel indices
-        df.index = pd.Index(idx.astype(np.int64))
+        df.index = pd.Index(labels)
         LAST_TIMING.update(fetch_s=t1 - t0, frame_s=time.perf_counter() - t1)
         if "enqueue_s" in LAST_TIMING and "device_ms" not in LAST_TIMING:      # this call's own frame (reverse_proj)
             LAST_TIMING["device_ms"] = _lib.event_elapsed_ms(_EV0, _EV1)

@@ -325,6 +325,15 @@ int alp_render_fetch_valid(alp_mesh_t *mesh, const double *offsets, uint32_t *id
 int alp_render_fetch_valid_planes(alp_mesh_t *mesh, const double *offsets, uint32_t *idx_out, double *x_out,
                                   double *y_out, double *z_out);
 
+/* The whole table of reverse_proj(), src/alproj/project.py:361-373, for the survivors of alp_render_valid_count (M rows, in
+ * pixel order): index_out[M] = the table's labels (linear pixel index v * w + u: the reference filters a RangeIndex-ed frame),
+ * u_out / v_out[M] = pixel column / row as int16 (:366), block_out = (3 + channels) contiguous float64 rows of M: x, y, z as
+ * alp_render_fetch_valid_planes defines them, then the caller's image array[h][w][channels] (ALP_U8 / _U16 / _F32 / _F64, :364)
+ * at each surviving pixel, cast to float64 -- the DataFrame's float64 block as pandas lays it out.  The array goes up
+ * once (63 MB for a 5616 x 3744 photograph); the host no longer gathers, casts and divides 11.7 M rows on one core. */
+int alp_render_fetch_valid_table(alp_mesh_t *mesh, const double *offsets, const void *array, int array_dtype,
+                                 int64_t channels, int64_t *index_out, int16_t *u_out, int16_t *v_out, double *block_out);
+
 /* set_gcp(), src/alproj/gcp.py:644-648, without the reverse_proj table: for n pixels (u[i], v[i])
  * of the last render (values = the vertices themselves) write xyz_out[i] = (x, y, z) as
  * alp_render_fetch_valid defines them, or NaN where the pixel lies outside the image or does

@@ -218,6 +218,37 @@ def test_reverse_proj_and_sim_image(L, scene):
         prj.reverse_proj(sim, scene["vert"], scene["ind"], p, off, chnames=["a", "b"])
 
 
+def test_reverse_proj_table_columns_formed_on_the_device(L, scene):
+    """to_frame: for uint8 / uint16 / float32 / float64 images every column (labels, u, v, x, y, z, channels) is formed on the
+    device (alp_render_fetch_valid_table); other dtypes keep the host gather.  Same frame either way -- values, dtypes, labels."""
+    import pandas as pd
+    from alproj_amd import project as prj
+    p = pose(scene, "tilt_roll")
+    off = scene["offsets"]
+    rng = np.random.default_rng(9)
+    base = rng.integers(0, 60000, (427, 640, 4))
+    with prj.reverse_proj_device(scene["vert"], scene["ind"], p, off) as rp:
+        want = rp.to_frame(base.astype(np.int32) % 256, list("abcd"))            # int32: the host path
+        assert 1000 < len(want) < 427 * 640
+        for dt, mod in ((np.uint8, 256), (np.uint16, 60000), (np.float32, 256), (np.float64, 256)):
+            img = (base % mod).astype(dt)
+            if dt in (np.float32, np.float64):
+                img = img + dt(0.37)
+            got = rp.to_frame(img, list("abcd"))
+            assert list(got.columns) == list(want.columns) and list(got.dtypes) == list(want.dtypes)
+            np.testing.assert_array_equal(got.index.to_numpy(), want.index.to_numpy())
+            assert got.index.dtype == np.int64 and got["u"].dtype == np.int16 and got["v"].dtype == np.int16
+            for c in ("u", "v", "x", "y", "z"):
+                np.testing.assert_array_equal(got[c].to_numpy(), want[c].to_numpy())
+            flat = img.reshape(-1, 4)[got.index.to_numpy()].astype(np.float64)
+            np.testing.assert_array_equal(got[list("abcd")].to_numpy(), flat)
+            np.testing.assert_array_equal(got["u"].to_numpy() + 640 * got["v"].to_numpy().astype(np.int64), got.index.to_numpy())
+        # a non-contiguous view of a larger image goes through the same entry
+        big = rng.integers(0, 256, (427, 640, 6), dtype=np.uint8)
+        got = rp.to_frame(big[:, :, ::2], list("abc"))
+        np.testing.assert_array_equal(got[list("abc")].to_numpy(), big[:, :, ::2].reshape(-1, 3)[got.index.to_numpy()].astype(np.float64))
+
+
 def test_set_gcp_on_the_device_equals_the_table_join(L, scene):
     """set_gcp against the resident coordinate image (alp_render_gather) gives
     the rows, labels and values of the reference's merge with the reverse_proj table"""
