@@ -95,6 +95,8 @@ _SIGNATURES = {
                           _c_dp],
     "alp_render_fetch_valid_table": [_c_void_p, _c_dp, _c_void_p, _c_int, _c_i64, ctypes.POINTER(ctypes.c_int64),
                                      ctypes.POINTER(ctypes.c_int16), ctypes.POINTER(ctypes.c_int16), _c_dp],
+    "alp_rasterize_columns": [_c_dp, _c_dp, ctypes.POINTER(ctypes.c_void_p), _c_i64, _c_i64, _c_double, _c_double, _c_double,
+                              _c_i64, _c_i64, _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_uint8)],
     "alp_distance_mask": [_c_dp, _c_i64, _c_dp, _c_double, _c_double, ctypes.POINTER(ctypes.c_uint8)],
     "alp_rasterize_points": [_c_dp, _c_dp, _c_dp, _c_i64, _c_i64, _c_double, _c_double, _c_double, _c_i64, _c_i64,
                              _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_uint8)],

@@ -677,11 +677,23 @@ extern "C" int alp_render_rasterize(alp_mesh_t *m, const void *array, int array_
     return ALP_OK;
 }
 
-extern "C" int alp_rasterize_points(const double *x, const double *y, const double *values, int64_t n, int64_t nb,
-                                    double x_min, double y_max, double resolution, int64_t width, int64_t height,
-                                    int agg, int sweeps, int nodata, uint8_t *out) {
+namespace alp {
+
+// columns of a table (each contiguous, as a DataFrame keeps them) -> the interleaved values[i][b] the kernels read
+__global__ __launch_bounds__(256) void rz_interleave_kernel(const double *__restrict__ planar, long long n, int nb,
+                                                            double *__restrict__ values) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        for (int b = 0; b < nb; ++b) values[i * nb + b] = planar[(long long)b * n + i];
+}
+
+// values (n x nb, interleaved) or cols (nb pointers to n contiguous doubles): exactly one is given
+static int rasterize_host_points(const char *who, const double *x, const double *y, const double *values,
+                                 const double *const *cols, int64_t n, int64_t nb, double x_min, double y_max,
+                                 double resolution, int64_t width, int64_t height, int agg, int sweeps, int nodata,
+                                 uint8_t *out) {
     if (int rc = require_init()) return rc;
-    ALP_REQUIRE(x && y && values && out, "NULL argument");
+    ALP_REQUIRE(x && y && (values || cols) && out, "NULL argument");
     ALP_REQUIRE(n >= 1 && nb >= 1 && nb <= 64, "n or band count out of range");
     ALP_REQUIRE(width >= 1 && height >= 1 && width * height <= ((int64_t)1 << 31), "raster size out of range");
     ALP_REQUIRE(resolution > 0, "resolution must be positive");
@@ -689,24 +701,38 @@ extern "C" int alp_rasterize_points(const double *x, const double *y, const doub
                 "agg must be ALP_AGG_MEAN, _MAX, _MIN or _MEDIAN");
     ALP_REQUIRE(n < ((int64_t)1 << 31), "more than 2^31 points");
     ALP_REQUIRE(sweeps >= 0 && sweeps <= 4096, "sweeps out of range");
+    if (cols)
+        for (int64_t b = 0; b < nb; ++b) ALP_REQUIRE(cols[b], "a band column is NULL");
     const size_t total = (size_t)width * height * nb;
     const size_t pts_bytes = (size_t)n * sizeof(double);
     char *dev = nullptr;
-    // x | y | values | acc (f64) | cnt (u32) | raster a | raster b | out (u8)
-    const size_t bytes = pts_bytes * (2 + nb) + total * (8 + 4 + 4 + 4 + 1) + 64;
+    // x | y | values | acc (f64) | cnt (u32) | raster a | raster b | out (u8); the columns are staged in acc | cnt
+    // (12 bytes per band-cell, cleared afterwards) when they fit, else behind out
+    const bool stage_in_acc = cols && pts_bytes * nb <= total * 12;
+    const size_t bytes = pts_bytes * (2 + nb) + total * (8 + 4 + 4 + 4 + 1) + 64 + ((cols && !stage_in_acc) ? pts_bytes * nb + 64 : 0);
     ALP_HIP(hipMalloc((void **)&dev, bytes));
     double *dx = (double *)dev, *dy = dx + n, *dv = dy + n;
     double *acc = dv + (size_t)n * nb;
     unsigned *cnt = (unsigned *)(acc + total);
     float *ra = (float *)(cnt + total), *rb = ra + total;
     unsigned char *out_dev = (unsigned char *)(rb + total);
+    double *planar = stage_in_acc ? acc : (double *)(((uintptr_t)(out_dev + total) + 63) & ~(uintptr_t)63);
     hipStream_t st = ctx().stream;
     hipError_t e = hipMemcpyAsync(dx, x, pts_bytes, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(dy, y, pts_bytes, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(dv, values, pts_bytes * nb, hipMemcpyHostToDevice, st);
+    if (cols) {
+        for (int64_t b = 0; b < nb && e == hipSuccess; ++b)
+            e = hipMemcpyAsync(planar + (size_t)b * n, cols[b], pts_bytes, hipMemcpyHostToDevice, st);
+    } else if (e == hipSuccess) {
+        e = hipMemcpyAsync(dv, values, pts_bytes * nb, hipMemcpyHostToDevice, st);
+    }
     int rc = ALP_OK;
     if (e == hipSuccess) {
         KTimeScope kt;
+        if (cols) {
+            const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, (long long)ctx().cu_count * 8);
+            hipLaunchKernelGGL(rz_interleave_kernel, dim3(grid), dim3(256), 0, st, planar, (long long)n, (int)nb, dv);
+        }
         if (agg == ALP_AGG_MEAN)
             rc = run_rasterize<AGG_MEAN>(dx, dy, dv, n, (int)nb, x_min, y_max, resolution, (int)width, (int)height, sweeps,
                                          nodata, acc, cnt, ra, rb, out_dev);
@@ -724,6 +750,22 @@ extern "C" int alp_rasterize_points(const double *x, const double *y, const doub
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     hipFree(dev);
     if (rc) return rc;
-    if (e != hipSuccess) return fail(ALP_EHIP, "alp_rasterize_points: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail(ALP_EHIP, "%s: %s", who, hipGetErrorString(e));
     return ALP_OK;
+}
+
+}  // namespace alp
+
+extern "C" int alp_rasterize_points(const double *x, const double *y, const double *values, int64_t n, int64_t nb,
+                                    double x_min, double y_max, double resolution, int64_t width, int64_t height,
+                                    int agg, int sweeps, int nodata, uint8_t *out) {
+    return alp::rasterize_host_points("alp_rasterize_points", x, y, values, nullptr, n, nb, x_min, y_max, resolution, width, height,
+                                      agg, sweeps, nodata, out);
+}
+
+extern "C" int alp_rasterize_columns(const double *x, const double *y, const double *const *columns, int64_t n, int64_t nb,
+                                     double x_min, double y_max, double resolution, int64_t width, int64_t height,
+                                     int agg, int sweeps, int nodata, uint8_t *out) {
+    return alp::rasterize_host_points("alp_rasterize_columns", x, y, nullptr, columns, n, nb, x_min, y_max, resolution, width, height,
+                                      agg, sweeps, nodata, out);
 }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development: randomised differential test of to_geotiff's compute (alp_rasterize_points through
+"""Development: randomised differential test of to_geotiff's compute (alp_rasterize_columns through
 alproj_amd.project.rasterize, and the device-fed ReverseProjection.rasterize) against the pandas / scipy restatement of the
 reference (oracle.ref_numpy.rasterize_points): clustered points (long runs of one raster cell inside a wave, runs across
 wave and workgroup boundaries), NaN values, 1-4 bands, all four aggregates, 0-9 focal sweeps, several resolutions.
