@@ -255,7 +255,7 @@ def dropin_leg(L, syn, surf, n_side, cam):
     return rec, df, sim
 
 
-def next_rows_leg(L, syn, orc, df):
+def next_rows_leg(L, syn, orc, df, ras_dev=None):
     """kernel time from HIP events inside the library (alp_kernel_timing), algorithmic bytes
     over it against the HBM peak, the numpy port of the reference timed beside it on a bounded sample."""
     from alproj_amd import project as aproj
@@ -335,6 +335,8 @@ def next_rows_leg(L, syn, orc, df):
             alg = npts * (16 + 8 * 3) + total * (2 * 12 + 1) if agg == "mean" else None
             f2[agg] = {"call_ms_incl_transfers": wall * 1e3, "kernel_ms": k_ms, "raster": list(raster.shape),
                        "mpoints_per_s_kernel": npts / (k_ms / 1e3) / 1e6}
+            if agg == "mean" and ras_dev is not None:
+                f2["equals_device_fed_raster"] = bool(np.array_equal(raster, ras_dev))
             if alg:
                 f2[agg]["roofline"] = {"bound": "hbm", "algorithmic_bytes": alg, "achieved": alg / (k_ms / 1e3) / 1e9, "peak": HBM_PEAK / 1e9,
                                        "unit": "GB/s", "frac": alg / (k_ms / 1e3) / HBM_PEAK,
@@ -636,7 +638,7 @@ def main():
             del img, ind
 
     # ---------------------------------------------------------------- the reference-typed call pair (1 GPU)
-    df_full = None
+    df_full = ras_dev = None
     if ctl.world == 1 and not args.no_dropin and not args.no_raster:
         out["dropin_call"], df_full, _sim = dropin_leg(L, syn, surf, n_side, syn.base_params(n_side))
         # f4: set_gcp's gather of 1 127 GCPs from the resident coordinate image (gcp.py:644-648)
@@ -657,9 +659,24 @@ def main():
             out["f4_set_gcp_gather"] = {"gcps": len(uu), "call_ms": t_g * 1e3, "kernel_ms": k_ms / max(k_n, 1),
                                         "reference_merge_with_the_table_ms_same_box": None if t_join is None else t_join * 1e3,
                                         "note": "launch-latency bound: 1127 x 12 B gathered"}
+            # f2 fed from the RESIDENT frame: reverse_proj -> to_geotiff's compute without the table in between
+            # (ReverseProjection.rasterize: alp_render_rasterize_plan + alp_render_rasterize); the 63 MB image goes up, the raster comes back
+            rp.rasterize(_sim, ["B", "G", "R"], 1.0, ["B", "G", "R"], True, 1.0, "mean")      # warm-up
+            L.kernel_timing(True)
+            L.kernel_time_ms()
+            t = time.perf_counter()
+            ras_dev, _bounds = rp.rasterize(_sim, ["B", "G", "R"], 1.0, ["B", "G", "R"], True, 1.0, "mean")
+            wall = time.perf_counter() - t
+            k_ms, k_n = L.kernel_time_ms()
+            L.kernel_timing(False)
+            out["f2_device_fed"] = {"call": "ReverseProjection.rasterize(image, ...) = reverse_proj + to_geotiff compute, no table",
+                                    "points": len(df_full), "raster": list(ras_dev.shape), "call_ms_incl_image_upload_and_raster_fetch": wall * 1e3,
+                                    "kernel_ms": k_ms, "kernel_sections": k_n}
         aproj.clear_mesh_cache()
     if ctl.world == 1 and not args.no_next_rows:
-        out["next_rows"] = next_rows_leg(L, syn, orc, df_full)
+        out["next_rows"] = next_rows_leg(L, syn, orc, df_full, ras_dev)
+        if "f2_device_fed" in out and "f2_rasterize_points" in out["next_rows"]:
+            out["f2_device_fed"]["byte_identical_to_the_table_path"] = out["next_rows"]["f2_rasterize_points"].pop("equals_device_fed_raster")
         del df_full
         # the whole pipeline of examples/pipeline_synthetic.py (= the reference's example.py) at the reference's sizes:
         # 5616 x 3744 image, 6000 x 6000 = 36 M-vertex surface (distance 3000 m at 1 m, example.py:22,25)
