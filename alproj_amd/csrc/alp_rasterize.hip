@@ -249,7 +249,7 @@ template <int AGG>
 __global__ __launch_bounds__(256) void rz_tail_kernel(const double *__restrict__ acc, const unsigned *__restrict__ cnt,
                                                       const float *__restrict__ raster, int width, int height, int S,
                                                       int nodata, int tiles_x, int tiles_y, unsigned char *__restrict__ out) {
-    __shared__ float buf[2][(RZ_TH + 2 * RZ_SMAX) * (RZ_TW + 2 * RZ_SMAX)];
+    extern __shared__ float rz_tail_lds[];                   // two rasters of (RZ_TH + 2 S) x (RZ_TW + 2 S) floats: 18 KB at S = 1, 31 KB at S = 8
     __shared__ int s_any;
     const float nan = __int_as_float(0x7fc00000);
     const int tid = (int)threadIdx.x;
@@ -261,32 +261,57 @@ __global__ __launch_bounds__(256) void rz_tail_kernel(const double *__restrict__
     const long long band_base = (long long)(t / tiles_y) * hw;
     const int x0 = tx * RZ_TW - S, y0 = ty * RZ_TH - S;        // raster position of LDS cell (0, 0)
     const int lw = RZ_TW + 2 * S, lh = RZ_TH + 2 * S;
+    float *buf_cur = rz_tail_lds, *buf_nxt = rz_tail_lds + lw * lh;
     const float inv_lw = 1.0f / (float)lw;                       // idx / lw through (idx + 0.5) * (1 / lw): idx < 3840, exact
     if (tid == 0) s_any = 0;
     __syncthreads();
     bool any = false;
-    for (int idx = tid; idx < lw * lh; idx += 256) {
-        const int r = (int)(((float)idx + 0.5f) * inv_lw), c = idx - r * lw;
-        const int gr = y0 + r, gc = x0 + c;
-        float v = nan;                                           // outside the raster: NaN, in every sweep
-        if (gr >= 0 && gr < height && gc >= 0 && gc < width) {
-            const long long g = band_base + (long long)gr * width + gc;
-            if constexpr (AGG == AGG_MEDIAN_FOCAL) {
-                v = raster[g];
-            } else {
-                const unsigned n = cnt[g];
-                if (n) {
-                    if constexpr (AGG == AGG_MEAN) v = (float)(acc[g] / (double)n);
-                    else v = (float)ord2d(reinterpret_cast<const unsigned long long *>(acc)[g]);
+    if constexpr (AGG == AGG_MEDIAN_FOCAL) {
+        for (int idx = tid; idx < lw * lh; idx += 256) {
+            const int r = (int)(((float)idx + 0.5f) * inv_lw), c = idx - r * lw;
+            const int gr = y0 + r, gc = x0 + c;
+            float v = nan;                                       // outside the raster: NaN, in every sweep
+            if (gr >= 0 && gr < height && gc >= 0 && gc < width) v = raster[band_base + (long long)gr * width + gc];
+            buf_cur[idx] = v;
+            any |= (v == v);
+        }
+    } else {
+        // two passes with the trip count fixed, so that all count loads of a lane are in flight together and the accumulator
+        // loads (occupied cells only) after them, instead of one count -> accumulator dependency per turn of a rolled loop
+        constexpr int TURNS = ((RZ_TW + 2 * RZ_SMAX) * (RZ_TH + 2 * RZ_SMAX) + 255) / 256;
+        unsigned have[TURNS];
+        long long at[TURNS];
+        const int cells = lw * lh;
+#pragma unroll
+        for (int k = 0; k < TURNS; ++k) {
+            const int idx = tid + k * 256;
+            have[k] = 0;
+            at[k] = 0;
+            if (idx < cells) {
+                const int r = (int)(((float)idx + 0.5f) * inv_lw), c = idx - r * lw;
+                const int gr = y0 + r, gc = x0 + c;
+                if (gr >= 0 && gr < height && gc >= 0 && gc < width) {       // outside the raster: NaN, in every sweep
+                    at[k] = band_base + (long long)gr * width + gc;
+                    have[k] = cnt[at[k]];
                 }
             }
         }
-        buf[0][idx] = v;
-        any |= (v == v);
+#pragma unroll
+        for (int k = 0; k < TURNS; ++k) {
+            const int idx = tid + k * 256;
+            if (idx < cells) {
+                float v = nan;
+                if (have[k]) {
+                    if constexpr (AGG == AGG_MEAN) v = (float)(acc[at[k]] / (double)have[k]);
+                    else v = (float)ord2d(reinterpret_cast<const unsigned long long *>(acc)[at[k]]);
+                    any = true;
+                }
+                buf_cur[idx] = v;
+            }
+        }
     }
     if (any) s_any = 1;
     __syncthreads();
-    int cur = 0;
     if (s_any) {
         for (int s = 0; s < S; ++s) {
             const int rw = lw - 2 * (s + 1), rh = lh - 2 * (s + 1);
@@ -296,22 +321,24 @@ __global__ __launch_bounds__(256) void rz_tail_kernel(const double *__restrict__
                 r += s + 1;
                 c += s + 1;
                 const int at = r * lw + c;
-                float o = buf[cur][at];
+                float o = buf_cur[at];
                 if (o != o) {
                     const int gr = y0 + r, gc = x0 + c;
-                    if (gr >= 0 && gr < height && gc >= 0 && gc < width) o = rz_window_value<AGG>(buf[cur], lw, at);
+                    if (gr >= 0 && gr < height && gc >= 0 && gc < width) o = rz_window_value<AGG>(buf_cur, lw, at);
                 }
-                buf[cur ^ 1][at] = o;
+                buf_nxt[at] = o;
             }
             __syncthreads();
-            cur ^= 1;
+            float *const done = buf_cur;
+            buf_cur = buf_nxt;
+            buf_nxt = done;
         }
     }
     for (int idx = tid; idx < RZ_TW * RZ_TH; idx += 256) {
         const int r = idx / RZ_TW, c = idx % RZ_TW;
         const int gr = y0 + S + r, gc = x0 + S + c;
         if (gr >= height || gc >= width) continue;
-        const float v = buf[cur][(r + S) * lw + c + S];
+        const float v = buf_cur[(r + S) * lw + c + S];
         unsigned char o;
         if (v != v) o = (unsigned char)nodata;
         else o = (unsigned char)(v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v));      // clip, then truncate
@@ -323,7 +350,8 @@ template <int AGG>
 static void launch_tail(const double *acc, const unsigned *cnt, const float *raster, int nb, int width, int height, int sweeps,
                         int nodata, unsigned char *out_dev) {
     const int tiles_x = (width + RZ_TW - 1) / RZ_TW, tiles_y = (height + RZ_TH - 1) / RZ_TH;
-    hipLaunchKernelGGL((rz_tail_kernel<AGG>), dim3((unsigned)((long long)tiles_x * tiles_y * nb)), dim3(256), 0, ctx().stream, acc,
+    const size_t lds = 2 * sizeof(float) * (size_t)(RZ_TW + 2 * sweeps) * (size_t)(RZ_TH + 2 * sweeps);
+    hipLaunchKernelGGL((rz_tail_kernel<AGG>), dim3((unsigned)((long long)tiles_x * tiles_y * nb)), dim3(256), lds, ctx().stream, acc,
                        cnt, raster, width, height, sweeps, nodata, tiles_x, tiles_y, out_dev);
 }
 
