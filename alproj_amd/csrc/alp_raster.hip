@@ -889,7 +889,7 @@ int alp_mesh_destroy(alp_mesh_t *m) {
                     (void *)m->tri_present, (void *)m->tri_rank, (void *)m->vis, (void *)m->image,
                     (void *)m->queue, (void *)m->gqueue, (void *)m->qcount_dev, (void *)m->compact_counts, (void *)m->compact_offsets,
                     (void *)m->tile_bounds, (void *)m->tile_lists, (void *)m->hiz, (void *)m->park_small, (void *)m->park_cell,
-                    (void *)m->rz_points})
+                    (void *)m->rz_points, (void *)m->rz_work})
         if (p) hipFree(p);
     if (m->qcount_host) hipHostFree(m->qcount_host);
     delete m;

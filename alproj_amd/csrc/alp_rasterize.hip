@@ -662,8 +662,14 @@ extern "C" int alp_render_rasterize(alp_mesh_t *m, const void *array, int array_
     const size_t total = (size_t)width * height * nb;
     // values | acc (f64) | cnt (u32) | raster a | raster b | out (u8) | band table | the caller's array
     const size_t bytes = (size_t)n * nb * 8 + total * (8 + 4 + 4 + 4 + 1) + 64 * 4 + 256 + arr_bytes + 64;
-    char *dev = nullptr;
-    ALP_HIP(hipMalloc((void **)&dev, bytes));
+    if (bytes > m->rz_work_cap) {
+        if (m->rz_work) hipFree(m->rz_work);
+        m->rz_work = nullptr;
+        m->rz_work_cap = 0;
+        ALP_HIP(hipMalloc((void **)&m->rz_work, bytes));
+        m->rz_work_cap = bytes;
+    }
+    char *dev = m->rz_work;
     double *dv = (double *)dev;
     double *acc = dv + (size_t)n * nb;
     unsigned *cnt = (unsigned *)(acc + total);
@@ -699,7 +705,6 @@ extern "C" int alp_render_rasterize(alp_mesh_t *m, const void *array, int array_
     if (!rc && e == hipSuccess) e = hipMemcpyAsync(out, out_dev, total, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     else hipStreamSynchronize(st);
-    hipFree(dev);
     if (rc) return rc;
     if (e != hipSuccess) return fail(ALP_EHIP, "alp_render_rasterize: %s", hipGetErrorString(e));
     return ALP_OK;
