@@ -44,6 +44,8 @@ _SIGNATURES = {
     "alp_shutdown": [],
     "alp_device_count": [ctypes.POINTER(_c_int)],
     "alp_device_info": [ctypes.c_char_p, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_i64)],
+    "alp_device_pci_bus_id": [ctypes.c_char_p, _c_int],
+    "alp_host_hash64": [_c_void_p, _c_i64, _c_int, ctypes.POINTER(ctypes.c_uint64)],
     "alp_synchronize": [],
     "alp_event_record": [_c_int],
     "alp_event_elapsed_ms": [_c_int, _c_int, _c_fp],
@@ -55,6 +57,8 @@ _SIGNATURES = {
     "alp_comm_destroy": [],
     "alp_comm_info": [ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)],
     "alp_comm_bcast": [_c_void_p, _c_i64, _c_int],
+    "alp_comm_allgather_counts": [_c_i64, ctypes.POINTER(_c_i64)],
+    "alp_comm_allgatherv": [_c_void_p, _c_void_p, ctypes.POINTER(_c_i64)],
     "alp_points_create": [_c_void_p, _c_int, _c_i64, _c_dp, _c_int, ctypes.POINTER(_c_void_p)],
     "alp_points_destroy": [_c_void_p],
     "alp_points_count": [_c_void_p, ctypes.POINTER(_c_i64)],
@@ -82,6 +86,8 @@ _SIGNATURES = {
     "alp_render_fetch_u8": [_c_void_p, ctypes.c_float, _c_int, ctypes.POINTER(ctypes.c_uint8)],
     "alp_mesh_set_value": [_c_void_p, _c_void_p, _c_int],
     "alp_mesh_frame_counts": [_c_void_p, ctypes.POINTER(_c_i64)],
+    "alp_mesh_frame_ms": [_c_void_p, _c_fp],
+    "alp_mesh_trim": [_c_void_p],
     "alp_mesh_set_value_source": [_c_void_p, _c_int],
     "alp_mesh_set_valid": [_c_void_p, ctypes.POINTER(ctypes.c_uint8)],
     "alp_mesh_from_rasters": [_c_void_p, _c_int, _c_i64, _c_i64, _c_dp, ctypes.c_double, _c_void_p, _c_int,
@@ -158,7 +164,19 @@ def device_info():
     cu = _c_int()
     mem = _c_i64()
     check(l.alp_device_info(name, 128, ctypes.byref(cu), ctypes.byref(mem)))
-    return {"arch": name.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value}
+    bus = ctypes.create_string_buffer(32)
+    check(l.alp_device_pci_bus_id(bus, 32))
+    return {"arch": name.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value, "pci_bus_id": bus.value.decode()}
+
+
+def host_hash64(a, threads=0):
+    """64-bit content digest of a C-contiguous numpy array (alp_host_hash64; host threads, no device needed)"""
+    a = np.asarray(a)
+    if not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("array must be C-contiguous")
+    d = ctypes.c_uint64()
+    check(load().alp_host_hash64(a.ctypes.data_as(_c_void_p), a.nbytes, int(threads), ctypes.byref(d)))
+    return int(d.value)
 
 
 def params_vector(params):
@@ -357,6 +375,16 @@ class Mesh:
         c = (_c_i64 * 4)()
         check(self._lib.alp_mesh_info(self._h, c))
         return dict(implicit=bool(c[0]), grid_h=int(c[1]), grid_w=int(c[2]), n_tri=int(c[3]))
+
+    def frame_ms(self):
+        """device ms of the launches of the last render_enqueue (waits for the frame)"""
+        ms = ctypes.c_float()
+        check(self._lib.alp_mesh_frame_ms(self._h, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def trim(self):
+        """release the rasterisation work areas kept between calls (alp_mesh_trim)"""
+        check(self._lib.alp_mesh_trim(self._h))
 
     def frame_counts(self):
         """(full frames, frames served from the visibility cache by the resolve stage alone)"""
@@ -681,6 +709,20 @@ def comm_bcast(array, root=0):
         raise ValueError("array must be C-contiguous")
     check(lib().alp_comm_bcast(array.ctypes.data_as(_c_void_p), array.nbytes, int(root)))
     return array
+
+
+def comm_allgather(array):
+    """Concatenation, in rank order, of every rank's 1-D / 2-D C-contiguous array along axis 0 (rows of equal width, row
+    counts may differ); a copy without a communicator (alp_comm_allgather_counts + alp_comm_allgatherv)."""
+    array = np.ascontiguousarray(array)
+    _, world = comm_info()
+    counts = (_c_i64 * world)()
+    check(lib().alp_comm_allgather_counts(array.nbytes, counts))
+    row = array.strides[0] if array.ndim > 1 else array.itemsize
+    total = sum(counts)
+    out = np.empty((total // row,) + array.shape[1:], dtype=array.dtype)
+    check(lib().alp_comm_allgatherv(array.ctypes.data_as(_c_void_p), out.ctypes.data_as(_c_void_p), counts))
+    return out
 
 
 def comm_destroy():

@@ -5,6 +5,8 @@
 #include <rccl/rccl.h>
 
 #include <cmath>
+#include <thread>
+#include <vector>
 
 namespace alp {
 
@@ -245,6 +247,72 @@ int alp_device_info(char *name, int len, int *cu_count, int64_t *hbm_bytes) {
     return ALP_OK;
 }
 
+// ------------------------------------------------------------------ content hash of a host array
+// Four independent lanes of the xxHash64 round (acc = rotl(acc + w * P2, 31) * P1: a bijection of acc for a fixed
+// word and of the word for a fixed acc, so a change of ONE 8-byte word always changes the digest; several changed
+// words collide with probability 2^-64), one contiguous slice per thread, slice digests chained in order.
+namespace {
+constexpr uint64_t HP1 = 0x9E3779B185EBCA87ull, HP2 = 0xC2B2AE3D27D4EB4Full, HP3 = 0x165667B19E3779F9ull;
+inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+inline uint64_t hround(uint64_t acc, uint64_t w) { return rotl64(acc + w * HP2, 31) * HP1; }
+inline uint64_t avalanche(uint64_t h) {
+    h ^= h >> 33; h *= HP2; h ^= h >> 29; h *= HP3; h ^= h >> 32;
+    return h;
+}
+uint64_t hash_slice(const unsigned char *p, size_t n, uint64_t seed) {
+    uint64_t a0 = seed + HP1 + HP2, a1 = seed + HP2, a2 = seed, a3 = seed - HP1;
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        uint64_t w[4];
+        memcpy(w, p + i, 32);
+        a0 = hround(a0, w[0]); a1 = hround(a1, w[1]); a2 = hround(a2, w[2]); a3 = hround(a3, w[3]);
+    }
+    uint64_t h = rotl64(a0, 1) + rotl64(a1, 7) + rotl64(a2, 12) + rotl64(a3, 18);
+    h = (h ^ hround(0, a0)) * HP1 + HP3; h = (h ^ hround(0, a1)) * HP1 + HP3;
+    h = (h ^ hround(0, a2)) * HP1 + HP3; h = (h ^ hround(0, a3)) * HP1 + HP3;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, p + i, 8);
+        h = rotl64(h ^ hround(0, w), 27) * HP1 + HP3;
+    }
+    for (; i < n; ++i) h = rotl64(h ^ (p[i] * HP3), 11) * HP1;
+    return avalanche(h + (uint64_t)n);
+}
+}  // namespace
+
+int alp_host_hash64(const void *buf, int64_t bytes, int threads, uint64_t *digest) {
+    ALP_REQUIRE(digest && bytes >= 0 && (bytes == 0 || buf), "bad argument");
+    const unsigned char *p = (const unsigned char *)buf;
+    int T = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    if (T < 1) T = 1;
+    if (T > 64) T = 64;
+    const int64_t SL = (int64_t)8 << 20;                        // fixed slices: the digest does not depend on the thread count
+    const int64_t ns = bytes > 0 ? (bytes + SL - 1) / SL : 1;
+    if ((int64_t)T > ns) T = (int)ns;
+    std::vector<uint64_t> part((size_t)ns);
+    auto run = [&](int t) {
+        for (int64_t s = t; s < ns; s += T) {
+            const int64_t lo = s * SL, hi = (lo + SL < bytes) ? lo + SL : bytes;
+            part[(size_t)s] = hash_slice(p + lo, (size_t)(hi > lo ? hi - lo : 0), (uint64_t)s);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(run, t);
+    run(0);
+    for (auto &x : th) x.join();
+    uint64_t h = HP3 ^ (uint64_t)bytes;
+    for (int64_t s = 0; s < ns; ++s) h = rotl64(h ^ hround(0, part[(size_t)s]), 27) * HP1 + HP3;
+    *digest = avalanche(h);
+    return ALP_OK;
+}
+
+int alp_device_pci_bus_id(char *id, int len) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(id && len >= 16, "id is NULL or shorter than 16 bytes");
+    ALP_HIP(hipDeviceGetPCIBusId(id, len, ctx().device));
+    return ALP_OK;
+}
+
 int alp_kernel_timing(int enable) {
     if (int rc = require_init()) return rc;
     ALP_HIP(hipStreamSynchronize(ctx().stream));
@@ -346,6 +414,64 @@ int alp_comm_bcast(void *buf, int64_t bytes, int root) {
     if (c.rank == root) ALP_HIP(hipMemcpyAsync(dev, buf, (size_t)bytes, hipMemcpyHostToDevice, c.stream));
     ALP_NCCL(ncclBroadcast(dev, dev, (size_t)bytes, ncclChar, root, (ncclComm_t)c.comm, c.stream));
     ALP_HIP(hipMemcpyAsync(buf, dev, (size_t)bytes, hipMemcpyDeviceToHost, c.stream));
+    ALP_HIP(hipStreamSynchronize(c.stream));
+    return ALP_OK;
+}
+
+// Every rank contributes `bytes` bytes (its own count); counts[world] receives all of them in rank order.
+int alp_comm_allgather_counts(int64_t bytes, int64_t *counts) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(bytes >= 0 && counts, "bad argument");
+    Context &c = ctx();
+    if (!c.comm) {
+        counts[0] = bytes;
+        return ALP_OK;
+    }
+    int64_t *dev = nullptr;
+    if (int rc = scratch_reserve((size_t)(c.world + 1) * sizeof(int64_t), (void **)&dev)) return rc;
+    ALP_HIP(hipMemcpyAsync(dev + c.world, &bytes, sizeof(int64_t), hipMemcpyHostToDevice, c.stream));
+    ALP_NCCL(ncclAllGather(dev + c.world, dev, 1, ncclInt64, (ncclComm_t)c.comm, c.stream));
+    ALP_HIP(hipMemcpyAsync(counts, dev, (size_t)c.world * sizeof(int64_t), hipMemcpyDeviceToHost, c.stream));
+    ALP_HIP(hipStreamSynchronize(c.stream));
+    return ALP_OK;
+}
+
+// recv receives rank 0's send buffer, then rank 1's, ...: counts[r] bytes each (as alp_comm_allgather_counts returned
+// them; counts[own rank] must be the size of `send`).  One ncclBroadcast per rank inside one group, staged through
+// the device scratch.
+int alp_comm_allgatherv(const void *send, void *recv, const int64_t *counts) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(recv && counts, "NULL argument");
+    Context &c = ctx();
+    int64_t total = 0;
+    for (int r = 0; r < c.world; ++r) {
+        ALP_REQUIRE(counts[r] >= 0, "negative count");
+        total += counts[r];
+    }
+    ALP_REQUIRE(counts[c.rank] == 0 || send, "send is NULL");
+    if (!c.comm) {
+        if (counts[0]) memcpy(recv, send, (size_t)counts[0]);
+        return ALP_OK;
+    }
+    if (total == 0) return ALP_OK;
+    char *dev = nullptr;
+    if (int rc = scratch_reserve((size_t)total, (void **)&dev)) return rc;
+    int64_t off = 0, mine = 0;
+    for (int r = 0; r < c.rank; ++r) mine += counts[r];
+    if (counts[c.rank]) ALP_HIP(hipMemcpyAsync(dev + mine, send, (size_t)counts[c.rank], hipMemcpyHostToDevice, c.stream));
+    ALP_NCCL(ncclGroupStart());
+    for (int r = 0; r < c.world; ++r) {
+        if (counts[r]) {
+            ncclResult_t e = ncclBroadcast(dev + off, dev + off, (size_t)counts[r], ncclChar, r, (ncclComm_t)c.comm, c.stream);
+            if (e != ncclSuccess) {
+                ncclGroupEnd();
+                return fail(ALP_ERCCL, "ncclBroadcast failed: %s", ncclGetErrorString(e));
+            }
+        }
+        off += counts[r];
+    }
+    ALP_NCCL(ncclGroupEnd());
+    ALP_HIP(hipMemcpyAsync(recv, dev, (size_t)total, hipMemcpyDeviceToHost, c.stream));
     ALP_HIP(hipStreamSynchronize(c.stream));
     return ALP_OK;
 }

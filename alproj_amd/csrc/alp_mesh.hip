@@ -97,8 +97,15 @@ int alp_mesh_set_value(alp_mesh_t *m, const void *value, int value_dtype) {
         return ALP_OK;
     }
     ALP_REQUIRE(value_dtype == ALP_F32 || value_dtype == ALP_F64, "value_dtype must be ALP_F32 or ALP_F64");
-    if (!m->value) ALP_HIP(hipMalloc((void **)&m->value, (size_t)m->n_vert * 12));
-    return upload_f32(m->value, value, value_dtype, m->n_vert);    // stream-ordered behind any resolve in flight
+    const bool fresh = !m->value;
+    if (fresh) ALP_HIP(hipMalloc((void **)&m->value, (size_t)m->n_vert * 12));
+    const int rc = upload_f32(m->value, value, value_dtype, m->n_vert);    // stream-ordered behind any resolve in flight
+    if (rc && fresh) {               // never leave an allocated, unwritten value buffer behind: it would render as colours
+        hipStreamSynchronize(ctx().stream);
+        hipFree(m->value);
+        m->value = nullptr;
+    }
+    return rc;
 }
 
 int alp_mesh_frame_counts(alp_mesh_t *m, int64_t counts[2]) {

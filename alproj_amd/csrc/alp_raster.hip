@@ -892,6 +892,8 @@ int alp_mesh_destroy(alp_mesh_t *m) {
                     (void *)m->rz_points, (void *)m->rz_work})
         if (p) hipFree(p);
     if (m->qcount_host) hipHostFree(m->qcount_host);
+    for (auto &e : m->ev_frame)
+        if (e) hipEventDestroy(e);
     delete m;
     return ALP_OK;
 }
@@ -908,7 +910,43 @@ int alp_render_enqueue(alp_mesh_t *m, const double params[ALP_NPARAM], const dou
     // same view as the frame whose visibility buffer is still there: the raster passes would rebuild it bit for bit
     const bool no_cache = getenv("ALP_NO_VIS_CACHE") != nullptr;      // tests, benchmarks: force the full frame
     const bool cached = m->vis_current && !no_cache && same_view(v, m->last_v);
-    return m->implicit ? render_impl<true>(m, v, rc, min_distance, cached) : render_impl<false>(m, v, rc, min_distance, cached);
+    if (!m->ev_frame[0]) {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+            if (a) hipEventDestroy(a);
+            return fail(ALP_EHIP, "hipEventCreate failed");
+        }
+        m->ev_frame[0] = a;
+        m->ev_frame[1] = b;
+    }
+    ALP_HIP(hipEventRecord(m->ev_frame[0], ctx().stream));
+    const int e = m->implicit ? render_impl<true>(m, v, rc, min_distance, cached) : render_impl<false>(m, v, rc, min_distance, cached);
+    if (e) return e;
+    ALP_HIP(hipEventRecord(m->ev_frame[1], ctx().stream));
+    return ALP_OK;
+}
+
+int alp_mesh_frame_ms(alp_mesh_t *m, float *ms) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(m && ms, "NULL argument");
+    if (!m->rendered || !m->ev_frame[1]) return fail(ALP_ESTATE, "alp_mesh_frame_ms: nothing rendered yet");
+    ALP_HIP(hipEventSynchronize(m->ev_frame[1]));
+    ALP_HIP(hipEventElapsedTime(ms, m->ev_frame[0], m->ev_frame[1]));
+    return ALP_OK;
+}
+
+int alp_mesh_trim(alp_mesh_t *m) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(m, "mesh handle is NULL");
+    ALP_HIP(hipStreamSynchronize(ctx().stream));
+    if (m->rz_work) hipFree(m->rz_work);
+    m->rz_work = nullptr;
+    m->rz_work_cap = 0;
+    if (m->rz_points) hipFree(m->rz_points);
+    m->rz_points = nullptr;
+    m->rz_cap = 0;
+    m->rz_n = -1;
+    return ALP_OK;
 }
 
 int alp_render_fetch(alp_mesh_t *m, float *out) {

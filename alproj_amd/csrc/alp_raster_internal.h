@@ -99,6 +99,8 @@ struct alp_mesh {
     // 5.3 GB for the 100 M-vertex frame at 1 m; allocating and freeing it per call cost 2 ms, and now and then 0.25-0.4 s
     char *rz_work = nullptr;
     size_t rz_work_cap = 0;
+    // HIP events around the launches of the last alp_render_enqueue (alp_mesh_frame_ms); created on first use
+    hipEvent_t ev_frame[2] = {nullptr, nullptr};
 };
 
 namespace alp {

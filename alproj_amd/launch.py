@@ -1,0 +1,310 @@
+"""Torch-free launcher and control plane for one-process-per-GPU jobs on one node.
+
+The data path of a multi-GPU job has exactly one collective -- the RCCL all-reduce of the P + 1 partial
+sums inside libalproj_hip.so (the loop it shards is reference optimize.py:418-424).
+Everything else a job needs between its ranks is control traffic: the 128-byte RCCL unique id from rank 0
+to the others, barriers around timed regions, a max over the ranks' wall times, a few gathered records.
+This module carries that over a localhost socket (``multiprocessing.connection``: stdlib, authenticated),
+so that neither the product nor ``bench.py`` needs ``torch.distributed``:
+
+* ``spawn(argv, n)``   -- the PARENT: starts ``n`` fresh children of ``argv`` with ``RANK`` / ``LOCAL_RANK`` /
+  ``WORLD_SIZE`` set, serves the hub, ends the others when one child fails, enforces one wall-clock limit.
+  The parent never touches the GPU and never ``exec``s: children are ``subprocess.Popen``-ed before any HIP call.
+* ``Control.from_env()`` -- a RANK: connects to the parent's hub (``ALPROJ_HUB``), or, when another launcher
+  (``torch.distributed.run``) set ``WORLD_SIZE``, to a hub that rank 0 hosts and announces through a file
+  keyed by ``MASTER_ADDR`` / ``MASTER_PORT`` / the launcher's run id.
+
+A collective is one message per rank to the hub and one reply per rank: barrier, max, bcast (rank 0's
+payload), gather (every rank's payload, in rank order).  A rank that dies closes its socket; the hub then
+answers every other rank with an error, so nobody waits for a barrier that cannot complete.
+"""
+import hashlib
+import os
+import signal
+import subprocess
+import sys
+import tempfile
+import threading
+import time
+from multiprocessing.connection import Client, Listener
+
+__all__ = ["Hub", "Control", "spawn", "LaunchError"]
+
+HUB_ENV, KEY_ENV = "ALPROJ_HUB", "ALPROJ_HUB_KEY"
+COLLECTIVE_TIMEOUT_S = 3600.0
+
+
+class LaunchError(RuntimeError):
+    pass
+
+
+class Hub:
+    """The meeting point of ``world`` ranks: accepts one connection per rank, then serves collectives until
+    every rank has said goodbye (or one has gone away)."""
+
+    def __init__(self, world, authkey=None, host="127.0.0.1"):
+        self.world = int(world)
+        self.authkey = authkey or os.urandom(16)
+        self.listener = Listener((host, 0), authkey=self.authkey)
+        self.address = self.listener.address          # (host, port) actually bound
+        self.error = None
+        self.collectives = 0
+        self._thread = None
+
+    def start(self):
+        self._thread = threading.Thread(target=self._serve, name="alproj-hub", daemon=True)
+        self._thread.start()
+        return self
+
+    def join(self, timeout=None):
+        if self._thread:
+            self._thread.join(timeout)
+
+    def close(self):
+        try:
+            self.listener.close()
+        except OSError:
+            pass
+
+    def _serve(self):
+        conns = [None] * self.world
+        try:
+            # the listening socket gets a timeout so that a rank which never starts does not park the hub for ever
+            self.listener._listener._socket.settimeout(COLLECTIVE_TIMEOUT_S)
+            for _ in range(self.world):
+                c = self.listener.accept()
+                op, rank = c.recv()
+                if op != "hello" or not (0 <= rank < self.world) or conns[rank] is not None:
+                    raise LaunchError(f"unexpected greeting {op!r} from rank {rank!r}")
+                conns[rank] = c
+            for c in conns:
+                c.send(("ok", self.world))
+            alive = self.world
+            while alive:
+                msgs = []
+                for r, c in enumerate(conns):
+                    if not c.poll(COLLECTIVE_TIMEOUT_S):
+                        raise LaunchError(f"rank {r} did not reach collective {self.collectives} within {COLLECTIVE_TIMEOUT_S:.0f} s")
+                    msgs.append(c.recv())              # EOFError when the rank has gone away
+                ops = {m[0] for m in msgs}
+                if len(ops) != 1:
+                    raise LaunchError(f"ranks disagree on collective {self.collectives}: {sorted(ops)}")
+                op = ops.pop()
+                payloads = [m[1] for m in msgs]
+                if op == "barrier":
+                    out = [None] * self.world
+                elif op == "max":
+                    out = [max(payloads)] * self.world
+                elif op == "bcast":
+                    out = [payloads[0]] * self.world
+                elif op == "gather":
+                    out = [payloads] * self.world
+                elif op == "bye":
+                    out = [None] * self.world
+                    alive = 0
+                else:
+                    raise LaunchError(f"unknown collective {op!r}")
+                for c, o in zip(conns, out):
+                    c.send(("ok", o))
+                self.collectives += 1
+        except (EOFError, OSError, LaunchError) as e:
+            self.error = f"{type(e).__name__}: {e}" if str(e) else f"{type(e).__name__}: a rank closed its connection"
+            for c in conns:
+                if c is not None:
+                    try:
+                        c.send(("error", self.error))
+                    except (OSError, ValueError):
+                        pass
+        finally:
+            for c in conns:
+                if c is not None:
+                    try:
+                        c.close()
+                    except OSError:
+                        pass
+            self.close()
+
+
+def _rendezvous_file():
+    """Where rank 0 announces its hub when a foreign launcher started the ranks: one name per job on this node."""
+    tag = "|".join(os.environ.get(k, "") for k in ("MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "GROUP_RANK"))
+    h = hashlib.sha256(tag.encode()).hexdigest()[:20]
+    return os.path.join(tempfile.gettempdir(), f"alproj_hub_{os.getuid()}_{h}"), hashlib.sha256(("key|" + tag).encode()).digest()[:16]
+
+
+class Control:
+    """A rank's end of the control plane.  ``world == 1`` needs no hub: every collective is the identity."""
+
+    def __init__(self, rank=0, world=1, local_rank=0, conn=None, hub=None, announce=None):
+        self.rank, self.world, self.local_rank = int(rank), int(world), int(local_rank)
+        self._conn, self._hub, self._announce = conn, hub, announce
+
+    @classmethod
+    def from_env(cls, connect_timeout_s=300.0):
+        rank = int(os.environ.get("RANK", "0"))
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+        if world <= 1:
+            return cls(0, 1, local_rank)
+        hub = announce = None
+        if HUB_ENV in os.environ:                       # started by spawn(): the parent serves the hub
+            host, port = os.environ[HUB_ENV].rsplit(":", 1)
+            address, key = (host, int(port)), bytes.fromhex(os.environ[KEY_ENV])
+            conn = cls._connect(lambda: (address, key), rank, connect_timeout_s)
+        else:                                           # started by torch.distributed.run or the like
+            path, key = _rendezvous_file()
+            if rank == 0:
+                hub = Hub(world, authkey=key).start()
+                tmp = f"{path}.tmp.{os.getpid()}"
+                with open(tmp, "w") as f:
+                    f.write(f"{hub.address[0]}:{hub.address[1]}")
+                os.replace(tmp, path)
+                announce = path
+
+            def where():
+                with open(path) as f:                   # FileNotFoundError until rank 0 has written it
+                    host, port = f.read().strip().rsplit(":", 1)
+                return (host, int(port)), key
+            conn = cls._connect(where, rank, connect_timeout_s)
+        return cls(rank, world, local_rank, conn, hub, announce)
+
+    @staticmethod
+    def _connect(where, rank, timeout_s):
+        """A stale announcement (an earlier job with the same MASTER_PORT) points at a closed port or at somebody who
+        fails the key handshake: both are retried until rank 0's new announcement is there."""
+        t0 = time.time()
+        last = None
+        while time.time() - t0 < timeout_s:
+            try:
+                address, key = where()
+                conn = Client(address, authkey=key)
+                conn.send(("hello", rank))
+                status, _ = conn.recv()
+                if status == "ok":
+                    return conn
+                last = LaunchError("hub refused the greeting")
+            except (OSError, EOFError, ValueError, Exception) as e:      # noqa: B014 -- AuthenticationError is a ProcessError
+                last = e
+            time.sleep(0.05)
+        raise LaunchError(f"rank {rank}: no hub after {timeout_s:.0f} s ({last})")
+
+    def _collective(self, op, payload=None):
+        if self.world <= 1:
+            return {"barrier": None, "max": payload, "bcast": payload, "gather": [payload], "bye": None}[op]
+        try:
+            self._conn.send((op, payload))
+            status, out = self._conn.recv()
+        except (EOFError, OSError) as e:
+            raise LaunchError(f"rank {self.rank}: the hub went away during {op} ({type(e).__name__})") from e
+        if status != "ok":
+            raise LaunchError(f"rank {self.rank}: {op} failed: {out}")
+        return out
+
+    def barrier(self):
+        self._collective("barrier")
+
+    def max(self, x):
+        return self._collective("max", float(x))
+
+    def bcast_bytes(self, b):
+        return self._collective("bcast", bytes(b))
+
+    def bcast(self, obj):
+        return self._collective("bcast", obj)
+
+    def gather(self, obj):
+        return self._collective("gather", obj)
+
+    def close(self):
+        if self.world > 1 and self._conn is not None:
+            try:
+                self._collective("bye")
+            finally:
+                self._conn.close()
+                self._conn = None
+        if self._hub is not None:
+            self._hub.join(5.0)
+            self._hub = None
+        if self._announce:
+            try:
+                os.unlink(self._announce)
+            except OSError:
+                pass
+            self._announce = None
+
+
+def _die_with_parent():
+    """preexec of a child: SIGTERM when the parent goes away (Linux PR_SET_PDEATHSIG), so that no rank outlives a
+    killed launcher and keeps a GPU busy"""
+    try:
+        import ctypes
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM)
+    except Exception:
+        pass
+
+
+def _stop(procs, grace_s=5.0):
+    """End exactly the processes this launcher started (by PID, never by pattern)."""
+    for p in procs:
+        if p.poll() is None:
+            try:
+                p.terminate()
+            except OSError:
+                pass
+    t0 = time.time()
+    while time.time() - t0 < grace_s and any(p.poll() is None for p in procs):
+        time.sleep(0.05)
+    for p in procs:
+        if p.poll() is None:
+            try:
+                p.kill()
+            except OSError:
+                pass
+    for p in procs:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            pass
+
+
+def spawn(argv, n, timeout_s=3600.0, env=None, log=sys.stderr):
+    """Run ``n`` ranks of ``argv`` and return the job's exit code: 0 when every rank returned 0; the first failing
+    rank's code (the others are ended) otherwise; 124 when ``timeout_s`` of wall clock ran out.
+
+    Rank r gets ``RANK=r LOCAL_RANK=r WORLD_SIZE=n`` and the hub's address; rank 0 inherits stdout (the ONE JSON
+    line), every rank inherits stderr."""
+    n = int(n)
+    if n < 1:
+        raise ValueError("need at least one rank")
+    hub = Hub(n)
+    base = dict(os.environ if env is None else env)
+    base.update({"WORLD_SIZE": str(n), HUB_ENV: f"{hub.address[0]}:{hub.address[1]}", KEY_ENV: hub.authkey.hex(),
+                 "HSA_ENABLE_IPC_MODE_LEGACY": base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})    # dmabuf IPC: RCCL needs it on this driver
+    procs = []
+    try:
+        for r in range(n):       # children first, hub thread afterwards: no fork out of a threaded parent
+            e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen(list(argv), env=e, stdout=None if r == 0 else subprocess.DEVNULL,
+                                          preexec_fn=_die_with_parent))
+        hub.start()
+        t0 = time.time()
+        rc = None
+        while rc is None:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                r, c = bad[0]
+                print(f"launch: rank {r} (pid {procs[r].pid}) exited with {c}; ending the other ranks", file=log, flush=True)
+                rc = c if c > 0 else 128 - c            # a signal's negative code as the shell would show it
+            elif all(c == 0 for c in codes):
+                rc = 0
+            elif time.time() - t0 > timeout_s:
+                print(f"launch: {timeout_s:.0f} s of wall clock are over; ending all ranks", file=log, flush=True)
+                rc = 124
+            else:
+                time.sleep(0.05)
+        return rc
+    finally:
+        _stop(procs)
+        hub.close()
+        hub.join(2.0)

@@ -275,13 +275,20 @@ class CMAOptimizer(BaseOptimizer):
 
 class LsqOptimizer(BaseOptimizer):
     """scipy.optimize.least_squares driver (reference optimize.py:442-539); the residual
-    vector of every trial point comes from ``alp_residuals`` on a float64 point set."""
+    vector of every trial point comes from ``alp_residuals`` on a float64 point set.
+
+    Several ranks (points sharded, one process per GPU): the reference solves ONE problem over all points
+    (optimize.py:510-528), so every rank all-gathers the residual vector -- and the rows of the batched Jacobian -- of
+    all shards, in rank order (``alp_comm_allgatherv``): contiguous shards concatenate to the single-process vector,
+    every rank runs the identical scipy solve on it and gets the identical optimum."""
 
     def _residual_function(self):
         pts = self._device_points("f64")
+        _, world = _lib.comm_info()
 
         def _residuals(values):
-            return pts.residuals(self._candidate_matrix(values)[0])
+            r = pts.residuals(self._candidate_matrix(values)[0])
+            return _lib.comm_allgather(r) if world > 1 else r
 
         _residuals.points = pts
         return _residuals
@@ -291,6 +298,7 @@ class LsqOptimizer(BaseOptimizer):
         sqrt(eps), sign-aware, flipped or shrunk at the bounds), but all D+1 residual vectors
         come from ONE ``alp_residuals_batch`` launch instead of D+1 sequential calls."""
         eps = np.finfo(np.float64).eps ** 0.5
+        _, world = _lib.comm_info()
         lb = np.full(len(self.target_params), -np.inf) if bounds is None else np.asarray(bounds[0], dtype=np.float64)
         ub = np.full(len(self.target_params), np.inf) if bounds is None else np.asarray(bounds[1], dtype=np.float64)
 
@@ -309,7 +317,8 @@ class LsqOptimizer(BaseOptimizer):
             trial[np.arange(1, d + 1), np.arange(d)] += h
             dx = trial[np.arange(1, d + 1), np.arange(d)] - x0          # the representable step
             res = pts.residuals_batch(self._candidate_matrix(trial))
-            return ((res[1:] - res[0]) / dx[:, None]).T
+            jac = ((res[1:] - res[0]) / dx[:, None]).T               # (2 n_local, D): this rank's rows
+            return _lib.comm_allgather(np.ascontiguousarray(jac)) if world > 1 else jac
 
         return _jac
 
@@ -334,9 +343,9 @@ class LsqOptimizer(BaseOptimizer):
                 result = least_squares(residual_func, self.target_params_init, method=method,
                                        bounds=(bounds[:, 0], bounds[:, 1]), loss=loss,
                                        f_scale=f_scale, **kwargs)
-            # Least squares does not shard (scipy drives ONE residual vector): with a communicator every rank has
-            # solved its own points, and the final error below is a collective over all of them -- which must be
-            # evaluated for ONE solution: rank 0's is broadcast and is the result on every rank.
+            # With a communicator every rank has solved the SAME gathered problem; the final error below is a collective
+            # over the shards and must be evaluated for one solution on all of them: rank 0's is broadcast (bit-identical
+            # to the others' on identical hosts; the broadcast makes it so on any).
             best = np.ascontiguousarray(result.x, dtype=np.float64)
             _, world = _lib.comm_info()
             if world > 1:

@@ -24,49 +24,74 @@ project.py:210-215).
 
 The reference's call pattern -- ``sim_image(vert, col, ind, params, offsets)`` followed by
 ``reverse_proj(img, vert, ind, params, offsets)`` with the SAME arrays (example.py:28,31; :57,59;
-:97,103) -- is served without a second upload: the last mesh stays on the device, keyed by the
-identity of the ``vert`` / ``ind`` arrays plus a content fingerprint (every 1024th row, head and
-tail), and a call that finds it re-renders it; at an unchanged pose only the resolve stage runs
-(the library's visibility cache).  ``MESH_CACHE = False`` (or ``clear_mesh_cache()``) switches it
-off; an in-place edit of a few vertices between two calls is the one thing the fingerprint can
-miss -- call ``clear_mesh_cache()`` after such an edit.
+:97,103) -- uploads the mesh on every call, like the reference does (project.py:213-215).  That is the
+default here too, because it is the only behaviour that can never show a stale mesh.  Two ways to keep the
+mesh on the device between calls:
+
+* pass a ``Mesh`` (or use ``reverse_proj_device``): the explicit device handle, nothing is compared;
+* ``set_mesh_cache(True)``: the last mesh stays resident and a call with the same array OBJECTS re-renders
+  it -- after the cache has made sure their CONTENT is unchanged: arrays that are read-only all the way
+  down (``a.setflags(write=False)``, no writeable base) are taken by identity; writeable arrays by a
+  64-bit digest of every byte (``alp_host_hash64``, all host cores), taken at upload time and again at
+  lookup.  An in-place edit of a single vertex between two calls is therefore always seen.  The digest
+  costs about what reading the arrays from host memory costs (``bench.py``: ``dropin_call.verify``): it pays
+  for writeable arrays only where PCIe is slower than the host's memory, for read-only arrays always.
+
+At an unchanged pose only the resolve stage runs (the library's visibility cache).
 """
 import math
 import time
 import warnings
 import weakref
-import zlib
 
 import numpy as np
 import pandas as pd
 
 from . import _lib
 
-MESH_CACHE = True
+_MESH_CACHE = False
 _cache = {"mesh": None, "vert": None, "ind": None, "value": None, "grid": None}
+LAST_CACHE = {}          # what the last lookup did: hit / miss, seconds spent verifying content
 
 
-def _fingerprint(a):
-    """identity-independent part of a cache key: layout + CRC of every 1024th row, the first and the last 64 rows"""
-    a = np.asarray(a)
-    if a.size == 0:
-        return (a.shape, a.dtype.str, a.strides, 0, 0)
-    rows = a.reshape(a.shape[0], -1) if a.ndim > 1 else a.reshape(-1, 1)
-    parts = (rows[::1024], rows[:64], rows[-64:])
-    crc = 0
-    for part in parts:
-        crc = zlib.crc32(np.ascontiguousarray(part).view(np.uint8).reshape(-1), crc)
-    return (a.shape, a.dtype.str, a.strides, a.__array_interface__["data"][0], crc)
+def set_mesh_cache(enabled):
+    """Keep the last uploaded mesh on the device for the next call with the same arrays (verified by content, see the
+    module docstring).  Off by default: the reference uploads on every call."""
+    global _MESH_CACHE
+    _MESH_CACHE = bool(enabled)
+    if not _MESH_CACHE:
+        clear_mesh_cache()
+
+
+def mesh_cache_enabled():
+    return _MESH_CACHE
+
+
+def _immutable(a):
+    """True when nobody can write the array's memory through numpy: read-only, and so is every base it views"""
+    while a is not None:
+        if not isinstance(a, np.ndarray) or a.flags.writeable:
+            return False
+        a = a.base
+    return True
 
 
 def _key(a):
-    return None if a is None else (weakref.ref(a), _fingerprint(a))
+    """(weak reference, layout, content digest or None for an immutable array)"""
+    if a is None:
+        return None
+    layout = (a.shape, a.dtype.str, a.strides, a.__array_interface__["data"][0])
+    return (weakref.ref(a), layout, None if _immutable(a) else _lib.host_hash64(np.ascontiguousarray(a)))
 
 
 def _same(key, a):
     if key is None or a is None:
         return key is None and a is None
-    return key[0]() is a and key[1] == _fingerprint(a)
+    if key[0]() is not a or key[1] != (a.shape, a.dtype.str, a.strides, a.__array_interface__["data"][0]):
+        return False
+    if key[2] is None:                # it was immutable when it was uploaded: it still has to be
+        return _immutable(a)
+    return key[2] == _lib.host_hash64(np.ascontiguousarray(a))
 
 
 def clear_mesh_cache():
@@ -75,28 +100,46 @@ def clear_mesh_cache():
     _cache.update(mesh=None, vert=None, ind=None, value=None, grid=None)
 
 
+def _new_mesh(vert, value, ind, grid_shape):
+    try:
+        return _lib.Mesh(vert, value, ind, grid_shape)
+    except _lib.AlprojHipError:
+        if _cache["mesh"] is None:
+            raise
+        clear_mesh_cache()                              # the resident mesh and its work areas may be what is in the way
+        return _lib.Mesh(vert, value, ind, grid_shape)
+
+
 def _resident_mesh(vert, value, ind, grid_shape):
     """-> (mesh, owned): the device mesh of these arrays, from the cache when the same arrays were rendered last.
     ``value`` None = the vertices themselves.  ``owned`` meshes are the caller's to close."""
-    cacheable = MESH_CACHE and isinstance(vert, np.ndarray) and (ind is None or isinstance(ind, np.ndarray))
+    cacheable = _MESH_CACHE and isinstance(vert, np.ndarray) and (ind is None or isinstance(ind, np.ndarray))
+    LAST_CACHE.clear()
     if not cacheable:
-        return _lib.Mesh(vert, value, ind, grid_shape), True
+        return _new_mesh(vert, value, ind, grid_shape), True
     c = _cache
-    if c["mesh"] is not None and c["mesh"]._h and _same(c["vert"], vert) and _same(c["ind"], ind) and c["grid"] == grid_shape:
+    t0 = time.perf_counter()
+    if c["mesh"] is not None and c["mesh"]._h and c["grid"] == grid_shape and _same(c["vert"], vert) and _same(c["ind"], ind):
         mesh = c["mesh"]
         if value is not None and not _same(c["value"], value):
+            c["value"] = None
             mesh.set_value(value)                       # sim_image after reverse_proj: only the colours travel
             c["value"] = _key(value) if isinstance(value, np.ndarray) else None
+        LAST_CACHE.update(hit=True, verify_s=time.perf_counter() - t0)
         return mesh, False
     clear_mesh_cache()                                  # before the new upload: both would not have to fit
+    t1 = time.perf_counter()
+    keys = dict(vert=_key(vert), ind=_key(ind), value=_key(value) if isinstance(value, np.ndarray) else None)
+    t2 = time.perf_counter()
     mesh = _lib.Mesh(vert, value, ind, grid_shape)
-    c.update(mesh=mesh, vert=_key(vert), ind=_key(ind), grid=grid_shape,
-             value=_key(value) if isinstance(value, np.ndarray) else None)
+    c.update(mesh=mesh, grid=grid_shape, **keys)
+    LAST_CACHE.update(hit=False, verify_s=t1 - t0, digest_s=t2 - t1)
     return mesh, False
+
 
 __all__ = ["projection_mat", "modelview_mat", "distort", "persp_proj", "sim_image",
            "reverse_proj", "reverse_proj_device", "ReverseProjection", "rasterize", "to_geotiff", "Mesh",
-           "clear_mesh_cache", "MESH_CACHE"]
+           "clear_mesh_cache", "set_mesh_cache", "mesh_cache_enabled", "set_timing"]
 
 Mesh = _lib.Mesh
 
@@ -169,8 +212,16 @@ def persp_proj(vert, value, ind, params, offsets=None, min_distance=None, *, gri
 
 # where the last call spent its time (seconds on the host; `device_ms` = HIP events around the frame's launches):
 # `mesh_s` cache lookup or upload, `enqueue_s` launches, `fetch_s` wait + copy back, `frame_s` DataFrame construction
+# Filled only after set_timing(True) (benchmarks, probes): reading `device_ms` waits for the frame.
 LAST_TIMING = {}
-_EV0, _EV1 = 60, 61              # event slots of the library reserved for these wrappers
+_TIMING = False
+
+
+def set_timing(enabled):
+    """Record where each wrapper call spends its time into LAST_TIMING (off by default: no extra calls, no waits)."""
+    global _TIMING
+    _TIMING = bool(enabled)
+    LAST_TIMING.clear()
 
 
 def _enqueue(vert, value, ind, params, offsets, min_distance, grid_shape, coords=None):
@@ -182,19 +233,24 @@ def _enqueue(vert, value, ind, params, offsets, min_distance, grid_shape, coords
     else:
         same = value is vert or value is None
         mesh, owned = _resident_mesh(vert, None if same else value, ind, grid_shape)
+    if not _TIMING:
+        mesh.render_enqueue(pvec, offsets, min_distance, coords=same)
+        return mesh, owned
     t1 = time.perf_counter()
     before = mesh.frame_counts()
-    _lib.event_record(_EV0)
     mesh.render_enqueue(pvec, offsets, min_distance, coords=same)
-    _lib.event_record(_EV1)
     LAST_TIMING.clear()
     LAST_TIMING.update(mesh_s=t1 - t0, enqueue_s=time.perf_counter() - t1, resident=not owned and before != (0, 0),
-                       resolve_only=mesh.frame_counts()[1] > before[1])
+                       resolve_only=mesh.frame_counts()[1] > before[1], cache=dict(LAST_CACHE), _mesh=weakref.ref(mesh))
     return mesh, owned
 
 
-def _fetched(t0):
-    LAST_TIMING.update(fetch_s=time.perf_counter() - t0, device_ms=_lib.event_elapsed_ms(_EV0, _EV1))
+def _fetched(t0, mesh=None):
+    if _TIMING:
+        m = LAST_TIMING.pop("_mesh", lambda: None)()
+        LAST_TIMING.update(fetch_s=time.perf_counter() - t0)
+        if m is not None and m._h:
+            LAST_TIMING["device_ms"] = m.frame_ms()
 
 
 def sim_image(vert, color, ind, params, offsets=None, min_distance=None, *, grid_shape=None):
@@ -279,9 +335,10 @@ class ReverseProjection:
         df.insert(1, "v", v_pix)
         # the reference filters a RangeIndex-ed frame, so the labels are the linear pixel indices
         df.index = pd.Index(labels)
-        LAST_TIMING.update(fetch_s=t1 - t0, frame_s=time.perf_counter() - t1)
-        if "enqueue_s" in LAST_TIMING and "device_ms" not in LAST_TIMING:      # this call's own frame (reverse_proj)
-            LAST_TIMING["device_ms"] = _lib.event_elapsed_ms(_EV0, _EV1)
+        if _TIMING:
+            LAST_TIMING.update(fetch_s=t1 - t0, frame_s=time.perf_counter() - t1)
+            if LAST_TIMING.pop("_mesh", None) is not None and hasattr(mesh, "frame_ms"):      # this call's own frame (reverse_proj)
+                LAST_TIMING["device_ms"] = mesh.frame_ms()
         return df
 
     def rasterize(self, array, chnames=["B", "G", "R"], resolution=1.0, bands=["R", "G", "B"], interpolate=True,

@@ -1,9 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the alproj camera-projection hot path on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            # N = 1, 2, 4, 8: starts its own N ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W          # ... or takes the ranks a launcher started
+
+With --gpus N > 1 and no WORLD_SIZE in the environment the process is the LAUNCHER (alproj_amd/launch.py): it
+never touches the GPU, starts N fresh children of this script (RANK / LOCAL_RANK / WORLD_SIZE set, no exec),
+serves their control plane (barrier, max, the 128-byte RCCL id) on a localhost socket, ends the others when one
+rank fails, and exits with the job's code.  No torch anywhere: the one collective of the data path is the RCCL
+all-reduce inside libalproj_hip.so.  `--launch-selftest` runs the same launch with a stub worker (no GPU).
 
 Workload (BASELINE.json metric: "Gpoints/s projected + CMA-ES iters/s, 100M-vertex DSM,
 1/2/4/8 MI355X"): the 100 M-vertex synthetic DSM of SURVEY.md 8(d), resident in HBM as
@@ -53,7 +59,8 @@ def parse():
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--pop", type=int, default=2048)
     ap.add_argument("--dims", type=int, default=21, choices=[9, 21])
-    ap.add_argument("--cma-steps", type=int, default=None, help="generations timed (default min(steps, 10))")
+    ap.add_argument("--cma-steps", type=int, default=50, help="generations timed at pop 2048 / D 21 (SURVEY 8(d) c5: 50, whatever --steps is)")
+    ap.add_argument("--c3-steps", type=int, default=100, help="generations timed at 10 M x pop 256 (SURVEY 8(d) c3: 100)")
     ap.add_argument("--no-cma", action="store_true")
     ap.add_argument("--no-raster", action="store_true")
     ap.add_argument("--no-raster-explicit", action="store_true", help="skip the int32 index-array mesh (2.4 GB of indices)")
@@ -62,56 +69,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the reference-typed sim_image + reverse_proj call pair (9.6 GB of host arrays)")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the SURVEY 8(f) rows f1-f4 and the full-size pipeline")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0, help="wall-clock limit of a self-launched multi-rank job (s)")
+    ap.add_argument("--launch-selftest", action="store_true", help="run the launch / control plane with a stub worker (no GPU, no library)")
+    ap.add_argument("--selftest-fail-rank", type=int, default=-1, help="selftest: this rank exits with code 7 after the first barrier")
+    ap.add_argument("--selftest-hang-rank", type=int, default=-1, help="selftest: this rank never reaches the second barrier")
     return ap.parse_args()
-
-
-class Control:
-    """Control plane: barrier / max-reduce / byte broadcast across the ranks torchrun started.
-    torch.distributed (gloo) is plumbing only; the data path's one collective is the RCCL
-    all-reduce inside libalproj_hip.so."""
-
-    def __init__(self):
-        self.rank = int(os.environ.get("RANK", "0"))
-        self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        self.dist = None
-        self.torch = None
-        if self.world > 1:
-            import torch
-            import torch.distributed as dist
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
-            self.dist, self.torch = dist, torch
-            if torch.cuda.is_available():
-                torch.cuda.set_device(self.local_rank)
-
-    def barrier(self):
-        if self.dist:
-            self.dist.barrier()
-
-    def device_sync(self, L):
-        L.synchronize()
-        if self.torch is not None and self.torch.cuda.is_available():
-            self.torch.cuda.synchronize()
-
-    def max(self, x):
-        if not self.dist:
-            return x
-        t = self.torch.tensor([x], dtype=self.torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t[0])
-
-    def bcast_bytes(self, b):
-        if not self.dist:
-            return b
-        t = self.torch.tensor(list(b), dtype=self.torch.uint8)
-        self.dist.broadcast(t, src=0)
-        return bytes(t.tolist())
-
-    def close(self):
-        if self.dist:
-            self.dist.barrier()
-            self.dist.destroy_process_group()
 
 
 def timed(ctl, L, fn, steps, warmup):
@@ -119,34 +81,121 @@ def timed(ctl, L, fn, steps, warmup):
     Returns (wall seconds, max over ranks; device ms between HIP events on the library stream)."""
     for _ in range(warmup):
         fn()
-    ctl.device_sync(L)
+    L.synchronize()
     ctl.barrier()
     t0 = time.perf_counter()
     L.event_record(0)
     for _ in range(steps):
         fn()
     L.event_record(1)
-    ctl.device_sync(L)
+    L.synchronize()
     t1 = time.perf_counter()           # this rank's K steps are complete on its GPU
     ctl.barrier()
     dev_ms = L.event_elapsed_ms(0, 1)
     return ctl.max(t1 - t0), dev_ms    # MAX over ranks
 
 
-def cpu_baseline(orc, truth, xyz_sample, obs_sample):
-    """numpy float64 port of the reference path on the host cores (oracle = checker only)."""
-    xyz = xyz_sample.astype(np.float64)
-    best_p, best_l = 1e30, 1e30
-    for i in range(3):
-        t = time.perf_counter()
-        uv = orc.project_points(xyz, truth)
-        t1 = time.perf_counter()
-        orc.huber(obs_sample, uv, 10.0)
-        t2 = time.perf_counter()
-        if i:
-            best_p = min(best_p, t1 - t)
-            best_l = min(best_l, t2 - t)
-    return best_p, best_l
+def launch_times(L, fn, launches=24):
+    """device ms of `launches` single calls, one HIP-event pair each on the library stream (slots 2 ... 2 + launches)"""
+    launches = min(launches, 50)
+    L.synchronize()
+    L.event_record(2)
+    for i in range(launches):
+        fn()
+        L.event_record(3 + i)
+    L.synchronize()
+    return np.array([L.event_elapsed_ms(2 + i, 3 + i) for i in range(launches)])
+
+
+def selftest(ctl, args):
+    """The stub worker of --launch-selftest: what a rank does with the control plane around the real benchmark --
+    rendezvous of a 128-byte id from rank 0, barriers, a max over ranks, a gather -- without GPU or library."""
+    import hashlib
+    print(f"selftest: rank {ctl.rank} pid {os.getpid()}", file=sys.stderr, flush=True)
+    uid = ctl.bcast_bytes(bytes((7 * i + 1) % 256 for i in range(128)) if ctl.rank == 0 else b"\0" * 128)
+    ctl.barrier()
+    if ctl.rank == args.selftest_fail_rank:
+        print(f"selftest: rank {ctl.rank} fails on purpose", file=sys.stderr, flush=True)
+        os._exit(7)
+    if ctl.rank == args.selftest_hang_rank:
+        time.sleep(1e6)
+    ctl.barrier()
+    worst = ctl.max(10.0 + ctl.rank)
+    recs = ctl.gather({"rank": ctl.rank, "local_rank": ctl.local_rank, "world": ctl.world, "pid": os.getpid(), "ppid": os.getppid(),
+                       "uid_sha256": hashlib.sha256(uid).hexdigest(), "hub": "parent" if "ALPROJ_HUB" in os.environ else "rank0",
+                       "env": {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}})
+    ctl.close()
+    if ctl.rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": ctl.world, "max_over_ranks": worst, "ranks": recs}), flush=True)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def blas_threads():
+    """threads of the BLAS behind numpy's np.dot (the only multi-threaded part of the reference path)"""
+    try:
+        from threadpoolctl import threadpool_info
+        pools = [p for p in threadpool_info() if p.get("user_api") == "blas"]
+        if pools:
+            return {"library": pools[0].get("internal_api"), "threads": pools[0].get("num_threads")}
+    except Exception:
+        pass
+    return {"library": None, "threads": os.environ.get("OPENBLAS_NUM_THREADS") or os.environ.get("OMP_NUM_THREADS")}
+
+
+def cpu_baseline(orc, truth, base, targets, bounds_fn, xyz_l, obs, n_total, pop):
+    """the numpy float64 port of the reference path (oracle = checker only) on the host cores, warm
+    best of 3 at N = 1e5, 1e6, 1e7 (strided samples of the same DSM); a population of P = 4 candidates through the
+    reference's per-candidate loop (optimize.py:347-356: denormalise, project, huber) extrapolated to P."""
+    sizes = {}
+    n_local = len(xyz_l)
+    for ns in (100_000, 1_000_000, 10_000_000):
+        ns = min(ns, n_local)
+        st = max(1, n_local // ns)
+        xyz = xyz_l[0:ns * st:st].astype(np.float64)
+        o = obs[0:ns * st:st].astype(np.float64) if obs is not None else np.zeros((ns, 2))
+        tp, tl = [], []
+        for i in range(4):                           # one warm-up, then best of 3
+            t = time.perf_counter()
+            uv = orc.project_points(xyz, truth)
+            t1 = time.perf_counter()
+            orc.huber(o, uv, 10.0)
+            t2 = time.perf_counter()
+            if i:
+                tp.append(t1 - t)
+                tl.append(t2 - t1)
+        sizes[ns] = {"project_s": min(tp), "huber_s": min(tl), "gpoints_per_s": ns / min(tp) / 1e9}
+        if ns == 1_000_000 or ns == n_local:
+            bounds = bounds_fn(base, targets)
+            X = np.random.default_rng(4).uniform(0.45, 0.55, (4, len(targets)))
+            tpop = []
+            for i in range(3):
+                t = time.perf_counter()
+                with np.errstate(all="ignore"):
+                    orc.population_losses(xyz, o, base, targets, bounds, X, 10.0)
+                tpop.append(time.perf_counter() - t)
+            pop4 = {"points": ns, "candidates": 4, "seconds": min(tpop[1:])}
+    big = max(sizes)
+    per_eval = pop4["seconds"] / 4 / pop4["points"]             # seconds per point-candidate
+    return {
+        "value": sizes[big]["gpoints_per_s"], "unit": "Gpoints/s", "cores": 1, "kind": "port",
+        "sample": f"numpy float64 restatement of the reference (oracle/ref_numpy.project_points) on strided samples of the same DSM, "
+                  f"N = {sorted(sizes)}, warm best of 3; `value` is the N = {big} figure; elementwise numpy is single-threaded, "
+                  f"only the two np.dot use BLAS threads",
+        "by_n": {str(k): v for k, v in sizes.items()},
+        "cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(), "blas": blas_threads(),
+        "population_sample": pop4,
+        "cma_iters_per_s_extrapolated": 1.0 / (per_eval * n_total * pop),
+        "cma_extrapolation": f"P = 4 candidates x {pop4['points']} points through the per-candidate loop, scaled to {pop} x {n_total}",
+    }
 
 
 def parity_report(got, ref, w):
@@ -217,41 +266,70 @@ def best_of(fn, reps=3):
 
 def dropin_leg(L, syn, surf, n_side, cam):
     """The reference's own call pair with the reference's own array types (example.py:28,31; project.py:213-215):
-    sim_image(vert f64, col f64, ind int64, params, offsets), then reverse_proj(sim, vert, ind, params, offsets)."""
+    sim_image(vert f64, col f64, ind int64, params, offsets), then reverse_proj(sim, vert, ind, params, offsets) --
+    as the reference runs it (the mesh uploaded on every call: the default), and with the opt-in mesh cache: writeable
+    arrays (every byte digested before the resident mesh is trusted) and read-only arrays (taken by identity)."""
     from alproj_amd import project as aproj
     n_total = n_side * n_side
     vert64 = surf["vert"].astype(np.float64)             # get_colored_surface returns float64 (surface.py:189-193)
     col64 = np.random.default_rng(syn.SEED + 1).random((n_total, 3))
     ind64 = syn.grid_indices(n_side, np.int64)           # 4.8 GB (docs/usage.md:96)
     nbytes = vert64.nbytes + col64.nbytes + ind64.nbytes
-    aproj.clear_mesh_cache()
+    aproj.set_timing(True)
     rec = {"call": "sim_image(vert f64, col f64, ind int64, params, offsets); reverse_proj(sim, vert, ind, params, offsets)",
            "vertices": n_total, "host_bytes_of_the_three_arrays": nbytes}
+    pcie = 56e9                                          # B/s, measured pageable H2D rate of this box class (tools/h2d_rate.hip)
+
+    def pair(tag):
+        t = time.perf_counter()
+        sim = aproj.sim_image(vert64, col64, ind64, cam, surf["offsets"])
+        t_sim = time.perf_counter() - t
+        r = {"sim_image": dict(aproj.LAST_TIMING, total_s=t_sim)}
+        t = time.perf_counter()
+        df = aproj.reverse_proj(sim, vert64, ind64, cam, surf["offsets"])
+        t_rev = time.perf_counter() - t
+        r["reverse_proj"] = dict(aproj.LAST_TIMING, total_s=t_rev, rows=len(df))
+        r["first_call_ms"], r["second_call_ms"] = t_sim * 1e3, t_rev * 1e3
+        r["second_call_device_ms"] = r["reverse_proj"].get("device_ms")
+        r["second_call_resolve_only"] = bool(r["reverse_proj"].get("resolve_only"))
+        rec[tag] = r
+        return sim, df
+
+    # (a) as the reference does it: every call uploads
+    sim, df = pair("default_upload_every_call")
+    rec["first_call_ms"] = rec["default_upload_every_call"]["first_call_ms"]
+    rec["first_call_pcie_floor_ms"] = nbytes / pcie * 1e3
+    rec["first_call_over_pcie_floor"] = rec["first_call_ms"] / rec["first_call_pcie_floor_ms"]
+    # (b) opt-in cache, writeable arrays: a hit costs a digest of every byte (alp_host_hash64, all host cores)
     t = time.perf_counter()
-    sim = aproj.sim_image(vert64, col64, ind64, cam, surf["offsets"])
-    t_sim = time.perf_counter() - t
-    rec["sim_image"] = dict(aproj.LAST_TIMING, total_s=t_sim)
-    t = time.perf_counter()
-    df = aproj.reverse_proj(sim, vert64, ind64, cam, surf["offsets"])
-    t_rev = time.perf_counter() - t
-    rec["reverse_proj"] = dict(aproj.LAST_TIMING, total_s=t_rev, rows=len(df))
-    # the pair once more, everything resident: what the reference's second and third render pairs cost (example.py:57,59; 97,103)
+    L.host_hash64(vert64), L.host_hash64(col64), L.host_hash64(ind64)
+    t_dig = time.perf_counter() - t
+    rec["digest_of_the_three_arrays_ms"] = t_dig * 1e3
+    rec["digest_gb_per_s"] = nbytes / t_dig / 1e9
+    aproj.set_mesh_cache(True)
+    sim_b, df_b = pair("verify")
+    assert np.array_equal(sim, sim_b) and df_b.equals(df)
+    del df_b, sim_b
+    # (c) opt-in cache, read-only arrays: identity is enough
+    aproj.clear_mesh_cache()
+    for a in (vert64, col64, ind64):
+        a.setflags(write=False)
+    sim_c, df_c = pair("read_only_arrays")
+    assert np.array_equal(sim, sim_c) and df_c.equals(df)
     t = time.perf_counter()
     sim2 = aproj.sim_image(vert64, col64, ind64, cam, surf["offsets"])
-    rec["sim_image_again"] = dict(aproj.LAST_TIMING, total_s=time.perf_counter() - t)
+    rec["read_only_arrays"]["sim_image_again"] = dict(aproj.LAST_TIMING, total_s=time.perf_counter() - t)
     assert np.array_equal(sim, sim2)
-    pcie = 56e9                                          # B/s, measured pageable H2D rate of this box class (tools/h2d_rate.hip)
-    rec["first_call_ms"] = t_sim * 1e3
-    rec["first_call_pcie_floor_ms"] = nbytes / pcie * 1e3
-    rec["first_call_over_pcie_floor"] = t_sim / (nbytes / pcie)
-    rec["second_call_device_ms"] = rec["reverse_proj"]["device_ms"]
-    rec["second_call_resolve_only"] = bool(rec["reverse_proj"]["resolve_only"])
+    del df_c, sim_c, sim2
+    rec["second_call_device_ms"] = rec["read_only_arrays"]["second_call_device_ms"]
+    rec["second_call_resolve_only"] = rec["read_only_arrays"]["second_call_resolve_only"]
     # what the reference does on the host before its own upload (project.py:213-215), same box, one core (numpy)
     t = time.perf_counter()
     a, b, c = vert64.astype("f4"), col64.astype("f4"), ind64.astype("i4")
     rec["reference_host_casts_s"] = time.perf_counter() - t
     del a, b, c
-    aproj.clear_mesh_cache()
+    aproj.set_mesh_cache(False)
+    aproj.set_timing(False)
     return rec, df, sim
 
 
@@ -355,20 +433,39 @@ def next_rows_leg(L, syn, orc, df, ras_dev=None):
 
 def main():
     args = parse()
-    ctl = Control()
+    from alproj_amd import launch
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the LAUNCHER: builds the library once (hipcc only), then starts the ranks; it never initialises the GPU
+        if not args.launch_selftest:
+            try:
+                from alproj_amd import _build
+                _build.build()
+            except Exception as e:
+                print(f"bench.py: build skipped: {e}", file=sys.stderr)
+        sys.exit(launch.spawn([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, timeout_s=args.launch_timeout))
+
+    ctl = launch.Control.from_env()
     if ctl.world != args.gpus:
         if ctl.rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ctl.world}; launch with torch.distributed.run",
-                  file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ctl.world}", file=sys.stderr)
         sys.exit(2)
+    if args.launch_selftest:
+        return selftest(ctl, args)
 
-    if ctl.local_rank == 0:                    # harness convenience: (re)build a missing/stale library
+    if ctl.local_rank == 0 and ctl.world == 1:  # harness convenience: (re)build a missing/stale library (the launcher did it for its ranks)
         try:
             from alproj_amd import _build
             _build.build()
         except Exception as e:                 # the product still fails loudly below if it is absent
             print(f"bench.py: build skipped: {e}", file=sys.stderr)
-    ctl.barrier()
+    elif "ALPROJ_HUB" not in os.environ:       # ranks of a foreign launcher: local rank 0 builds, the others wait
+        if ctl.local_rank == 0:
+            try:
+                from alproj_amd import _build
+                _build.build()
+            except Exception as e:
+                print(f"bench.py: build skipped: {e}", file=sys.stderr)
+        ctl.barrier()
     from alproj_amd import _lib as L
     from alproj_amd import dist as adist
     from alproj_amd import synthetic as syn
@@ -381,7 +478,7 @@ def main():
     comm_rank, comm_world = L.comm_info()
     # the communicator the LIBRARY reports must be the job: a rank that fell back to a world of its own would add
     # nothing to the all-reduce and the line would still look plausible
-    print(f"bench.py: rank {ctl.rank}/{ctl.world} on device {ctl.local_rank}: rccl rank {comm_rank} of {comm_world}",
+    print(f"bench.py: rank {ctl.rank}/{ctl.world} on device {ctl.local_rank} ({info.get('pci_bus_id')}): rccl rank {comm_rank} of {comm_world}",
           file=sys.stderr, flush=True)
     if comm_world != args.gpus or comm_rank != ctl.rank:
         print(f"bench.py: RCCL communicator has {comm_world} ranks (this one is {comm_rank}) but --gpus is {args.gpus}",
@@ -390,6 +487,8 @@ def main():
     if L.build_flags():
         print(f"bench.py: libalproj_hip.so was built with development switches: {L.build_flags()}", file=sys.stderr)
         sys.exit(4)
+    rank_devices = ctl.gather({"rank": ctl.rank, "device": ctl.local_rank, "pci_bus_id": info.get("pci_bus_id"),
+                               "rccl_rank": comm_rank, "rccl_nranks": comm_world, "pid": os.getpid()})
 
     # ---------------------------------------------------------------- workload
     n_side = syn.grid_side(args.vertices)
@@ -418,6 +517,7 @@ def main():
     kern_s = dev_ms / args.steps / 1e3
     bpv = BYTES_PER_VERTEX[args.precision]
     achieved = n_local * bpv / kern_s
+    per_launch = launch_times(L, lambda: pts.project(pv_truth))      # one event pair per launch: the median next to the mean
 
     t_fetch = time.perf_counter()
     uu_all, vv_all = pts.fetch(np.float32)          # device -> host of all projected pixels
@@ -456,11 +556,13 @@ def main():
                      "frac": achieved / HBM_PEAK, "traffic": traffic,
                      "traffic_source": f"{traffic_src} (rocprofv3 --pmc, bytes/vertex x vertices per launch)" if traffic else None,
                      "kernel": "project_kernel", "kernel_ms": kern_s * 1e3,
-                     "bytes_per_vertex": bpv, "vertices_per_launch": n_local},
+                     "kernel_ms_median_of_single_launches": float(np.median(per_launch)), "single_launches": len(per_launch),
+                     "bytes_per_vertex": bpv, "vertices_per_launch": n_local,
+                     "strict_1e-5_relative_pass": parity["strict_1e-5_relative_pass_fraction"]},
         "parity": parity,
         "device": info, "setup_s": t_gen,
-        # the communicator the library itself reports (ncclCommInitRank succeeded on every rank)
-        "rccl": {"rank": comm_rank, "nranks": comm_world},
+        # the communicator the library itself reports (ncclCommInitRank succeeded on every rank), and where every rank ran
+        "rccl": {"rank": comm_rank, "nranks": comm_world, "ranks": rank_devices},
         # SURVEY 8(d) c2 asks for the end-to-end figure beside the kernel figure; it is never `value`
         "pcie_inclusive": {"upload_s": t_up, "upload_s_second_time": t_up2,
                            "upload_gb_per_s_second_time": xyz_l.nbytes / t_up2 / 1e9, "fetch_uv_s": t_fetch,
@@ -480,9 +582,10 @@ def main():
         obs[~np.isfinite(obs)] = 0.0
         pts.set_observed(obs)
         generation, state = cma_loop(L, CMA, pts, base, targets, bounds_to_array, args.pop, L.LOSS_HUBER, 10.0)
-        k_cma = args.cma_steps or min(args.steps, 10)
-        wall_c, _ = timed(ctl, L, generation, k_cma, min(args.warmup, 2))
+        k_cma = args.cma_steps                               # 50 generations, whatever --steps is
+        wall_c, _ = timed(ctl, L, generation, k_cma, 2)
         eval_ms, ar_ms = pts.eval_population_timing()        # the last generation's kernels / all-reduce (HIP events)
+        eval_ms, ar_ms = ctl.max(eval_ms), ctl.max(ar_ms)    # the slowest rank's (they wait for each other in the all-reduce)
         evals = n_local * args.pop
         n_gen = state["n"]
         out["cma"] = {
@@ -505,11 +608,16 @@ def main():
                          "frac_at_survey_flops": evals * 100 / (eval_ms / 1e3) / VALU_PEAK,
                          "hbm_frac": n_local * 20 * ((args.pop + 127) // 128) / (eval_ms / 1e3) / HBM_PEAK},
         }
+        # flat copies where the driver keeps them (it stores `roofline` verbatim, other top-level keys by name only)
+        out["roofline"].update({"cma_iters_per_s": k_cma / wall_c, "cma_kernel_ms": eval_ms, "cma_generations_timed": k_cma,
+                                "cma_population": args.pop, "cma_dims": len(targets),
+                                "cma_valu_frac": out["cma"]["roofline"]["frac"], "cma_valu_frac_at_survey_100_flop": out["cma"]["roofline"]["frac_at_survey_flops"],
+                                "cma_all_reduce_ms": ar_ms, "cma_all_reduce_share": out["cma"]["all_reduce_share_of_generation"]})
 
     # ---------------------------------------------------------------- float64 parity mode (1 GPU)
     if ctl.world == 1 and not args.no_f64 and args.precision == "f32":
         p64 = L.Points(xyz_l, origin, "f64")
-        k64 = min(args.steps, 20)
+        k64 = max(20, min(args.steps, 40))
         wall64, dev64 = timed(ctl, L, lambda: p64.project(pv_truth), k64, 3)
         u64, v64 = p64.fetch_strided(0, step, cnt)
         par64 = parity_report(np.stack([u64, v64], 1), ref, truth["w"])
@@ -520,6 +628,9 @@ def main():
                                      "roofline": {"bound": "hbm", "achieved": n_local * 40 / k64_s / 1e9, "peak": HBM_PEAK / 1e9,
                                                   "unit": "GB/s", "frac": n_local * 40 / k64_s / HBM_PEAK, "kernel_ms": k64_s * 1e3,
                                                   "bytes_per_vertex": 40}}}
+        out["roofline"].update({"f64_gpoints_per_s": out["f64"]["projection"]["gpoints_per_s"], "f64_hbm_frac": n_local * 40 / k64_s / HBM_PEAK,
+                                "f64_kernel_ms": k64_s * 1e3, "f64_strict_1e-5_pass": par64["strict_1e-5_relative_pass_fraction"],
+                                "f64_max_err_rel": par64["max_err_rel_to_max(|ref|,w)_vs_f64_oracle"]})
         if not args.no_cma:
             p64.set_observed(obs)
             gen64, st64 = cma_loop(L, CMA, p64, base, targets, bounds_to_array, args.pop, L.LOSS_HUBER, 10.0)
@@ -531,6 +642,7 @@ def main():
                                  "roofline": {"bound": "valu_fp64", "achieved": n_local * args.pop * EVAL_FLOPS / (e64 / 1e3) / 1e12,
                                               "peak": VALU_PEAK_F64 / 1e12, "unit": "TFLOP/s",
                                               "frac": n_local * args.pop * EVAL_FLOPS / (e64 / 1e3) / VALU_PEAK_F64}}
+            out["roofline"]["f64_cma_iters_per_s"] = 2 / wall_c64
         p64.close()
 
     # ---------------------------------------------------------------- BASELINE configs 2 and 3: 10 M vertices (1 GPU)
@@ -544,9 +656,13 @@ def main():
             pv10 = L.params_vector(t10)
             w10, d10 = timed(ctl, L, lambda: p10.project(pv10), args.steps, args.warmup)
             k10 = d10 / args.steps / 1e3
+            pl10 = launch_times(L, lambda: p10.project(pv10))       # kernel only, median of >= 20 launches after warm-up
+            med10 = float(np.median(pl10)) / 1e3
             c2 = {"vertices": len(x10), "gpoints_per_s": len(x10) / (w10 / args.steps) / 1e9, "ms_per_step": w10 / args.steps * 1e3,
+                  "gpoints_per_s_kernel_median": len(x10) / med10 / 1e9, "kernel_ms_median": med10 * 1e3, "single_launches": len(pl10),
                   "roofline": {"bound": "hbm", "achieved": len(x10) * 20 / k10 / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                               "frac": len(x10) * 20 / k10 / HBM_PEAK, "kernel_ms": k10 * 1e3}}
+                               "frac": len(x10) * 20 / k10 / HBM_PEAK, "kernel_ms": k10 * 1e3, "frac_at_median": len(x10) * 20 / med10 / HBM_PEAK}}
+            out["roofline"].update({"c2_gpoints_per_s_kernel_median": c2["gpoints_per_s_kernel_median"], "c2_hbm_frac_at_median": c2["roofline"]["frac_at_median"]})
             uu, vv = p10.fetch(np.float32)
             o10 = np.stack([uu, vv], 1) + np.random.default_rng(1).normal(0, 1.0, (len(x10), 2)).astype(np.float32)
             o10[~np.isfinite(o10)] = 0.0
@@ -554,7 +670,7 @@ def main():
             c3 = {"vertices": len(x10), "population": 256, "dims": 9, "sigma": 1.0}
             for tag, kind, fs in (("huber_f10", L.LOSS_HUBER, 10.0), ("mean_distance", L.LOSS_MEAN_DIST, 0.0)):
                 g10, st10 = cma_loop(L, CMA, p10, b10, syn.TARGETS_D9, bounds_to_array, 256, kind, fs)
-                k_g = 50
+                k_g = args.c3_steps                        # 100 generations
                 wc, _ = timed(ctl, L, g10, k_g, 3)
                 ek, _ = p10.eval_population_timing()
                 c3[tag] = {"iters_per_s": k_g / wc, "ms_per_iter": wc / k_g * 1e3, "generations_timed": k_g, "kernel_ms": ek,
@@ -562,6 +678,9 @@ def main():
                            "host_ms_per_generation": {"ask": st10["t_ask"] / st10["n"] * 1e3, "tell": st10["t_tell"] / st10["n"] * 1e3},
                            "valu_frac": len(x10) * 256 * EVAL_FLOPS / (ek / 1e3) / VALU_PEAK}
         out["c2_c3_10m"] = {"c2_projection": c2, "c3_cma": c3}
+        out["roofline"].update({"c3_iters_per_s": c3["huber_f10"]["iters_per_s"], "c3_kernel_ms": c3["huber_f10"]["kernel_ms"],
+                                "c3_evals_per_s": c3["huber_f10"]["point_candidate_evals_per_s"], "c3_valu_frac": c3["huber_f10"]["valu_frac"],
+                                "c3_generations_timed": args.c3_steps, "c3_mean_distance_iters_per_s": c3["mean_distance"]["iters_per_s"]})
         del s10, x10, o10
 
     # ---------------------------------------------------------------- depth raster (1 GPU)
@@ -628,6 +747,12 @@ def main():
                              # 12 B written per pixel), which is fused away here
                              "frac_with_survey_remap_bytes": (alg + W * H * 24) / (dev_r / k_r / 1e3) / HBM_PEAK},
             }
+            if not explicit:
+                out["roofline"].update({"raster_ms_per_frame": dev_r / k_r, "raster_hbm_frac": alg / (dev_r / k_r / 1e3) / HBM_PEAK,
+                                        "raster_frames_timed": k_r, "raster_same_view_again_ms": dev_c / k_r})
+            elif name == "int32_indices":
+                out["roofline"].update({"raster_int32_indices_ms_per_frame": dev_r / k_r,
+                                        "raster_int32_indices_hbm_frac": alg / (dev_r / k_r / 1e3) / HBM_PEAK})
             if not explicit:     # also with the distorted ground-truth pose (remap stage on)
                 pv_dist = L.params_vector(syn.truth_params(n_side))
                 os.environ["ALP_NO_VIS_CACHE"] = "1"
@@ -722,17 +847,7 @@ def main():
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1)
     if ctl.world == 1 and not args.no_cpu_baseline:
-        ns = min(n_local, 20_000_000)          # ~10 s of host work in all
-        sl = slice(0, ns * (n_local // ns), n_local // ns)
-        obs_s = obs[sl][:ns].astype(np.float64) if obs is not None else np.zeros((ns, 2))
-        t_proj, t_eval = cpu_baseline(orc, truth, xyz_l[sl][:ns], obs_s)
-        out["cpu_baseline"] = {
-            "value": ns / t_proj / 1e9, "unit": "Gpoints/s", "cores": 1, "kind": "port",
-            "sample": f"numpy float64 restatement of the reference (oracle/ref_numpy.project_points) on a {ns}-vertex "
-                      f"strided sample of the same DSM, best of 2 after warm-up (elementwise numpy is single-"
-                      f"threaded); os.cpu_count()={os.cpu_count()}",
-            "cma_iters_per_s_extrapolated": 1.0 / ((t_proj + t_eval) * (n_total / ns) * args.pop),
-        }
+        out["cpu_baseline"] = cpu_baseline(orc, truth, base, targets, bounds_to_array, xyz_l, obs, n_total, args.pop)
         out["speedup_vs_cpu_baseline"] = gpts / out["cpu_baseline"]["value"]
 
     pts.close()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ALP_ABI_VERSION 3
+#define ALP_ABI_VERSION 4
 
 /* x,y,z,fov,pan,tilt,roll,a1,a2,k1..k6,p1,p2,s1..s4,w,h,cx,cy */
 #define ALP_NPARAM 25
@@ -75,12 +75,20 @@ int alp_shutdown(void);
 int alp_device_count(int *count);
 /* name[len] receives the gcnArchName ("gfx950:sramecc+:xnack-"); cu_count the CU number. */
 int alp_device_info(char *name, int len, int *cu_count, int64_t *hbm_bytes);
+/* PCI bus id ("0000:75:00.0") of the device this process was initialised on: what tells the ranks of a
+ * multi-GPU job apart in a benchmark record.  len >= 16. */
+int alp_device_pci_bus_id(char *id, int len);
+/* 64-bit content digest of a HOST array, computed by `threads` host threads (0 = all cores); needs no device.
+ * A change of any single 8-byte word always changes the digest.  The render wrappers use it to make sure a mesh
+ * kept on the device still equals the caller's arrays (the reference uploads on every call,
+ * src/alproj/project.py:213-215, so an in-place edit between two calls must be seen). */
+int alp_host_hash64(const void *buf, int64_t bytes, int threads, uint64_t *digest);
 /* Block until everything queued on the library stream is done. */
 int alp_synchronize(void);
 
 /* HIP-event timer slots on the library stream (what bench.py brackets kernels with).
- * slot in [0, 64); the package's own wrappers (alproj_amd.project: LAST_TIMING) record into
- * slots 60 and 61. */
+ * slot in [0, 64).  (The package's render wrappers do not use them: a frame's device time comes from
+ * alp_mesh_frame_ms.) */
 int alp_event_record(int slot);
 int alp_event_elapsed_ms(int slot_start, int slot_stop, float *ms); /* synchronises on stop */
 
@@ -113,6 +121,14 @@ int alp_comm_info(int *rank, int *world_size); /* 0,1 when no communicator */
  * (src/alproj/optimize.py:410-416), which is fine for one process and silently wrong for several
  * that must all-reduce the sums of identical candidates. */
 int alp_comm_bcast(void *buf, int64_t bytes, int root);
+/* All-gather of host buffers of different sizes: alp_comm_allgather_counts tells every rank the byte count of every
+ * rank (counts[world_size]); alp_comm_allgatherv then fills `recv` (sum of the counts) with rank 0's `send`, rank
+ * 1's, ... (one ncclBroadcast per rank in one group, on the library stream).  Without a communicator: a copy.
+ * LsqOptimizer (src/alproj/optimize.py:442-539) solves ONE least-squares problem over all points: with the points
+ * sharded over ranks, every rank gathers the residual vector and the Jacobian rows of all shards and runs the
+ * identical scipy solve on them. */
+int alp_comm_allgather_counts(int64_t bytes, int64_t *counts);
+int alp_comm_allgatherv(const void *send, void *recv, const int64_t *counts);
 
 /* ---------------------------------------------------------------- point sets ---------- */
 /* Device-resident set of 3-D points (GCPs or DSM vertices) -- the `obj_points` DataFrame
@@ -297,6 +313,12 @@ int alp_render_enqueue(alp_mesh_t *mesh, const double params[ALP_NPARAM],
                        const double *offsets, double min_distance);
 int alp_render_fetch(alp_mesh_t *mesh, float *out);
 int alp_mesh_frame_counts(alp_mesh_t *mesh, int64_t counts[2]);
+/* Device time of the launches of the last alp_render_enqueue on this mesh (HIP events owned by the mesh, on the
+ * library stream; waits for the frame). */
+int alp_mesh_frame_ms(alp_mesh_t *mesh, float *ms);
+/* Release the work areas the mesh keeps between calls of alp_render_rasterize_plan / alp_render_rasterize (the
+ * compacted points and the 5 GB-class accumulator area of a 100 M-vertex frame); the mesh and its frame stay. */
+int alp_mesh_trim(alp_mesh_t *mesh);
 /* The last frame as h x w x 3 uint8: (image * scale) cast like numpy's astype(uint8)
  * (truncation toward zero, wrap), channels reversed when reverse_channels != 0 -- the tail of
  * sim_image(), src/alproj/project.py:322-324 (scale 255, RGB -> BGR), on the device, so that

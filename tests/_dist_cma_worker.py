@@ -37,8 +37,23 @@ def main():
         log.append(("bcast", str(array.dtype), tuple(array.shape)))
         return array
 
+    def comm_allgather(array):
+        """rows of every rank in rank order, like alp_comm_allgather_counts + alp_comm_allgatherv"""
+        array = np.ascontiguousarray(array)
+        counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(counts, torch.tensor([array.shape[0]], dtype=torch.int64))
+        counts = [int(c[0]) for c in counts]
+        width = array.shape[1:] if array.ndim > 1 else ()
+        pad = np.zeros((max(counts),) + width, dtype=array.dtype)
+        pad[:array.shape[0]] = array
+        parts = [torch.zeros(pad.shape, dtype=torch.from_numpy(pad).dtype) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(pad))
+        log.append(("allgather", tuple(array.shape)))
+        return np.concatenate([p.numpy()[:c] for p, c in zip(parts, counts)])
+
     _lib.comm_info = lambda: (rank, world)
     _lib.comm_bcast = comm_bcast
+    _lib.comm_allgather = comm_allgather
 
     truth = syn.truth_params(316)
     init = dict(truth, pan=truth["pan"] + 1.5, tilt=truth["tilt"] - 1.0, fov=truth["fov"] + 2, x=truth["x"] + 3)
@@ -94,14 +109,17 @@ def main():
     res["cma_err"] = err
     res["cma_X"] = np.stack(X_seen)
     res["cma_log"] = np.array([repr(e) for e in log])
-    # ---- least squares: every rank solves its shard, rank 0's solution is the result everywhere
-    del log[:]
-    q = aopt.LsqOptimizer(obj, img, init)
-    q.set_target(["fov", "pan", "tilt", "roll"])
-    lp, lerr = q.optimize(method="trf", loss="linear", max_nfev=30)
-    res["lsq_params"] = np.array([lp[k] for k in _lib.PARAM_KEYS], dtype=np.float64)
-    res["lsq_err"] = lerr
-    res["lsq_log"] = np.array([repr(e) for e in log])
+    # ---- least squares: every rank gathers all shards' residuals / Jacobian rows and solves the reference's ONE problem
+    for tag, kw in (("lsq", dict(method="trf", loss="linear", max_nfev=30)),
+                    ("lsq_huber", dict(method="trf", loss="huber", f_scale=2.0, max_nfev=30)),
+                    ("lsq_2point", dict(method="dogbox", loss="linear", jac="2-point", max_nfev=30))):
+        del log[:]
+        q = aopt.LsqOptimizer(obj, img, init)
+        q.set_target(["fov", "pan", "tilt", "roll"])
+        lp, lerr = q.optimize(**kw)
+        res[tag + "_params"] = np.array([lp[k] for k in _lib.PARAM_KEYS], dtype=np.float64)
+        res[tag + "_err"] = lerr
+        res[tag + "_log"] = np.array([repr(e) for e in log])
     np.savez(out, **res)
     dist.barrier()
     dist.destroy_process_group()

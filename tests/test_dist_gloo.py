@@ -112,6 +112,53 @@ def test_combine_partials_semantics():
     assert np.isnan(losses[0])                          # np.mean of an empty set
 
 
+def _single_process_lsq(points=slice(None)):
+    """LsqOptimizer.optimize of the product in THIS process over all 1201 points (world 1), the oracle standing in for the
+    device exactly as in tests/_dist_cma_worker.py"""
+    import pandas as pd
+    from alproj_amd import _lib
+    from alproj_amd import optimize as aopt
+    truth = syn.truth_params(316)
+    init = dict(truth, pan=truth["pan"] + 1.5, tilt=truth["tilt"] - 1.0, fov=truth["fov"] + 2, x=truth["x"] + 3)
+    n = 1201
+    xyz = syn.gcp_points(n, truth, seed=11)
+    uv = orc.project_points(xyz, truth) + np.random.default_rng(11).normal(0, 0.8, (n, 2))
+    xyz, uv = xyz[points], uv[points]
+
+    class AllPoints:
+        precision, n = _lib.ALP_F64, len(xyz)
+
+        def eval_population(self, cand, kind, f_scale):
+            return np.array([orc.mean_distance(uv, orc.project_points(xyz, orc.vector_to_params(c))) for c in cand]), 0
+
+        def residuals(self, vec):
+            return orc.residual_vector(xyz, uv, orc.vector_to_params(vec))
+
+        def residuals_batch(self, cand):
+            return np.stack([self.residuals(c) for c in cand])
+
+        def close(self):
+            pass
+
+    saved = aopt.BaseOptimizer._device_points, _lib.comm_info
+    aopt.BaseOptimizer._device_points = lambda self, precision: AllPoints()
+    _lib.comm_info = lambda: (0, 1)
+    out = {}
+    try:
+        obj, img = pd.DataFrame(xyz, columns=["x", "y", "z"]), pd.DataFrame(uv, columns=["u", "v"])
+        for tag, kw in (("lsq", dict(method="trf", loss="linear", max_nfev=30)),
+                        ("lsq_huber", dict(method="trf", loss="huber", f_scale=2.0, max_nfev=30)),
+                        ("lsq_2point", dict(method="dogbox", loss="linear", jac="2-point", max_nfev=30))):
+            q = aopt.LsqOptimizer(obj, img, init)
+            q.set_target(["fov", "pan", "tilt", "roll"])
+            lp, lerr = q.optimize(**kw)
+            out[tag + "_params"] = np.array([lp[k] for k in _lib.PARAM_KEYS], dtype=np.float64)
+            out[tag + "_err"] = lerr
+    finally:
+        aopt.BaseOptimizer._device_points, _lib.comm_info = saved
+    return out
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_optimisers_multi_rank_branches_stay_in_lockstep(tmp_path, world):
     """The multi-rank branches of CMAOptimizer.optimize (seed broadcast before the sampler exists, candidate
@@ -133,14 +180,29 @@ def test_optimisers_multi_rank_branches_stay_in_lockstep(tmp_path, world):
         np.testing.assert_array_equal(r["cma_X"], res[0]["cma_X"])
         np.testing.assert_array_equal(r["cma_params"], res[0]["cma_params"])
         assert float(r["cma_err"]) == float(res[0]["cma_err"])
-        np.testing.assert_array_equal(r["lsq_params"], res[0]["lsq_params"])
-        assert float(r["lsq_err"]) == float(res[0]["lsq_err"])
+        for tag in ("lsq", "lsq_huber", "lsq_2point"):
+            np.testing.assert_array_equal(r[tag + "_params"], res[0][tag + "_params"])
+            assert float(r[tag + "_err"]) == float(res[0][tag + "_err"])
     assert res[0]["cma_X"].shape == (20, 12, 9)
     # the order of collectives every rank went through: seed, then (candidates, evaluation) x 20, then the final error
     expect = ["('bcast', 'uint64', (1,))"] + ["('bcast', 'float64', (12, 9))", "('eval', 12)"] * 20 + ["('eval', 1)"]
     for r in res:
         assert list(r["cma_log"]) == expect
-        assert list(r["lsq_log"]) == ["('bcast', 'float64', (4,))", "('eval', 1)"]
+        log = list(r["lsq_log"])
+        assert log[-2:] == ["('bcast', 'float64', (4,))", "('eval', 1)"]
+        assert len(log) > 4 and all(e.startswith("('allgather'") for e in log[:-2])       # residual vectors (1-D) and Jacobian rows (., 4)
+        assert any(e.endswith(", 4))") for e in log[:-2]) and not any(e.endswith(", 4))") for e in r["lsq_2point_log"])
+    # the reference's problem, not a shard's: the single-process solve over ALL points (same host code, the oracle as the
+    # device) gives the same optimum, to the tolerances of g14 (tests/test_gpu_golden_render.py: what the reference's own
+    # optimum moves by when its residuals change in the last bits -- numpy's BLAS rounds a shard's np.dot differently from
+    # the whole array's, and 2-point differences with a 1.5e-8 step amplify that): 2e-4 degrees, 5e-5 px on the error.
+    # A shard-only solve (the round-3 behaviour) is 1e-2 ... 1e-1 degrees away.
+    single = _single_process_lsq()
+    for tag in ("lsq", "lsq_huber", "lsq_2point"):
+        np.testing.assert_allclose(res[0][tag + "_params"], single[tag + "_params"], rtol=0, atol=2e-4)
+        assert abs(float(res[0][tag + "_err"]) - single[tag + "_err"]) < 5e-5
+    shard = _single_process_lsq(points=slice(0, 1201 // world))
+    assert np.abs(shard["lsq_params"] - single["lsq_params"]).max() > 2e-3
     # ... and least squares found the pose (20 generations of 12 do not finish CMA-ES's 9-parameter search, and
     # its result is the last generation's best, quirk Q9: nothing to assert on its error but that it is finite)
     assert np.isfinite(float(res[0]["cma_err"])) and float(res[0]["lsq_err"]) < 10.0 < float(res[0]["init_err"])

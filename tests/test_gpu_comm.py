@@ -37,12 +37,20 @@ def test_allreduce_path_world1():
             Y = X.copy()
             L.comm_bcast(Y)
             np.testing.assert_array_equal(X, Y)
+            # all-gather of ragged host arrays (LsqOptimizer's residual vectors and Jacobian rows): ncclAllGather of the
+            # counts, one ncclBroadcast per rank
+            np.testing.assert_array_equal(L.comm_allgather(X), X)
+            r = np.random.default_rng(1).random(1601)
+            np.testing.assert_array_equal(L.comm_allgather(r), r)
+            assert L.comm_allgather(X[:0]).shape == (0, 21)
         finally:
             L.comm_destroy()
         again, amin2 = pts.eval_population(cand, L.LOSS_HUBER, 10.0)
     assert L.comm_info() == (0, 1)
     z = np.arange(4.0)
     L.comm_bcast(z)                                                     # no communicator: no-op
+    np.testing.assert_array_equal(L.comm_allgather(z), z)               # ... and a copy
+    assert len(L.device_info()["pci_bus_id"]) >= 7
     np.testing.assert_array_equal(before, after)
     np.testing.assert_array_equal(before, again)
     assert amin0 == amin1 == amin2
@@ -77,8 +85,13 @@ def test_optimisers_take_rank0s_seed_and_candidates_on_the_device(monkeypatch):
         events.append(("bcast", str(array.dtype), array.shape))
         return array
 
+    def fake_allgather(array):                                          # "rank 0" holds no points: the gathered rows are this rank's
+        events.append(("allgather", array.shape))
+        return np.ascontiguousarray(array)
+
     monkeypatch.setattr(L, "comm_info", lambda: (1, 2))
     monkeypatch.setattr(L, "comm_bcast", fake_bcast)
+    monkeypatch.setattr(L, "comm_allgather", fake_allgather)
     real_cma = aopt.CMA
 
     class SpyCMA(real_cma):
@@ -125,6 +138,9 @@ def test_optimisers_take_rank0s_seed_and_candidates_on_the_device(monkeypatch):
     q = aopt.LsqOptimizer(obj, img, init)
     q.set_target(["fov", "pan", "tilt", "roll"])
     lp, lerr = q.optimize(method="trf", loss="linear", max_nfev=20)
+    gathers = [e for e in events if e[0] == "allgather"]
+    events[:] = [e for e in events if e[0] != "allgather"]
+    assert {g[1] for g in gathers} == {(1600,), (1600, 4)}             # every residual vector and every Jacobian went through it
     assert [e[0] for e in events] == ["bcast", "eval"] and events[0][1:] == ("float64", (4,))
     np.testing.assert_array_equal([lp[t] for t in q.target_params], sent[0])
     np.testing.assert_array_equal(events[1][1][0, cols], sent[0])

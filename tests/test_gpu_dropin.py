@@ -128,51 +128,97 @@ def test_visibility_cache_survives_a_queue_overflow(L, scene, monkeypatch):
     np.testing.assert_allclose(img, orast.render(v32, None, None, p, scene["offsets"], grid=grid), rtol=1e-6, atol=1e-6)
 
 
-def test_reference_call_pattern_keeps_the_mesh_resident(L, scene):
-    """example.py:28,31 with the reference's array types: the second call finds the first call's mesh (no upload),
-    renders by the resolve alone, and returns what the uncached path returns"""
+def test_reference_call_pattern_uploads_on_every_call_by_default(L, scene):
+    """project.py:213-215: the reference uploads the mesh on every call, so an in-place edit between sim_image and
+    reverse_proj is seen -- the default here too (no mesh is kept)"""
+    from alproj_amd import project as aproj
+    assert not aproj.mesh_cache_enabled()
+    p, off = scene["params"], scene["offsets"]
+    vert, col, ind = scene["vert64"].copy(), scene["col64"], scene["ind64"]
+    sim = aproj.sim_image(vert, col, ind, p, off)
+    assert aproj._cache["mesh"] is None
+    df = aproj.reverse_proj(sim, vert, ind, p, off)
+    vert[len(vert) // 2 + 777, 1] += 40.0                     # ONE vertex, in place: a spike in the middle of the surface
+    df_edit = aproj.reverse_proj(sim, vert, ind, p, off)
+    with L.Mesh(vert, None, ind) as fresh:
+        fresh.render_enqueue(L.params_vector(p), off, coords=True)
+        want = fresh.fetch()
+    got = aproj.persp_proj(vert, vert, ind, p, off)
+    np.testing.assert_array_equal(got, want)
+    assert not df_edit.equals(df) and aproj._cache["mesh"] is None
+
+
+def test_opt_in_mesh_cache_verifies_content(L, scene):
+    """set_mesh_cache(True): example.py:28,31 with the reference's array types -- the second call finds the first call's
+    mesh (no upload) and renders by the resolve alone; the cache answers only after a digest of EVERY byte of the arrays
+    (or for arrays nobody can write): an in-place edit of one vertex, one colour or one index between two calls gives
+    the result of a fresh upload"""
     from alproj_amd import project as aproj
     p, off = scene["params"], scene["offsets"]
-    vert, col, ind = scene["vert64"], scene["col64"], scene["ind64"]
-    aproj.clear_mesh_cache()
-    sim = aproj.sim_image(vert, col, ind, p, off)
-    mesh = aproj._cache["mesh"]
-    assert mesh is not None and mesh.frame_counts() == (1, 0)
-    df = aproj.reverse_proj(sim, vert, ind, p, off)
-    assert aproj._cache["mesh"] is mesh and mesh.frame_counts() == (1, 1)
-    raw = aproj.persp_proj(vert, col, ind, dict(p, **LENS), off, min_distance=40.0)
-    assert aproj._cache["mesh"] is mesh and mesh.frame_counts() == (1, 2)
-    # reverse_proj first, sim_image second: only the colours are uploaded
-    aproj.clear_mesh_cache()
-    df2 = aproj.reverse_proj(sim, vert, ind, p, off)
-    mesh2 = aproj._cache["mesh"]
-    assert mesh2 is not mesh and not mesh2.has_value
-    sim2 = aproj.sim_image(vert, col, ind, p, off)
-    assert aproj._cache["mesh"] is mesh2 and mesh2.has_value and mesh2.frame_counts() == (1, 1)
-    np.testing.assert_array_equal(sim2, sim)
-    assert df2.equals(df)
-    # the uncached path
-    aproj.clear_mesh_cache()
-    aproj.MESH_CACHE = False
+    vert, col, ind = scene["vert64"].copy(), scene["col64"].copy(), scene["ind64"].copy()
+    aproj.set_mesh_cache(True)
     try:
-        np.testing.assert_array_equal(aproj.sim_image(vert, col, ind, p, off), sim)
-        assert aproj._cache["mesh"] is None
-        assert aproj.reverse_proj(sim, vert, ind, p, off).equals(df)
-        np.testing.assert_array_equal(aproj.persp_proj(vert, col, ind, dict(p, **LENS), off, min_distance=40.0), raw)
+        sim = aproj.sim_image(vert, col, ind, p, off)
+        mesh = aproj._cache["mesh"]
+        assert mesh is not None and mesh.frame_counts() == (1, 0)
+        df = aproj.reverse_proj(sim, vert, ind, p, off)
+        assert aproj._cache["mesh"] is mesh and mesh.frame_counts() == (1, 1) and aproj.LAST_CACHE["hit"]
+        raw = aproj.persp_proj(vert, col, ind, dict(p, **LENS), off, min_distance=40.0)
+        assert aproj._cache["mesh"] is mesh and mesh.frame_counts() == (1, 2)
+        # reverse_proj first, sim_image second: only the colours are uploaded
+        aproj.clear_mesh_cache()
+        df2 = aproj.reverse_proj(sim, vert, ind, p, off)
+        mesh2 = aproj._cache["mesh"]
+        assert mesh2 is not mesh and not mesh2.has_value
+        sim2 = aproj.sim_image(vert, col, ind, p, off)
+        assert aproj._cache["mesh"] is mesh2 and mesh2.has_value and mesh2.frame_counts() == (1, 1)
+        np.testing.assert_array_equal(sim2, sim)
+        assert df2.equals(df)
+        # other arrays with the same content are another mesh
+        aproj.sim_image(vert.copy(), col, ind, p, off)
+        assert aproj._cache["mesh"] is not mesh2
+        # ---- in-place edits between two calls: one un-sampled vertex, one colour row, one index row
+        aproj.clear_mesh_cache()
+        aproj.sim_image(vert, col, ind, p, off)
+        held = aproj._cache["mesh"]
+        vert[len(vert) // 2 + 777, 1] += 40.0
+        df_v = aproj.reverse_proj(sim, vert, ind, p, off)
+        assert aproj._cache["mesh"] is not held and not aproj.LAST_CACHE["hit"]
+        aproj.set_mesh_cache(False)
+        assert df_v.equals(aproj.reverse_proj(sim, vert, ind, p, off)) and not df_v.equals(df)
+        aproj.set_mesh_cache(True)
+        sim_a = aproj.sim_image(vert, col, ind, p, off)
+        held = aproj._cache["mesh"]
+        col[len(col) // 2 + 1501] = (1.0, 0.0, 1.0)
+        sim_c = aproj.sim_image(vert, col, ind, p, off)
+        assert aproj._cache["mesh"] is held and held.frame_counts()[1] >= 1       # same geometry: only the colours went up again
+        ind[70001 % len(ind)] = ind[0]
+        sim_i = aproj.sim_image(vert, col, ind, p, off)
+        assert aproj._cache["mesh"] is not held
+        aproj.set_mesh_cache(False)
+        np.testing.assert_array_equal(sim_i, aproj.sim_image(vert, col, ind, p, off))
+        np.testing.assert_array_equal(sim_c, aproj.sim_image(vert, col, scene["ind64"], p, off))
+        assert (sim_c != sim_a).any()
+        # ---- read-only arrays are taken by identity (no digest), and stop being cacheable when made writeable again
+        aproj.set_mesh_cache(True)
+        for a in (vert, col, ind):
+            a.setflags(write=False)
+        aproj.sim_image(vert, col, ind, p, off)
+        assert aproj._cache["vert"][2] is None and aproj._cache["ind"][2] is None
+        held = aproj._cache["mesh"]
+        aproj.reverse_proj(sim, vert, ind, p, off)
+        assert aproj._cache["mesh"] is held and aproj.LAST_CACHE["hit"]
+        vert.setflags(write=True)
+        vert[5, 1] += 1.0
+        aproj.reverse_proj(sim, vert, ind, p, off)
+        assert aproj._cache["mesh"] is not held
+        view = vert[:]                                             # a read-only view of a writeable array is not immutable
+        view.setflags(write=False)
+        assert not aproj._immutable(view)
     finally:
-        aproj.MESH_CACHE = True
-    # other arrays with the same content are another mesh; an edit of the array is noticed by the fingerprint
-    sim3 = aproj.sim_image(vert, col, ind, p, off)
-    first = aproj._cache["mesh"]
-    aproj.sim_image(vert.copy(), col, ind, p, off)
-    assert aproj._cache["mesh"] is not first
-    moved = vert.copy()
-    aproj.sim_image(moved, col, ind, p, off)
-    held = aproj._cache["mesh"]
-    moved[:, 1] += 25.0
-    sim4 = aproj.sim_image(moved, col, ind, p, off)
-    assert aproj._cache["mesh"] is not held and (sim4 != sim3).any()
-    aproj.clear_mesh_cache()
+        aproj.set_mesh_cache(False)
+    assert aproj._cache["mesh"] is None
+    np.testing.assert_array_equal(aproj.persp_proj(scene["vert64"], scene["col64"], scene["ind64"], dict(p, **LENS), off, min_distance=40.0), raw)
 
 
 @pytest.mark.parametrize("threads", ["0", "1", "5"], ids=["checked_on_the_device", "one_host_thread", "five_host_threads"])

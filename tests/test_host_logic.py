@@ -155,8 +155,10 @@ def test_cma_argument_checks():
 
 
 def test_resident_mesh_cache_keys():
-    """alproj_amd.project keeps the last mesh for the reference's call pair (sim_image then reverse_proj with the same
-    arrays): the key is the array object + layout + a content fingerprint (every 1024th row, head, tail)"""
+    """alproj_amd.project's opt-in mesh cache (set_mesh_cache): the key is the array object + layout + a digest of EVERY byte
+    (alp_host_hash64), or identity alone for arrays nobody can write; the advisor's three round-3 counter-examples -- a
+    contiguous in-place edit of 1023 rows between two sampled rows, of colour rows 1025..2047, of one index row -- are
+    all seen"""
     import gc
     import numpy as np
     from alproj_amd import project as aproj
@@ -170,7 +172,13 @@ def test_resident_mesh_cache_keys():
     assert not aproj._same(key, vert)
     vert[0, 0] -= 1.0
     assert aproj._same(key, vert)
-    vert[2048, 1] = -5.0                                           # a sampled row
+    vert[2048, 1] = -5.0                                           # a row the round-3 fingerprint sampled
+    assert not aproj._same(key, vert)
+    key = aproj._key(vert)
+    vert[5121:6144, 1] += 100                                      # ... and 1023 rows it did not
+    assert not aproj._same(key, vert)
+    key = aproj._key(vert)
+    vert[31_337, 2] = np.nextafter(vert[31_337, 2], 2.0)           # one bit of one coordinate
     assert not aproj._same(key, vert)
     key = aproj._key(vert)
     vert += 1e-9                                                   # a global edit
@@ -180,7 +188,21 @@ def test_resident_mesh_cache_keys():
     assert not aproj._same(key, view)                              # another layout
     ind = np.arange(30, dtype=np.int64).reshape(10, 3)
     k2 = aproj._key(ind)
-    assert aproj._same(k2, ind) and aproj._fingerprint(np.zeros((0, 3), np.int64))[4] == 0
+    assert aproj._same(k2, ind) and aproj._same(aproj._key(np.zeros((0, 3), np.int64)), None) is False
+    big = np.arange(300_000, dtype=np.int64).reshape(-1, 3)
+    k3 = aproj._key(big)
+    big[70_001] = 0                                                # one index row
+    assert not aproj._same(k3, big)
+    # read-only all the way down: identity is enough (no digest is taken), until somebody makes it writeable again
+    frozen = rng.random((1000, 3))
+    frozen.setflags(write=False)
+    kf = aproj._key(frozen)
+    assert kf[2] is None and aproj._same(kf, frozen) and aproj._immutable(frozen)
+    frozen.setflags(write=True)
+    assert not aproj._same(kf, frozen)
+    ro_view = frozen[:]
+    ro_view.setflags(write=False)
+    assert not aproj._immutable(ro_view)                           # its base can still be written
     other = view.copy()
     del vert, view
     gc.collect()

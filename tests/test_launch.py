@@ -1,0 +1,177 @@
+"""The torch-free launcher and control plane (alproj_amd/launch.py) that `python bench.py --gpus N` uses to start its own
+ranks: CPU tests with bench.py's stub worker (--launch-selftest: rendezvous of a 128-byte id, barriers, max over
+ranks, gather -- what a rank does around the real benchmark, without GPU or library)."""
+import json
+import os
+import re
+import socket
+import subprocess
+import sys
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from alproj_amd import launch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, timeout=120, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", launch.HUB_ENV, launch.KEY_ENV):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
+
+
+def _pids(stderr):
+    return [int(m) for m in re.findall(r"selftest: rank \d+ pid (\d+)", stderr)]
+
+
+def _gone(pids, within_s=10.0):
+    t0 = time.time()
+    while time.time() - t0 < within_s:
+        alive = []
+        for p in pids:
+            try:
+                os.kill(p, 0)
+                alive.append(p)
+            except ProcessLookupError:
+                pass
+        if not alive:
+            return True
+        time.sleep(0.1)
+    return False
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_bench_launches_its_own_ranks(n):
+    r = _run(["--gpus", str(n), "--launch-selftest"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1                                     # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["selftest"] and out["n_gpus"] == n and out["max_over_ranks"] == 10.0 + n - 1
+    ranks = out["ranks"]
+    assert [x["rank"] for x in ranks] == list(range(n)) and [x["local_rank"] for x in ranks] == list(range(n))
+    assert all(x["world"] == n and x["hub"] == "parent" for x in ranks)
+    assert all(x["env"] == {"RANK": str(i), "LOCAL_RANK": str(i), "WORLD_SIZE": str(n)} for i, x in enumerate(ranks))
+    assert len({x["uid_sha256"] for x in ranks}) == 1          # rank 0's 128 bytes reached everybody
+    assert len({x["pid"] for x in ranks}) == n and len({x["ppid"] for x in ranks}) == 1     # fresh children of one launcher
+    assert sorted(_pids(r.stderr)) == sorted(x["pid"] for x in ranks) and _gone(_pids(r.stderr))
+
+
+def test_a_failing_rank_ends_the_job_and_the_other_ranks():
+    r = _run(["--gpus", "3", "--launch-selftest", "--selftest-fail-rank", "1"])
+    assert r.returncode == 7, (r.returncode, r.stderr[-2000:])
+    assert not r.stdout.strip()                                # no JSON line from a failed job
+    assert "rank 1" in r.stderr and "exited with 7" in r.stderr
+    pids = _pids(r.stderr)
+    assert len(pids) == 3 and _gone(pids)
+
+
+def test_one_wall_clock_timeout_for_the_whole_job():
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--launch-selftest", "--selftest-hang-rank", "1", "--launch-timeout", "4"])
+    assert r.returncode == 124 and time.time() - t0 < 30, (r.returncode, r.stderr[-2000:])
+    pids = _pids(r.stderr)
+    assert len(pids) == 2 and _gone(pids)
+
+
+def test_gpus_1_needs_no_launcher_and_world_mismatch_is_refused():
+    r = _run(["--gpus", "1", "--launch-selftest"])
+    assert r.returncode == 0 and json.loads(r.stdout)["n_gpus"] == 1 and len(_pids(r.stderr)) == 1
+    r = _run(["--gpus", "2", "--launch-selftest"], env={"WORLD_SIZE": "1", "RANK": "0"})      # a launcher's ranks, wrong --gpus
+    assert r.returncode == 2
+
+
+def test_ranks_of_a_foreign_launcher_meet_at_rank_0(tmp_path):
+    """WORLD_SIZE already set (torch.distributed.run, or here: three plain children with its environment): rank 0 hosts
+    the hub and announces it through a file keyed by MASTER_ADDR / MASTER_PORT; the file is gone afterwards"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+    base = dict(os.environ, WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, TMPDIR=str(tmp_path))
+    base.pop(launch.HUB_ENV, None)
+    procs = [subprocess.Popen([sys.executable, BENCH, "--gpus", "3", "--launch-selftest"], cwd=ROOT,
+                              env=dict(base, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in (2, 0, 1)]                               # rank 0 is not the first to start
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0, 0], [o[1][-800:] for o in outs]
+    out = json.loads(outs[1][0])
+    assert out["n_gpus"] == 3 and all(x["hub"] == "rank0" for x in out["ranks"]) and len({x["uid_sha256"] for x in out["ranks"]}) == 1
+    assert not outs[0][0].strip() and not outs[2][0].strip()
+    assert not [f for f in os.listdir(tmp_path) if f.startswith("alproj_hub_")]
+
+
+def test_hub_collectives_in_process():
+    n = 4
+    hub = launch.Hub(n).start()
+    res = [None] * n
+
+    def rank(r):
+        conn = launch.Control._connect(lambda: (hub.address, hub.authkey), r, 30.0)
+        c = launch.Control(r, n, r, conn)
+        c.barrier()
+        got = (c.max(float(r)), c.bcast_bytes(bytes([r]) * 4), c.gather({"r": r}), c.bcast(("x", r)))
+        c.close()
+        res[r] = got
+
+    th = [threading.Thread(target=rank, args=(r,)) for r in range(n)]
+    [t.start() for t in th]
+    [t.join(30) for t in th]
+    hub.join(5)
+    assert hub.error is None and hub.collectives == 6
+    for got in res:
+        assert got == (3.0, b"\0\0\0\0", [{"r": i} for i in range(n)], ("x", 0))
+
+
+def test_a_vanished_rank_releases_the_others():
+    hub = launch.Hub(2).start()
+    err = []
+
+    def survivor():
+        c = launch.Control(0, 2, 0, launch.Control._connect(lambda: (hub.address, hub.authkey), 0, 30.0))
+        try:
+            c.barrier()
+        except launch.LaunchError as e:
+            err.append(str(e))
+
+    t = threading.Thread(target=survivor)
+    t.start()
+    gone = launch.Control._connect(lambda: (hub.address, hub.authkey), 1, 30.0)
+    gone.close()                                               # dies before its first collective
+    t.join(30)
+    hub.join(5)
+    assert err and "barrier failed" in err[0] and hub.error
+
+
+def test_single_rank_control_is_the_identity():
+    c = launch.Control()
+    assert (c.rank, c.world) == (0, 1)
+    c.barrier()
+    assert c.max(2.5) == 2.5 and c.bcast_bytes(b"ab") == b"ab" and c.gather(7) == [7]
+    c.close()
+
+
+def test_host_digest_sees_every_word_and_ignores_the_thread_count():
+    from alproj_amd import _lib
+    rng = np.random.default_rng(0)
+    a = rng.random(3_000_001)                                  # 24 MB: three slices, a ragged tail
+    d = _lib.host_hash64(a)
+    assert d == _lib.host_hash64(a, 1) == _lib.host_hash64(a, 3) == _lib.host_hash64(a.copy())
+    for i in (0, 1, 1_048_575, 1_048_576, 2_345_678, len(a) - 1):
+        b = a.copy()
+        b[i] = np.nextafter(b[i], 2.0)                         # one bit of one word
+        assert _lib.host_hash64(b) != d
+    u = rng.integers(0, 256, 1001, dtype=np.uint8)
+    du = _lib.host_hash64(u)
+    for i in (0, 500, 999, 1000):                              # the tail bytes beyond the last whole word too
+        v = u.copy()
+        v[i] ^= 1
+        assert _lib.host_hash64(v) != du
+    assert _lib.host_hash64(u[:0]) != _lib.host_hash64(np.zeros(1, np.uint8))
+    assert _lib.host_hash64(np.zeros(8, np.uint8)) != _lib.host_hash64(np.zeros(9, np.uint8))

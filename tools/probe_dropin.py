@@ -22,8 +22,8 @@ def t(label, fn, nbytes=None):
 
 for rep in range(2):
     print(f"--- rep {rep}")
-    t("fingerprint vert", lambda: aproj._fingerprint(vert))
-    t("fingerprint ind", lambda: aproj._fingerprint(ind))
+    t("digest vert", lambda: L.host_hash64(vert), vert.nbytes)
+    t("digest ind", lambda: L.host_hash64(ind), ind.nbytes)
     m = t("Mesh(vert f64, None, grid)", lambda: L.Mesh(vert, None, None, grid=(n, n)), vert.nbytes); m.close()
     m = t("Mesh(vert f64, col f64, grid)", lambda: L.Mesh(vert, col, None, grid=(n, n)), vert.nbytes + col.nbytes); m.close()
     m = t("Mesh(vert f64, None, ind int64)", lambda: L.Mesh(vert, None, ind), vert.nbytes + ind.nbytes); m.close()
