@@ -67,7 +67,7 @@
 // the full-frame path and the exact path without its culling.
 #if defined(ALP_WG_TIMING) || defined(ALP_RASTER_STATS) || defined(VIS_PLAIN_STORE) || defined(VIS_NEVER) || defined(PARK_NOATOMIC) || \
     defined(PARKED_SKIP_CELLS) || defined(PARKED_SKIP_COOP) || defined(PARKED_SKIP_COOP4) || defined(GRID_STOP_AFTER) ||               \
-    defined(GRID_NO_XCD_SWIZZLE)
+    defined(GRID_NO_XCD_SWIZZLE) || defined(PT_SKIP_CELLS) || defined(PT_SKIP_SMALL) || defined(PT_SKIP_LARGE) || defined(PARKED_TILES_LAB)
 #define ALP_DEV_SWITCHES 1
 #ifndef ALP_DEV
 #error "development switch given without -DALP_DEV: this would build a library that renders wrong images"
@@ -75,7 +75,7 @@
 #endif
 #if defined(INLINE_LOG2) || defined(FAST_MAX) || defined(COOP_MIN_W) || defined(COOP_MIN_PIX) || defined(GT_W_LOG2) || defined(GT_H_LOG2) || \
     defined(HIZ_SPAN) || defined(GRID_WAVES_PER_EU) || defined(PATCH_MIN_FAST) || defined(PATCH_WORDS_NEAR) || defined(PATCH_WORDS_FAR) ||    \
-    defined(RASTER_BLOCKS_PER_CU) || defined(RESOLVE_BLOCKS_PER_CU)
+    defined(RASTER_BLOCKS_PER_CU) || defined(RESOLVE_BLOCKS_PER_CU) || defined(PARKED_TILES_WGS_PER_CU)
 #define ALP_DEV_TUNABLES 1
 #ifndef ALP_DEV
 #error "tuning parameter overridden without -DALP_DEV"
@@ -110,6 +110,12 @@ const char *raster_dev_flags() {
 #if defined(PARKED_SKIP_CELLS) || defined(PARKED_SKIP_COOP) || defined(PARKED_SKIP_COOP4)
            "PARKED_SKIP_*(wrong image),"
 #endif
+#ifdef PARKED_TILES_LAB
+           "PARKED_TILES_LAB,"
+#endif
+#if defined(PT_SKIP_CELLS) || defined(PT_SKIP_SMALL) || defined(PT_SKIP_LARGE)
+           "PT_SKIP_*(wrong image),"
+#endif
 #ifdef GRID_STOP_AFTER
            "GRID_STOP_AFTER(wrong image),"
 #endif
@@ -123,6 +129,13 @@ const char *raster_dev_flags() {
 static const char *dev_getenv(const char *name) { return getenv(name); }
 #else
 static const char *dev_getenv(const char *) { return nullptr; }
+#endif
+
+#ifndef PARKED_BY_TILES_DEFAULT
+#define PARKED_BY_TILES_DEFAULT 0       // 1: raster_parked_tiles_kernel draws the first round's parked work (ALP_PARKED=tiles / waves overrides)
+#endif
+#ifndef PARKED_TILES_WGS_PER_CU
+#define PARKED_TILES_WGS_PER_CU 4       // persistent grid: 32 KB of LDS per workgroup
 #endif
 
 // The stages, in dependency order (one translation unit: the kernels inline each other's device functions):
@@ -389,10 +402,28 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
             ALP_HIP(hipGetLastError());
             return ALP_OK;
         };
+        // how the first round's parked work is drawn: by queue entry (raster_parked_kernel) or by tile through LDS depth
+        // patches (raster_parked_tiles_kernel); the same image either way
+        bool by_tiles = false;
+#ifdef PARKED_TILES_LAB
+        if constexpr (IMPLICIT) {
+            const char *e = dev_getenv("ALP_PARKED");
+            by_tiles = e ? e[0] == 't' : PARKED_BY_TILES_DEFAULT != 0;
+        }
+#endif
         auto drain_parked = [&](int round) -> int {
             unsigned *items = fcount + QC_STRIDE * round;
             const unsigned *cap = round ? m->park_cap_b : m->park_cap;
             const int wgs = round ? cu * 2 : cu * 8;
+#ifdef PARKED_TILES_LAB
+            if (round == 0 && by_tiles) {
+                hipLaunchKernelGGL(raster_parked_tiles_kernel, dim3(cu * PARKED_TILES_WGS_PER_CU), dim3(256), 0, st, v, m->vis, m->park_small,
+                                   m->park_large, m->park_cell, items + 2, cap[0], cap[1], cap[2], m->park_tiles, m->park_units,
+                                   m->park_units_cap);
+                ALP_HIP(hipGetLastError());
+                return ALP_OK;
+            }
+#endif
             hipLaunchKernelGGL(raster_parked_kernel, dim3(wgs), dim3(256), 0, st, v, m->vis,
                                m->park_small + (round ? m->park_cap[0] : 0), m->park_large + (round ? m->park_cap[1] : 0),
                                m->park_cell + (round ? m->park_cap[2] : 0), items + 2, cap[0], cap[1], cap[2]);
@@ -408,6 +439,21 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
             }
             const int tiles_x = (int)((m->grid_w - 1 + GT_W - 1) / GT_W);
             const long long tiles = (long long)tiles_x * ((m->grid_h - 1 + GT_H - 1) / GT_H);
+            if (by_tiles && !m->park_tiles) {
+                // one record per tile at most; units: a frame of the 100 M-vertex DSM makes ~45 k (grown on overflow, finish_frame)
+                const unsigned ucap = std::max(m->park_units_cap, (unsigned)std::min<long long>(std::max<long long>(tiles, 1 << 16), 1 << 22));
+                ParkedTile *pt = nullptr;
+                ParkedUnit *pu = nullptr;
+                if (hipMalloc((void **)&pt, (size_t)tiles * sizeof(ParkedTile)) != hipSuccess ||
+                    hipMalloc((void **)&pu, (size_t)ucap * sizeof(ParkedUnit)) != hipSuccess) {
+                    if (pt) hipFree(pt);
+                    return fail(ALP_EHIP, "allocation of the parked-tile records failed");
+                }
+                m->park_tiles = pt;
+                m->park_units = pu;
+                m->park_tiles_cap = (unsigned)tiles;
+                m->park_units_cap = ucap;
+            }
             if (!m->tile_bounds) {      // once per mesh: the vertices never change
                 // published only when both allocations and the launch succeeded: a half-made plan must not
                 // make the next frame skip this block and read uninitialised boxes
@@ -451,7 +497,8 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
             hipLaunchKernelGGL(raster_grid_kernel, dim3(grid_wgs), dim3(256), (size_t)patch_near * 8, st, m->vert, m->valid,
                                (int)m->grid_h, (int)m->grid_w, v, m->vis, m->gqueue, fcount + 1, m->gcap,
                                along_rows, near_list, counts + 0, m->park_small, m->park_large, m->park_cell,
-                               fcount + 2, m->park_cap[0], m->park_cap[1], m->park_cap[2], patch_near);
+                               fcount + 2, m->park_cap[0], m->park_cap[1], m->park_cap[2], patch_near,
+                               by_tiles ? m->park_tiles : nullptr, m->park_units, m->park_units_cap);
             ALP_HIP(hipGetLastError());
 #ifdef ALP_WG_TIMING
             {   // duration of every workgroup of the first round
@@ -511,12 +558,32 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
                                    (int)m->grid_h, (int)m->grid_w, v, m->vis, m->gqueue, fcount + 1, m->gcap,
                                    along_rows, second_list, counts + 2, m->park_small + m->park_cap[0],
                                    m->park_large + m->park_cap[1], m->park_cell + m->park_cap[2], fcount + QC_STRIDE + 2,
-                                   m->park_cap_b[0], m->park_cap_b[1], m->park_cap_b[2], patch_far);
+                                   m->park_cap_b[0], m->park_cap_b[1], m->park_cap_b[2], patch_far, (ParkedTile *)nullptr,
+                                   (ParkedUnit *)nullptr, 0u);
                 ALP_HIP(hipGetLastError());
                 if (int e = drain_rare(0)) return e;
                 if (int e = drain_parked(1)) return e;
             }
 #ifdef ALP_RASTER_STATS
+            if (by_tiles) {      // census of the parked-tile records: how many bin passes, how full
+                unsigned pc[8];
+                ALP_HIP(hipStreamSynchronize(st));
+                ALP_HIP(hipMemcpy(pc, fcount, sizeof(pc), hipMemcpyDeviceToHost));
+                std::vector<ParkedTile> rr(pc[7]);
+                if (pc[7]) ALP_HIP(hipMemcpy(rr.data(), m->park_tiles, rr.size() * sizeof(ParkedTile), hipMemcpyDeviceToHost));
+                long long bins = 0, area = 0, ent[3] = {0, 0, 0}, hist[8] = {0, 0, 0, 0, 0, 0, 0, 0}, scan = 0;
+                for (const ParkedTile &r : rr) {
+                    const int nb = (((r.i1 - (r.i0 & ~7)) >> 6) + 1) * (((r.j1 - r.j0) >> 6) + 1);
+                    bins += nb;
+                    area += (long long)(r.i1 - r.i0 + 1) * (r.j1 - r.j0 + 1);
+                    for (int k = 0; k < 3; ++k) ent[k] += r.n[k];
+                    scan += (long long)nb * (r.n[0] + r.n[1] + r.n[2]);
+                    ++hist[nb <= 1 ? 0 : nb <= 2 ? 1 : nb <= 4 ? 2 : nb <= 8 ? 3 : nb <= 16 ? 4 : nb <= 32 ? 5 : nb <= 128 ? 6 : 7];
+                }
+                fprintf(stderr, "[parked tiles] records %u units %u | bins %lld (box area %lld px) | entries small %lld large %lld cells %lld | "
+                                "entry scans over all passes %lld | records by bins <=1 %lld, 2 %lld, <=4 %lld, <=8 %lld, <=16 %lld, <=32 %lld, <=128 %lld, more %lld\n",
+                        pc[7], pc[6], bins, area, ent[0], ent[1], ent[2], scan, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7]);
+            }
             {
                 unsigned hc[4];
                 ALP_HIP(hipMemcpyAsync(hc, counts, sizeof(hc), hipMemcpyDeviceToHost, st));
@@ -622,7 +689,15 @@ int finish_frame(alp_mesh *m) {
             if (m->park_small && h[2 + k] > m->park_cap[k]) { park_ok = false; want_a[k] = h[2 + k] + h[2 + k] / 4 + 1024; }
             if (m->park_small && h[QC_STRIDE + 2 + k] > m->park_cap_b[k]) { park_ok = false; want_b[k] = h[QC_STRIDE + 2 + k] + h[QC_STRIDE + 2 + k] / 4 + 1024; }
         }
-        if (items <= m->qcap && general <= m->gcap && park_ok) break;
+        const bool units_ok = !m->park_units || h[6] <= m->park_units_cap;      // [6]: units the first round's tiles asked for
+        if (items <= m->qcap && general <= m->gcap && park_ok && units_ok) break;
+        if (!units_ok) {
+            hipFree(m->park_tiles);
+            hipFree(m->park_units);
+            m->park_tiles = nullptr;
+            m->park_units = nullptr;
+            m->park_units_cap = h[6] + h[6] / 4 + 1024;      // reallocated by the frame below
+        }
         if (!park_ok) {
             for (int k = 0; k < 3; ++k) m->park_cap_b[k] = want_b[k];
             m->park_cap[0] = 0;           // force the reallocation
@@ -889,7 +964,7 @@ int alp_mesh_destroy(alp_mesh_t *m) {
                     (void *)m->tri_present, (void *)m->tri_rank, (void *)m->vis, (void *)m->image,
                     (void *)m->queue, (void *)m->gqueue, (void *)m->qcount_dev, (void *)m->compact_counts, (void *)m->compact_offsets,
                     (void *)m->tile_bounds, (void *)m->tile_lists, (void *)m->hiz, (void *)m->park_small, (void *)m->park_cell,
-                    (void *)m->rz_points, (void *)m->rz_work})
+                    (void *)m->rz_points, (void *)m->rz_work, (void *)m->park_tiles, (void *)m->park_units})
         if (p) hipFree(p);
     if (m->qcount_host) hipHostFree(m->qcount_host);
     for (auto &e : m->ev_frame)

@@ -39,6 +39,22 @@ struct alignas(16) ParkedCell {
     unsigned pad[3];
 };
 
+// What ONE tile (workgroup) of raster_grid_kernel parked, for raster_parked_tiles_kernel: its contiguous ranges in the
+// three queues and the pixel box (clamped to the viewport) of everything in them.  The consumer covers that box with
+// PT_BIN x PT_BIN-pixel LDS depth patches; a unit = (tile record, slot): the bins slot, slot + nslots, ... of the tile.
+struct ParkedTile {
+    unsigned base[3];          // first entry: small triangles, large triangles, cells
+    unsigned n[3];
+    int i0, j0, i1, j1;
+    unsigned pad[2];
+};
+struct ParkedUnit {
+    unsigned rec;
+    unsigned short slot, nslots;
+};
+constexpr int PT_BIN = 64;            // 4096 words of 8 bytes = 32 KB of LDS per workgroup
+constexpr int PT_MAX_UNITS = 32;      // a tile's bins are dealt to at most this many units (the nearest tiles cover 100+ bins)
+
 }  // namespace alp
 
 struct alp_mesh {
@@ -69,6 +85,9 @@ struct alp_mesh {
     alp::ParkedCell *park_cell = nullptr;                         // implicit grid: parked cells
     unsigned park_cap[3] = {0, 0, 0};                             // small, large, cells: first round
     unsigned park_cap_b[3] = {0, 0, 0};                           // second round (its entries follow the first round's)
+    alp::ParkedTile *park_tiles = nullptr;                        // first round: one record per tile that parked something
+    alp::ParkedUnit *park_units = nullptr;
+    unsigned park_tiles_cap = 0, park_units_cap = 0;
     // per round (2 rounds x QC_STRIDE) [0] work items, [1] general entries, [2] small parked, [3] large parked,
     // [4] parked cells; then the three tile-list lengths of the frame plan
     unsigned *qcount_dev = nullptr;

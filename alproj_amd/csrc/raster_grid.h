@@ -22,7 +22,8 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
                         const unsigned *__restrict__ tile_list, const unsigned *__restrict__ tile_count,
                         Deferred *__restrict__ park_small, Deferred *__restrict__ park_large,
                         ParkedCell *__restrict__ park_cell, unsigned *__restrict__ park_counts, unsigned park_cap_small,
-                        unsigned park_cap_large, unsigned park_cap_cell, int patch_cap) {
+                        unsigned park_cap_large, unsigned park_cap_cell, int patch_cap,
+                        ParkedTile *__restrict__ park_tiles, ParkedUnit *__restrict__ park_units, unsigned park_units_cap) {
     // s_xy[].x of a vertex without window coordinates: behind the near plane / outside the
     // fixed-point range / masked out (nodata: its triangles do not exist, surface.py:203-205)
     constexpr int BEHIND = INT_MIN, RANGE = INT_MIN + 1, NODATA = INT_MIN + 2;
@@ -34,6 +35,10 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
     // triangles, so 2 * GT_NC entries always suffice)
     __shared__ unsigned short s_park[2 * GT_NC];
     __shared__ unsigned s_nfast, s_nslow, s_npark[3], s_park_base[3];
+#ifdef PARKED_TILES_LAB
+    __shared__ int s_pbb[4];              // pixel box of everything parked (park_tiles)
+    __shared__ unsigned s_unit0, s_rec, s_nunits;
+#endif
     // the tile's depth patch (dynamic LDS, patch_cap words): see phase 3
     extern __shared__ unsigned long long s_patch[];
     __shared__ int s_wbb[4][4];
@@ -61,6 +66,9 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
         s_npark[0] = 0;
         s_npark[1] = 0;
         s_npark[2] = 0;
+#ifdef PARKED_TILES_LAB
+        s_pbb[0] = INT_MAX; s_pbb[1] = INT_MIN; s_pbb[2] = INT_MAX; s_pbb[3] = INT_MIN;
+#endif
     }
     // ---- phase 1: vertices.  Every load of the thread's (up to) GT_VPT vertices is issued before the
     // first one is used: ONE memory round trip per tile instead of one per vertex (the round trip is what
@@ -438,12 +446,21 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
         s_park_base[threadIdx.x] = cnt ? atomicAdd(park_counts + threadIdx.x, cnt) : 0u;
     }
     __syncthreads();
+#ifdef PARKED_TILES_LAB
+    int pb_x0 = INT_MAX, pb_x1 = INT_MIN, pb_y0 = INT_MAX, pb_y1 = INT_MIN;      // snapped extent of this thread's parked entries
+#endif
     for (unsigned e = threadIdx.x; e < ncell; e += 256) {
         const int id = (int)s_park[e];
         int lr, lc;
         cell_rc(id, lr, lc);
         const int ia = lr * GT_VW + lc, ib = ia + GT_VW, ic = ib + 1, idd = ia + 1;
         const int2 A = s_xy[ia], B = s_xy[ib], C = s_xy[ic], D = s_xy[idd];
+#ifdef PARKED_TILES_LAB
+        pb_x0 = min(pb_x0, min(min(A.x, B.x), min(C.x, D.x)));
+        pb_x1 = max(pb_x1, max(max(A.x, B.x), max(C.x, D.x)));
+        pb_y0 = min(pb_y0, min(min(A.y, B.y), min(C.y, D.y)));
+        pb_y1 = max(pb_y1, max(max(A.y, B.y), max(C.y, D.y)));
+#endif
 #ifdef ALP_RASTER_STATS
         {   // census of the parked cells' boxes
             const int minx = min(min(A.x, B.x), min(C.x, D.x)), maxx = max(max(A.x, B.x), max(C.x, D.x));
@@ -476,6 +493,12 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
         const int ia = lr * GT_VW + lc, ib = ia + GT_VW, ic = ib + 1, idd = ia + 1;
         const int k1 = half ? ic : ib, k2 = half ? idd : ic;
         const int2 A = s_xy[ia], B = s_xy[k1], C = s_xy[k2];
+#ifdef PARKED_TILES_LAB
+        pb_x0 = min(pb_x0, min(A.x, min(B.x, C.x)));
+        pb_x1 = max(pb_x1, max(A.x, max(B.x, C.x)));
+        pb_y0 = min(pb_y0, min(A.y, min(B.y, C.y)));
+        pb_y1 = max(pb_y1, max(A.y, max(B.y, C.y)));
+#endif
         Deferred d;
         d.X[0] = A.x; d.X[1] = B.x; d.X[2] = C.x;
         d.Y[0] = A.y; d.Y[1] = B.y; d.Y[2] = C.y;
@@ -485,6 +508,51 @@ void raster_grid_kernel(const float *__restrict__ vert, const unsigned char *__r
         Deferred *queue = large ? park_large : park_small;
         if (slot < (large ? park_cap_large : park_cap_small)) queue[slot] = d;    // an overflow is noticed by finish_frame
     }
+#ifdef PARKED_TILES_LAB
+    if (park_tiles) {
+        // the tile's record for raster_parked_tiles_kernel: where its entries are and which pixels they can touch;
+        // record slot and first unit come from ONE 64-bit add (units in the low word), so both run in the same order
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            pb_x0 = min(pb_x0, __shfl_xor(pb_x0, m, 64));
+            pb_x1 = max(pb_x1, __shfl_xor(pb_x1, m, 64));
+            pb_y0 = min(pb_y0, __shfl_xor(pb_y0, m, 64));
+            pb_y1 = max(pb_y1, __shfl_xor(pb_y1, m, 64));
+        }
+        if (lane == 0 && pb_x0 <= pb_x1) {
+            atomicMin(&s_pbb[0], pb_x0); atomicMax(&s_pbb[1], pb_x1);
+            atomicMin(&s_pbb[2], pb_y0); atomicMax(&s_pbb[3], pb_y1);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            ParkedTile r;
+            r.base[0] = s_park_base[0]; r.base[1] = s_park_base[1]; r.base[2] = s_park_base[2];
+            r.n[0] = np_small; r.n[1] = np_large; r.n[2] = ncell;
+            r.i0 = max((s_pbb[0] + SUB / 2 - 1) >> 8, 0); r.i1 = min((s_pbb[1] - SUB / 2) >> 8, v.w - 1);
+            r.j0 = max((s_pbb[2] + SUB / 2 - 1) >> 8, 0); r.j1 = min((s_pbb[3] - SUB / 2) >> 8, v.h - 1);
+            r.pad[0] = r.pad[1] = 0;
+            unsigned nun = 0;
+            if (r.i1 >= r.i0 && r.j1 >= r.j0) {
+                const int nb = (((r.i1 - (r.i0 & ~7)) >> 6) + 1) * (((r.j1 - r.j0) >> 6) + 1);
+                nun = (unsigned)min(nb, PT_MAX_UNITS);
+            }
+            s_nunits = nun;
+            if (nun) {
+                const unsigned long long old = atomicAdd((unsigned long long *)(park_counts + 4), (1ull << 32) | (unsigned long long)nun);
+                s_unit0 = (unsigned)old;
+                s_rec = (unsigned)(old >> 32);
+                park_tiles[(unsigned)(old >> 32)] = r;         // at most one record per listed tile: the array holds them all
+            }
+        }
+        __syncthreads();
+        for (unsigned k = threadIdx.x; k < s_nunits; k += 256)
+            if (s_unit0 + k < park_units_cap) {                // an overflow is noticed by finish_frame
+                ParkedUnit u;
+                u.rec = s_rec; u.slot = (unsigned short)k; u.nslots = (unsigned short)s_nunits;
+                park_units[s_unit0 + k] = u;
+            }
+    }
+#endif
 #ifdef ALP_WG_TIMING
     __syncthreads();
 #endif

@@ -40,6 +40,7 @@ mesh on the device between calls:
 At an unchanged pose only the resolve stage runs (the library's visibility cache).
 """
 import math
+import threading
 import time
 import warnings
 import weakref
@@ -129,11 +130,27 @@ def _resident_mesh(vert, value, ind, grid_shape):
         return mesh, False
     clear_mesh_cache()                                  # before the new upload: both would not have to fit
     t1 = time.perf_counter()
-    keys = dict(vert=_key(vert), ind=_key(ind), value=_key(value) if isinstance(value, np.ndarray) else None)
-    t2 = time.perf_counter()
-    mesh = _lib.Mesh(vert, value, ind, grid_shape)
+    # the digests are taken by host threads WHILE the arrays cross PCIe (both calls release the GIL); the caller cannot
+    # edit the arrays in between: this call has not returned yet
+    keys, err = {}, []
+
+    def digest():
+        try:
+            keys.update(vert=_key(vert), ind=_key(ind), value=_key(value) if isinstance(value, np.ndarray) else None)
+        except BaseException as e:          # reported below, in the caller's thread
+            err.append(e)
+
+    th = threading.Thread(target=digest)
+    th.start()
+    try:
+        mesh = _lib.Mesh(vert, value, ind, grid_shape)
+    finally:
+        th.join()
+    if err:
+        mesh.close()
+        raise err[0]
     c.update(mesh=mesh, grid=grid_shape, **keys)
-    LAST_CACHE.update(hit=False, verify_s=t1 - t0, digest_s=t2 - t1)
+    LAST_CACHE.update(hit=False, verify_s=t1 - t0, upload_and_digest_s=time.perf_counter() - t1)
     return mesh, False
 
 

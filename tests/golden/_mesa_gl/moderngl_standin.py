@@ -283,7 +283,9 @@ class VertexArray:
             in vec3 v_color;
             in float v_distance;
             layout(location=0) out vec4 f_color;
-            void main() { f_color = vec4(float(gl_PrimitiveID + 1), v_distance, gl_FragCoord.z, 1.0); }
+            // the id in two exactly representable halves: one float32 holds integers up to 2^24 only, and the c4-sized
+            // draw has 72 M triangles
+            void main() { int id = gl_PrimitiveID + 1; f_color = vec4(float(id & 0xFFFFF), v_distance, float(id >> 20), 1.0); }
         """)
         for k in ("proj", "view"):
             idp[k].value = self.program._values[k]
@@ -296,9 +298,8 @@ class VertexArray:
         _gl("glBindVertexArray", va2.glo)
         _gl("glDrawElements", GL_TRIANGLES, self.n_indices, GL_UNSIGNED_INT, None)
         img = np.frombuffer(fb2.read(dtype="f4"), dtype=np.float32).reshape(h, w, 3)
-        LAST["prim_id"] = np.rint(img[:, :, 0]).astype(np.int64) - 1      # -1 = nothing drawn
+        LAST["prim_id"] = (np.rint(img[:, :, 0]).astype(np.int64) | (np.rint(img[:, :, 2]).astype(np.int64) << 20)) - 1      # -1 = nothing drawn
         LAST["frag_distance"] = img[:, :, 1].copy()
-        LAST["frag_z"] = img[:, :, 2].copy()
         va2.release(), fb2.release(), rb.release(), db.release(), idp.release()
         fbo.use()
         _gl("glBindVertexArray", self.glo)

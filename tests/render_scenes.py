@@ -92,7 +92,7 @@ def _big_cells_scene():
 
 # scenes whose fixture keeps gl_PrimitiveID for every pixel but GL's image only on every IMAGE_STRIDE-th pixel of both
 # axes (the frame is large; the values are asserted on that subset)
-IMAGE_STRIDE = {"grid_big_cells": 4}
+IMAGE_STRIDE = {"grid_big_cells": 4, "c4_frame_36m": 16}
 
 LENS = dict(a1=1.03, a2=0.97, k1=-0.06, k2=0.012, k3=0.002, k4=0.004, k5=-0.001, k6=0.0005, p1=0.0015, p2=-0.002,
             s1=0.0006, s2=-0.0002, s3=-0.0004, s4=0.0001)
@@ -105,6 +105,24 @@ def _lens_scene():
     s["params"] = dict(s["params"], **LENS)
     return s
 
+
+def _c4_frame_scene():
+    """BASELINE config 4 at the reference's own sizes: the 5616 x 3744 frame (example.py:22) over a 6000 x 6000 = 36 M-vertex
+    surface at 1 m (distance 3000, example.py:25; the grid of examples/pipeline_synthetic.py), the pose of bench.py's render
+    leg (camera over the centre of the west edge, fov 75, pan 95) 450 m above the ground and 10 degrees down: 72 M triangles
+    at 0.5 ... 6 km -- cells of 8 px (parked cells, LDS depth patches) in the foreground, 5 px at the median pixel, under a
+    pixel towards the horizon; every second visible pixel shows a triangle of its own; 38 % of the frame is sky"""
+    n, w, h = 6000, 5616, 3744
+    s = syn.surface(n)
+    p = dict(syn.base_params(n), w=w, h=h, cx=w / 2.0, cy=h / 2.0, tilt=-10.0)
+    p["z"] += 400.0
+    return dict(vert=s["vert"], ind=None, grid=(n, n), params=p, offsets=s["offsets"])
+
+
+# the c4-sized fixture (tests/golden/gen_golden_gl_c4.py -> g16_gl_c4_frame.npz) keeps gl_PrimitiveID on every PRIM_STRIDE-th
+# pixel of both window axes and GL's image on every IMAGE_STRIDE-th
+C4_SCENES = {"c4_frame_36m": _c4_frame_scene}
+PRIM_STRIDE = {"c4_frame_36m": 8}
 
 GL_SCENES = dict(SCENES)
 GL_SCENES.update({
