@@ -106,6 +106,8 @@ _SIGNATURES = {
     "alp_distance_mask": [_c_dp, _c_i64, _c_dp, _c_double, _c_double, ctypes.POINTER(ctypes.c_uint8)],
     "alp_rasterize_points": [_c_dp, _c_dp, _c_dp, _c_i64, _c_i64, _c_double, _c_double, _c_double, _c_i64, _c_i64,
                              _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_uint8)],
+    "alp_rasterize_points_f32": [_c_dp, _c_dp, _c_dp, _c_i64, _c_i64, _c_double, _c_double, _c_double, _c_i64, _c_i64,
+                                 _c_int, _c_int, _c_fp],
     "alp_render_rasterize_plan": [_c_void_p, _c_dp, ctypes.POINTER(_c_i64), _c_dp],
     "alp_render_rasterize": [_c_void_p, _c_void_p, _c_int, _c_i64, ctypes.POINTER(ctypes.c_int32), _c_i64, _c_double, _c_double,
                              _c_double, _c_i64, _c_i64, _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_uint8)],
@@ -608,6 +610,29 @@ def distance_mask(xyz, camera, min_distance=None, max_distance=None):
                                   float("nan") if max_distance is None else float(max_distance),
                                   keep.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))))
     return keep.astype(bool)
+
+
+AGG_CODES = {"mean": 0, "max": 1, "min": 2, "median": 3}
+
+
+def rasterize_points_f32(x, y, values, resolution=1.0, interpolate=True, max_dist=1.0, agg_func="mean"):
+    """The float32 raster (bands, height, width) of the reference's to_geotiff before its byte conversion (project.py:448-479;
+    NaN = empty cell) for points x, y (n,) with band values (n, bands): alp_rasterize_points_f32.  -> (raster, bounds)"""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    if values.ndim != 2 or values.shape[0] != len(x) or len(y) != len(x):
+        raise ValueError("x, y (n,) and values (n, bands) expected")
+    x_min, x_max, y_min, y_max = x.min(), x.max(), y.min(), y.max()
+    width = int(np.ceil((x_max - x_min) / resolution))
+    height = int(np.ceil((y_max - y_min) / resolution))
+    if width <= 0 or height <= 0:
+        raise ValueError(f"Invalid raster dimensions: width={width}, height={height}")
+    sweeps = int(np.ceil(max_dist / resolution)) if (interpolate and max_dist > 0) else 0
+    out = np.empty((values.shape[1], height, width), dtype=np.float32)
+    check(lib().alp_rasterize_points_f32(as_dp(x), as_dp(y), as_dp(values), len(x), values.shape[1], float(x_min), float(y_max),
+                                         float(resolution), width, height, AGG_CODES[agg_func], sweeps, as_fp(out)))
+    return out, (x_min, y_min, x_max, y_max, width, height)
 
 
 def distort_image(img, coeffs):

@@ -12,10 +12,14 @@
 //   project.py:483-485  NaN -> nodata, clip to [0, 255], truncate to uint8
 // The GeoTIFF file itself (rasterio) stays on the host side of the ABI.
 //
-// Kernels: scatter (float64 atomics per band: sum+count, or ordered-integer max/min),
-// finalize (float32 raster), focal sweep (ping-pong), uint8 conversion.  The 3x3 mean adds its
-// window in numpy's order (pairwise block of 8, then the ninth) so that the float64 sum -- and
-// with it the float32 value and the truncated byte -- match the reference.
+// Kernels (round 4: sort-based, no atomics, no accumulators): the cell of every point, ONE stable radix sort of (cell, point)
+// shared by all bands, then a thread per run of equal cells walks its points IN THEIR ORIGINAL ORDER and forms pandas'
+// aggregate -- for the mean the Kahan-compensated float64 sum of libgroupby's group_mean, so that the float64 value, its
+// float32 cast and the truncated byte are the reference's for ANY band values, not only for byte-valued ones (the atomics of
+// rounds 2-3 added in arrival order: exact for integers below 2^53, one ulp off for general floats); the median sorts one
+// composite 64-bit key (cell : order-preserving float32 value) per band.  Then the fused tail (float32 raster -> focal
+// sweeps in LDS -> bytes) or, for more than RZ_SMAX sweeps, separate sweep / conversion kernels.  The 3x3 mean adds its
+// window in numpy's order (pairwise block of 8, then the ninth).
 #include "alp_raster_internal.h"
 
 #include <algorithm>
@@ -42,92 +46,128 @@ __device__ __forceinline__ double ord2d(unsigned long long o) {
     return __longlong_as_double((long long)u);
 }
 
-// Points arrive in the pixel order of the camera image, so neighbouring lanes of a wave mostly fall into the same
-// raster cell (near the camera hundreds of pixels share a 1 m cell): every RUN of equal cells inside a wave is reduced
-// with a segmented shuffle reduction first and only its first lane goes to memory -- one float64 atomic and one count
-// atomic per run and band instead of per point (the per-point version spent 2.7 ... 8 ms on 11.7 M points x 3 bands,
-// serialised on the hot cells).  Sums of a cell are formed in another order than point by point; the aggregates the
-// reference forms are order-free for max / min and, for the byte-valued channels the path carries, exact for mean.
-template <int AGG>
-__global__ __launch_bounds__(256) void rz_scatter_kernel(const double *__restrict__ x, const double *__restrict__ y,
-                                                         const double *__restrict__ values, long long n, int nb,
-                                                         double x_min, double y_max, double res, int width,
-                                                         int height, double *__restrict__ acc,
-                                                         unsigned *__restrict__ cnt) {
+// cell (row * width + col, project.py:435-436) and index of every point
+__global__ __launch_bounds__(256) void rz_cell_kernel(const double *__restrict__ x, const double *__restrict__ y, long long n,
+                                                      double x_min, double y_max, double res, int width, int height,
+                                                      unsigned *__restrict__ cell, unsigned *__restrict__ idx) {
     const long long stride = (long long)gridDim.x * blockDim.x;
-    const long long hw = (long long)width * height;
-    const int lane = (int)(threadIdx.x & 63);
-    const long long rounds = (n + stride - 1) / stride;                 // every lane makes every round: the shuffles are wave-wide
-    for (long long k = 0; k < rounds; ++k) {
-        const long long i = k * stride + (long long)blockIdx.x * blockDim.x + threadIdx.x;
-        const bool in = i < n;
-        long long cell = -1 - lane;                                      // lanes past the end: runs of their own, never stored
-        if (in) {
-            long long col = (long long)((x[i] - x_min) / res);
-            long long row = (long long)((y_max - y[i]) / res);
-            col = col < 0 ? 0 : (col > width - 1 ? width - 1 : col);
-            row = row < 0 ? 0 : (row > height - 1 ? height - 1 : row);
-            cell = row * width + col;
-        }
-        const long long prev = __shfl_up(cell, 1);
-        const bool head = lane == 0 || prev != cell;
-        const unsigned long long heads = __ballot(head);
-        const int run = __popcll(heads & (~0ull >> (63 - lane)));        // run number of this lane (1-based, monotone)
-        int same[6];                                                     // does lane + 2^j belong to this lane's run?
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int r2 = __shfl_down(run, 1 << j);
-            same[j] = (lane + (1 << j) < 64) && r2 == run;
-        }
-        for (int b = 0; b < nb; ++b) {
-            const double val = in ? values[i * nb + b] : __longlong_as_double(0x7ff8000000000000ll);
-            const bool ok = val == val;                                  // pandas skips NaN
-            unsigned c = ok ? 1u : 0u;
-            if constexpr (AGG == AGG_MEAN) {
-                double sum = ok ? val : 0.0;
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    const double s2 = __shfl_down(sum, 1 << j);
-                    const unsigned c2 = __shfl_down(c, 1 << j);
-                    if (same[j]) { sum += s2; c += c2; }
-                }
-                if (head && c) {
-                    atomicAdd(&acc[b * hw + cell], sum);
-                    atomicAdd(&cnt[b * hw + cell], c);
-                }
-            } else {
-                unsigned long long key = ok ? d2ord(val) : (AGG == AGG_MAX ? 0ull : ~0ull);      // the identities of max / min
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    const unsigned long long k2 = __shfl_down(key, 1 << j);
-                    const unsigned c2 = __shfl_down(c, 1 << j);
-                    if (same[j]) {
-                        key = (AGG == AGG_MAX) ? (k2 > key ? k2 : key) : (k2 < key ? k2 : key);
-                        c += c2;
-                    }
-                }
-                if (head && c) {
-                    if constexpr (AGG == AGG_MAX) atomicMax(reinterpret_cast<unsigned long long *>(&acc[b * hw + cell]), key);
-                    else atomicMin(reinterpret_cast<unsigned long long *>(&acc[b * hw + cell]), key);
-                    atomicAdd(&cnt[b * hw + cell], c);
-                }
-            }
-        }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        long long col = (long long)((x[i] - x_min) / res);
+        long long row = (long long)((y_max - y[i]) / res);
+        col = col < 0 ? 0 : (col > width - 1 ? width - 1 : col);
+        row = row < 0 ? 0 : (row > height - 1 ? height - 1 : row);
+        cell[i] = (unsigned)(row * width + col);
+        idx[i] = (unsigned)i;
     }
 }
 
+// Runs of equal cell in the (stably) cell-sorted order: the points of a run are the rows of one pandas group in their
+// original order.  Each run is aggregated band by band, skipping NaN like pandas does:
+//   mean   libgroupby.group_mean: Kahan summation  y = v - c; t = s + y; c = (t - s) - y; s = t  (c reset to 0 when it
+//          turns NaN: an infinite value), then s / count -- checked against pandas 2.3 bit for bit (tests)
+//   max / min   order-free
+// and its float32 cast (project.py:459) goes into the NaN-filled raster.  The recurrence is sequential, the loads need not
+// be: a WAVE owns 64 consecutive sorted positions; runs of at most RZ_SHORT points that end inside them are walked by their
+// head lane (most cells of a georectified photograph hold one or two pixels), every other run -- next to the camera
+// hundreds or thousands of pixels share a cell -- by the whole wave: 64 points loaded at once, then the recurrence over
+// them with the operands broadcast from lane to lane (a thread walking such a run alone waits for one gather per point:
+// measured 2.9 ms for the 11.7 M points of the 100 M-vertex frame, of which the long runs were nearly all).
+constexpr int RZ_SHORT = 6, RZ_BG = 4;      // bands are taken RZ_BG at a time (their state lives in registers)
+
 template <int AGG>
-__global__ __launch_bounds__(256) void rz_finalize_kernel(const double *__restrict__ acc, const unsigned *__restrict__ cnt,
-                                                          long long total, float *__restrict__ raster) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const unsigned c = cnt[i];
-        float r = __int_as_float(0x7fc00000);                 // NaN
-        if (c) {
-            if constexpr (AGG == AGG_MEAN) r = (float)(acc[i] / (double)c);
-            else r = (float)ord2d(reinterpret_cast<const unsigned long long *>(acc)[i]);
+struct RzAcc {
+    double s = 0.0, comp = 0.0, m = AGG == AGG_MAX ? -INFINITY : INFINITY;
+    long long cnt = 0;
+    __device__ __forceinline__ void take(double v) {
+        if (v != v) return;
+        ++cnt;
+        if constexpr (AGG == AGG_MEAN) {
+            const double yv = v - comp, t = s + yv;
+            comp = (t - s) - yv;
+            if (comp != comp) comp = 0.0;
+            s = t;
+        } else if constexpr (AGG == AGG_MAX) {
+            m = v > m ? v : m;
+        } else {
+            m = v < m ? v : m;
         }
-        raster[i] = r;
+    }
+    __device__ __forceinline__ float result() const { return AGG == AGG_MEAN ? (float)(s / (double)cnt) : (float)m; }
+};
+
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    const long long u = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)u, src), hi = __builtin_amdgcn_readlane((int)(u >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+template <int AGG>
+__global__ __launch_bounds__(256) void rz_runs_kernel(const unsigned *__restrict__ cell_s, const unsigned *__restrict__ idx_s,
+                                                      const double *__restrict__ values, long long n, int nb, long long hw,
+                                                      float *__restrict__ raster) {
+    const int lane = (int)(threadIdx.x & 63);
+    const long long nchunks = (n + 63) >> 6;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long ch = wave0; ch < nchunks; ch += nwaves) {
+        const long long base = ch << 6, p = base + lane;
+        const bool in = p < n;
+        const unsigned mycell = in ? cell_s[p] : 0xFFFFFFFFu;
+        const bool head = in && (p == 0 || cell_s[p - 1] != mycell);
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1)) << (lane + 1);
+        const int valid = __popcll(__ballot(in));
+        const int nxt = above ? __ffsll((long long)above) - 1 : 64;
+        // does the run that starts here end inside these 64 positions?
+        bool ends_here = nxt < 64 || base + 64 >= n;
+        if (head && !ends_here) ends_here = cell_s[base + 64] != mycell;
+        const int len = (nxt < 64 ? nxt : valid) - lane;
+        const bool shortrun = head && ends_here && len <= RZ_SHORT;
+        if (shortrun) {
+            for (int b0 = 0; b0 < nb; b0 += RZ_BG) {
+                RzAcc<AGG> acc[RZ_BG];
+                for (int e = 0; e < len; ++e) {
+                    const double *row = values + (long long)idx_s[p + e] * nb + b0;
+#pragma unroll
+                    for (int g = 0; g < RZ_BG; ++g)
+                        if (b0 + g < nb) acc[g].take(row[g]);
+                }
+#pragma unroll
+                for (int g = 0; g < RZ_BG; ++g)
+                    if (b0 + g < nb && acc[g].cnt) raster[(long long)(b0 + g) * hw + mycell] = acc[g].result();
+            }
+        }
+        unsigned long long todo = __ballot(head && !shortrun);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)mycell, src);
+            const long long g0 = base + src;
+            for (int b0 = 0; b0 < nb; b0 += RZ_BG) {
+                RzAcc<AGG> acc[RZ_BG];
+                for (long long pos = g0;; pos += 64) {
+                    const long long q = pos + lane;
+                    const bool ok = q < n && cell_s[q] == c;
+                    const unsigned long long bad = __ballot(!ok);
+                    const int f = bad ? __ffsll((long long)bad) - 1 : 64;      // the run's points among these 64: a prefix
+                    if (f == 0) break;
+                    double v[RZ_BG];
+                    const double *row = values + (lane < f ? (long long)idx_s[q] * nb + b0 : 0);
+#pragma unroll
+                    for (int g = 0; g < RZ_BG; ++g) v[g] = (lane < f && b0 + g < nb) ? row[g] : 0.0;
+                    for (int e = 0; e < f; ++e) {
+#pragma unroll
+                        for (int g = 0; g < RZ_BG; ++g)
+                            if (b0 + g < nb) acc[g].take(readlane_f64(v[g], e));
+                    }
+                    if (f < 64) break;
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int g = 0; g < RZ_BG; ++g)
+                        if (b0 + g < nb && acc[g].cnt) raster[(long long)(b0 + g) * hw + c] = acc[g].result();
+                }
+            }
+        }
     }
 }
 
@@ -244,10 +284,9 @@ __device__ __forceinline__ float rz_window_value(const float *__restrict__ s, in
     }
 }
 
-// AGG_MEAN / _MAX / _MIN read the scatter's accumulators, AGG_MEDIAN_FOCAL the float32 raster the median runs wrote
+// the float32 raster the run kernels wrote (NaN = empty cell) -> S sweeps of the aggregate's own 3x3 window -> bytes
 template <int AGG>
-__global__ __launch_bounds__(256) void rz_tail_kernel(const double *__restrict__ acc, const unsigned *__restrict__ cnt,
-                                                      const float *__restrict__ raster, int width, int height, int S,
+__global__ __launch_bounds__(256) void rz_tail_kernel(const float *__restrict__ raster, int width, int height, int S,
                                                       int nodata, int tiles_x, int tiles_y, unsigned char *__restrict__ out) {
     extern __shared__ float rz_tail_lds[];                   // two rasters of (RZ_TH + 2 S) x (RZ_TW + 2 S) floats: 18 KB at S = 1, 31 KB at S = 8
     __shared__ int s_any;
@@ -266,49 +305,13 @@ __global__ __launch_bounds__(256) void rz_tail_kernel(const double *__restrict__
     if (tid == 0) s_any = 0;
     __syncthreads();
     bool any = false;
-    if constexpr (AGG == AGG_MEDIAN_FOCAL) {
-        for (int idx = tid; idx < lw * lh; idx += 256) {
-            const int r = (int)(((float)idx + 0.5f) * inv_lw), c = idx - r * lw;
-            const int gr = y0 + r, gc = x0 + c;
-            float v = nan;                                       // outside the raster: NaN, in every sweep
-            if (gr >= 0 && gr < height && gc >= 0 && gc < width) v = raster[band_base + (long long)gr * width + gc];
-            buf_cur[idx] = v;
-            any |= (v == v);
-        }
-    } else {
-        // two passes with the trip count fixed, so that all count loads of a lane are in flight together and the accumulator
-        // loads (occupied cells only) after them, instead of one count -> accumulator dependency per turn of a rolled loop
-        constexpr int TURNS = ((RZ_TW + 2 * RZ_SMAX) * (RZ_TH + 2 * RZ_SMAX) + 255) / 256;
-        unsigned have[TURNS];
-        long long at[TURNS];
-        const int cells = lw * lh;
-#pragma unroll
-        for (int k = 0; k < TURNS; ++k) {
-            const int idx = tid + k * 256;
-            have[k] = 0;
-            at[k] = 0;
-            if (idx < cells) {
-                const int r = (int)(((float)idx + 0.5f) * inv_lw), c = idx - r * lw;
-                const int gr = y0 + r, gc = x0 + c;
-                if (gr >= 0 && gr < height && gc >= 0 && gc < width) {       // outside the raster: NaN, in every sweep
-                    at[k] = band_base + (long long)gr * width + gc;
-                    have[k] = cnt[at[k]];
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < TURNS; ++k) {
-            const int idx = tid + k * 256;
-            if (idx < cells) {
-                float v = nan;
-                if (have[k]) {
-                    if constexpr (AGG == AGG_MEAN) v = (float)(acc[at[k]] / (double)have[k]);
-                    else v = (float)ord2d(reinterpret_cast<const unsigned long long *>(acc)[at[k]]);
-                    any = true;
-                }
-                buf_cur[idx] = v;
-            }
-        }
+    for (int idx = tid; idx < lw * lh; idx += 256) {
+        const int r = (int)(((float)idx + 0.5f) * inv_lw), c = idx - r * lw;
+        const int gr = y0 + r, gc = x0 + c;
+        float v = nan;                                           // outside the raster: NaN, in every sweep
+        if (gr >= 0 && gr < height && gc >= 0 && gc < width) v = raster[band_base + (long long)gr * width + gc];
+        buf_cur[idx] = v;
+        any |= (v == v);
     }
     if (any) s_any = 1;
     __syncthreads();
@@ -346,71 +349,63 @@ __global__ __launch_bounds__(256) void rz_tail_kernel(const double *__restrict__
     }
 }
 
-template <int AGG>
-static void launch_tail(const double *acc, const unsigned *cnt, const float *raster, int nb, int width, int height, int sweeps,
-                        int nodata, unsigned char *out_dev) {
-    const int tiles_x = (width + RZ_TW - 1) / RZ_TW, tiles_y = (height + RZ_TH - 1) / RZ_TH;
-    const size_t lds = 2 * sizeof(float) * (size_t)(RZ_TW + 2 * sweeps) * (size_t)(RZ_TH + 2 * sweeps);
-    hipLaunchKernelGGL((rz_tail_kernel<AGG>), dim3((unsigned)((long long)tiles_x * tiles_y * nb)), dim3(256), lds, ctx().stream, acc,
-                       cnt, raster, width, height, sweeps, nodata, tiles_x, tiles_y, out_dev);
-}
-
-template <int AGG>
-static int run_rasterize(const double *dx, const double *dy, const double *dv, long long n, int nb, double x_min,
-                         double y_max, double res, int width, int height, int sweeps, int nodata, double *acc,
-                         unsigned *cnt, float *ra, float *rb, unsigned char *out_dev) {
-    hipStream_t st = ctx().stream;
-    const long long total = (long long)width * height * nb;
-    const int cu = ctx().cu_count;
-    auto grid = [&](long long items) {
-        const long long want = (items + 255) / 256;
-        return (unsigned)(want < 1 ? 1 : (want < (long long)cu * 8 ? want : (long long)cu * 8));
-    };
-    if constexpr (AGG == AGG_MEAN) {
-        ALP_HIP(hipMemsetAsync(acc, 0, (size_t)total * sizeof(double), st));
-    } else {
-        // identity of max over the ordered keys is 0, of min all ones
-        ALP_HIP(hipMemsetAsync(acc, AGG == AGG_MAX ? 0x00 : 0xff, (size_t)total * sizeof(double), st));
-    }
-    ALP_HIP(hipMemsetAsync(cnt, 0, (size_t)total * sizeof(unsigned), st));
-    hipLaunchKernelGGL((rz_scatter_kernel<AGG>), dim3(grid(n)), dim3(256), 0, st, dx, dy, dv, n, nb, x_min, y_max, res,
-                       width, height, acc, cnt);
-    if (sweeps <= RZ_SMAX && !rz_separate_passes()) {
-        launch_tail<AGG>(acc, cnt, nullptr, nb, width, height, sweeps, nodata, out_dev);
-        ALP_HIP(hipGetLastError());
-        return ALP_OK;
-    }
-    hipLaunchKernelGGL((rz_finalize_kernel<AGG>), dim3(grid(total)), dim3(256), 0, st, acc, cnt, total, ra);
-    float *cur = ra, *nxt = rb;
-    for (int s = 0; s < sweeps; ++s) {
-        hipLaunchKernelGGL((rz_focal_kernel<AGG>), dim3(grid(total)), dim3(256), 0, st, cur, nxt, nb, width, height);
-        float *t = cur; cur = nxt; nxt = t;
-    }
-    hipLaunchKernelGGL(rz_to_u8_kernel, dim3(grid(total)), dim3(256), 0, st, cur, total, nodata, out_dev);
-    ALP_HIP(hipGetLastError());
-    return ALP_OK;
-}
-
 // ------------------------------------------------------------------ median
-// groupby median needs the values of every pixel in order: the points of one band are sorted
-// by value, then stably by pixel (two rocPRIM radix sorts: a library sort, nothing to hand-tune),
-// and the middle element(s) of each pixel's run are averaged like numpy/pandas do.
-__global__ __launch_bounds__(256) void rz_median_keys_kernel(const double *__restrict__ x, const double *__restrict__ y,
-                                                             const double *__restrict__ values, long long n, int nb,
-                                                             int band, double x_min, double y_max, double res,
-                                                             int width, int height,
-                                                             unsigned long long *__restrict__ vkey,
+// groupby median needs the values of every cell in order.  Image bands are bytes or float32 in float64 columns: when every
+// non-NaN value of the band IS a float32 (checked on the device), ONE radix sort of the composite key
+// (cell : order-preserving float32 bits) per band puts every cell's values in order, and the middle key(s) of a run ARE the
+// median's operands.  Any other band takes two stable sorts (by value, then by cell) as before.
+__device__ __forceinline__ unsigned f2ord(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u >> 31) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) { return __uint_as_float((o >> 31) ? (o & 0x7fffffffu) : ~o); }
+
+__global__ __launch_bounds__(256) void rz_median_key32_kernel(const unsigned *__restrict__ cell, const double *__restrict__ values,
+                                                              long long n, int nb, int band, unsigned long long *__restrict__ key,
+                                                              unsigned *__restrict__ not_f32) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double val = values[i * nb + band];
+        const float f = (float)val;
+        if (val == val && (double)f != val) bad = true;
+        // NaN: behind every cell (cells are below 2^31)
+        key[i] = val != val ? ~0ull : (((unsigned long long)cell[i] << 32) | (unsigned long long)f2ord(f));
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(not_f32, 1u);
+}
+
+__global__ __launch_bounds__(256) void rz_median_runs32_kernel(const unsigned long long *__restrict__ key_s, long long n,
+                                                               float *__restrict__ raster_band) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const unsigned long long k0 = key_s[i];
+        const unsigned c = (unsigned)(k0 >> 32);
+        if (k0 == ~0ull || (i > 0 && (unsigned)(key_s[i - 1] >> 32) == c)) continue;      // NaN tail, or not the head of a run
+        // the run's end: gallop, then bisect (a load per element would cost a run of thousands a millisecond)
+        long long lo = i, step = 1;                            // key_s[lo] is in the run
+        while (lo + step < n && (unsigned)(key_s[lo + step] >> 32) == c) { lo += step; step <<= 1; }
+        long long hi = lo + step < n ? lo + step : n;         // key_s[hi] is not (or hi == n)
+        while (hi - lo > 1) {
+            const long long mid = lo + ((hi - lo) >> 1);
+            if ((unsigned)(key_s[mid] >> 32) == c) lo = mid; else hi = mid;
+        }
+        const long long k = hi - i;
+        const double a = (double)ord2f((unsigned)key_s[i + (k - 1) / 2]);
+        const double b = (double)ord2f((unsigned)key_s[i + k / 2]);
+        raster_band[c] = (float)((k & 1) ? a : (a + b) / 2);
+    }
+}
+
+__global__ __launch_bounds__(256) void rz_median_keys_kernel(const unsigned *__restrict__ cell_in, const double *__restrict__ values,
+                                                             long long n, int nb, int band, unsigned long long *__restrict__ vkey,
                                                              unsigned *__restrict__ idx, unsigned *__restrict__ cell) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        long long col = (long long)((x[i] - x_min) / res);
-        long long row = (long long)((y_max - y[i]) / res);
-        col = col < 0 ? 0 : (col > width - 1 ? width - 1 : col);
-        row = row < 0 ? 0 : (row > height - 1 ? height - 1 : row);
         const double val = values[i * nb + band];
         vkey[i] = d2ord(val);
         idx[i] = (unsigned)i;
-        cell[i] = (val != val) ? 0xFFFFFFFFu : (unsigned)(row * width + col);      // NaN: sorts behind every pixel
+        cell[i] = (val != val) ? 0xFFFFFFFFu : cell_in[i];      // NaN: sorts behind every pixel
     }
 }
 
@@ -431,9 +426,14 @@ __global__ __launch_bounds__(256) void rz_median_runs_kernel(const unsigned *__r
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const unsigned c = cell_sorted[i];
         if (c == 0xFFFFFFFFu || (i > 0 && cell_sorted[i - 1] == c)) continue;      // not the head of a run
-        long long j = i + 1;
-        while (j < n && cell_sorted[j] == c) ++j;
-        const long long k = j - i;
+        long long lo = i, step = 1;                            // gallop, then bisect, as above
+        while (lo + step < n && cell_sorted[lo + step] == c) { lo += step; step <<= 1; }
+        long long hi = lo + step < n ? lo + step : n;
+        while (hi - lo > 1) {
+            const long long mid = lo + ((hi - lo) >> 1);
+            if (cell_sorted[mid] == c) lo = mid; else hi = mid;
+        }
+        const long long k = hi - i;
         const double a = values[(long long)idx_sorted[i + (k - 1) / 2] * nb + band];
         const double b = values[(long long)idx_sorted[i + k / 2] * nb + band];
         raster_band[c] = (float)((k & 1) ? a : (a + b) / 2);
@@ -481,9 +481,36 @@ __global__ __launch_bounds__(256) void rz_focal_median_kernel(const float *__res
 
 namespace alp {
 
-static int run_rasterize_median(const double *dx, const double *dy, const double *dv, long long n, int nb, double x_min,
-                                double y_max, double res, int width, int height, int sweeps, int nodata, float *ra,
-                                float *rb, unsigned char *out_dev) {
+enum { AGG_MEDIAN = 3 };
+
+template <int AGG>
+static void launch_tail(const float *raster, int nb, int width, int height, int sweeps, int nodata, unsigned char *out_dev) {
+    const int tiles_x = (width + RZ_TW - 1) / RZ_TW, tiles_y = (height + RZ_TH - 1) / RZ_TH;
+    const size_t lds = 2 * sizeof(float) * (size_t)(RZ_TW + 2 * sweeps) * (size_t)(RZ_TH + 2 * sweeps);
+    hipLaunchKernelGGL((rz_tail_kernel<AGG>), dim3((unsigned)((long long)tiles_x * tiles_y * nb)), dim3(256), lds, ctx().stream, raster,
+                       width, height, sweeps, nodata, tiles_x, tiles_y, out_dev);
+}
+
+// bytes of device scratch run_rasterize needs for n points (sort buffers + rocPRIM's temporary storage)
+static size_t rz_sort_bytes(long long n, size_t *tmp_out) {
+    size_t t1 = 0, t2 = 0, t3 = 0;
+    const size_t count = (size_t)n;
+    rocprim::radix_sort_pairs(nullptr, t1, (unsigned *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr, count, 0u, 32u,
+                              ctx().stream);
+    rocprim::radix_sort_keys(nullptr, t2, (unsigned long long *)nullptr, (unsigned long long *)nullptr, count, 0u, 64u, ctx().stream);
+    rocprim::radix_sort_pairs(nullptr, t3, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (unsigned *)nullptr,
+                              (unsigned *)nullptr, count, 0u, 64u, ctx().stream);
+    const size_t tmp = std::max(t1, std::max(t2, t3));
+    if (tmp_out) *tmp_out = tmp;
+    // cell, idx (x 2: in / out) | 64-bit keys x 2 | third cell array of the two-sort median | flag | temporary storage
+    return (size_t)n * (16 + 16 + 4) + 256 + tmp + 256;
+}
+
+// dx, dy, dv: the points on the device (values interleaved n x nb); ra, rb: float32 rasters (rb only for the separate-pass
+// path); `sort_area`: rz_sort_bytes(n) bytes.  agg: AGG_MEAN / _MAX / _MIN / AGG_MEDIAN.
+static int run_rasterize(int agg, const double *dx, const double *dy, const double *dv, long long n, int nb, double x_min,
+                         double y_max, double res, int width, int height, int sweeps, int nodata, float *ra, float *rb,
+                         unsigned char *out_dev, char *sort_area, float **f32_out = nullptr) {
     hipStream_t st = ctx().stream;
     const long long hw = (long long)width * height, total = hw * nb;
     const int cu = ctx().cu_count;
@@ -491,53 +518,81 @@ static int run_rasterize_median(const double *dx, const double *dy, const double
         const long long want = (items + 255) / 256;
         return (unsigned)(want < 1 ? 1 : (want < (long long)cu * 8 ? want : (long long)cu * 8));
     };
-    // scratch: value keys (2 x u64), point ids (2 x u32), pixel ids (3 x u32), rocPRIM temporary storage
-    size_t tmp1 = 0, tmp2 = 0;
+    size_t tmp = 0;
+    rz_sort_bytes(n, &tmp);
     const size_t count = (size_t)n;
-    rocprim::radix_sort_pairs(nullptr, tmp1, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
-                              (unsigned *)nullptr, (unsigned *)nullptr, count, 0u, 64u, st);
-    rocprim::radix_sort_pairs(nullptr, tmp2, (unsigned *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr,
-                              (unsigned *)nullptr, count, 0u, 32u, st);
-    const size_t tmp = tmp1 > tmp2 ? tmp1 : tmp2;
-    char *scratch = nullptr;
-    ALP_HIP(hipMalloc((void **)&scratch, (size_t)n * (16 + 8 + 12) + tmp + 256));
-    unsigned long long *vkey = (unsigned long long *)scratch, *vkey2 = vkey + n;
-    unsigned *idx = (unsigned *)(vkey2 + n), *idx2 = idx + n, *cell = idx2 + n, *cell_s = cell + n, *cell_s2 = cell_s + n;
-    void *sort_tmp = (void *)(((uintptr_t)(cell_s2 + n) + 255) & ~(uintptr_t)255);
+    unsigned *cell = (unsigned *)sort_area, *cell_s = cell + n, *idx = cell_s + n, *idx_s = idx + n;
+    unsigned long long *key = (unsigned long long *)(idx_s + n), *key_s = key + n;
+    unsigned *cell3 = (unsigned *)(key_s + n);
+    unsigned *flag = (unsigned *)(((uintptr_t)(cell3 + n) + 63) & ~(uintptr_t)63);
+    void *sort_tmp = (void *)(((uintptr_t)(flag + 16) + 255) & ~(uintptr_t)255);
+    unsigned cell_bits = 1;
+    while (cell_bits < 32 && (1ll << cell_bits) < hw) ++cell_bits;
     hipLaunchKernelGGL(rz_fill_nan_kernel, dim3(grid(total)), dim3(256), 0, st, ra, total);
-    hipError_t e = hipSuccess;
-    for (int b = 0; b < nb && e == hipSuccess; ++b) {
-        hipLaunchKernelGGL(rz_median_keys_kernel, dim3(grid(n)), dim3(256), 0, st, dx, dy, dv, n, nb, b, x_min, y_max, res,
-                           width, height, vkey, idx, cell);
+    hipLaunchKernelGGL(rz_cell_kernel, dim3(grid(n)), dim3(256), 0, st, dx, dy, n, x_min, y_max, res, width, height, cell, idx);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && agg != AGG_MEDIAN) {
         size_t t = tmp;
-        e = rocprim::radix_sort_pairs(sort_tmp, t, vkey, vkey2, idx, idx2, count, 0u, 64u, st);   // by value
-        if (e != hipSuccess) break;
-        hipLaunchKernelGGL(rz_gather_cell_kernel, dim3(grid(n)), dim3(256), 0, st, idx2, cell, n, cell_s);
-        t = tmp;
-        e = rocprim::radix_sort_pairs(sort_tmp, t, cell_s, cell_s2, idx2, idx, count, 0u, 32u, st);   // stably by pixel
-        if (e != hipSuccess) break;
-        hipLaunchKernelGGL(rz_median_runs_kernel, dim3(grid(n)), dim3(256), 0, st, cell_s2, idx, dv, n, nb, b, ra + b * hw);
+        e = rocprim::radix_sort_pairs(sort_tmp, t, cell, cell_s, idx, idx_s, count, 0u, cell_bits, st);      // stable: a run keeps the rows' order
+        if (e == hipSuccess) {
+            if (agg == AGG_MEAN) hipLaunchKernelGGL((rz_runs_kernel<AGG_MEAN>), dim3(grid(n)), dim3(256), 0, st, cell_s, idx_s, dv, n, nb, hw, ra);
+            else if (agg == AGG_MAX) hipLaunchKernelGGL((rz_runs_kernel<AGG_MAX>), dim3(grid(n)), dim3(256), 0, st, cell_s, idx_s, dv, n, nb, hw, ra);
+            else hipLaunchKernelGGL((rz_runs_kernel<AGG_MIN>), dim3(grid(n)), dim3(256), 0, st, cell_s, idx_s, dv, n, nb, hw, ra);
+            e = hipGetLastError();
+        }
+    } else if (e == hipSuccess) {
+        for (int b = 0; b < nb && e == hipSuccess; ++b) {
+            e = hipMemsetAsync(flag, 0, sizeof(unsigned), st);
+            if (e != hipSuccess) break;
+            hipLaunchKernelGGL(rz_median_key32_kernel, dim3(grid(n)), dim3(256), 0, st, cell, dv, n, nb, b, key, flag);
+            unsigned not_f32 = 0;
+            e = hipMemcpyAsync(&not_f32, flag, sizeof(unsigned), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) break;
+            size_t t = tmp;
+            if (!not_f32) {
+                e = rocprim::radix_sort_keys(sort_tmp, t, key, key_s, count, 0u, 64u, st);      // the NaN keys (all ones) end up last
+                if (e != hipSuccess) break;
+                hipLaunchKernelGGL(rz_median_runs32_kernel, dim3(grid(n)), dim3(256), 0, st, key_s, n, ra + b * hw);
+            } else {
+                // values that are not float32: by value (64-bit keys), then stably by cell
+                hipLaunchKernelGGL(rz_median_keys_kernel, dim3(grid(n)), dim3(256), 0, st, cell, dv, n, nb, b, key, idx, cell3);
+                e = rocprim::radix_sort_pairs(sort_tmp, t, key, key_s, idx, idx_s, count, 0u, 64u, st);
+                if (e != hipSuccess) break;
+                hipLaunchKernelGGL(rz_gather_cell_kernel, dim3(grid(n)), dim3(256), 0, st, idx_s, cell3, n, cell_s);
+                t = tmp;
+                unsigned *cell_s2 = (unsigned *)key;           // the value keys are spent
+                e = rocprim::radix_sort_pairs(sort_tmp, t, cell_s, cell_s2, idx_s, idx, count, 0u, 32u, st);
+                if (e != hipSuccess) break;
+                hipLaunchKernelGGL(rz_median_runs_kernel, dim3(grid(n)), dim3(256), 0, st, cell_s2, idx, dv, n, nb, b, ra + b * hw);
+            }
+            e = hipGetLastError();
+        }
     }
-    if (e == hipSuccess && sweeps <= RZ_SMAX && !rz_separate_passes()) {
-        launch_tail<AGG_MEDIAN_FOCAL>(nullptr, nullptr, ra, nb, width, height, sweeps, nodata, out_dev);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(st);          // scratch is freed below
-        hipFree(scratch);
-        if (e != hipSuccess) return fail(ALP_EHIP, "median rasterisation: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail(ALP_EHIP, "rasterisation: %s", hipGetErrorString(e));
+    if (sweeps <= RZ_SMAX && !rz_separate_passes() && !f32_out) {
+        if (agg == AGG_MEAN) launch_tail<AGG_MEAN>(ra, nb, width, height, sweeps, nodata, out_dev);
+        else if (agg == AGG_MAX) launch_tail<AGG_MAX>(ra, nb, width, height, sweeps, nodata, out_dev);
+        else if (agg == AGG_MIN) launch_tail<AGG_MIN>(ra, nb, width, height, sweeps, nodata, out_dev);
+        else launch_tail<AGG_MEDIAN_FOCAL>(ra, nb, width, height, sweeps, nodata, out_dev);
+        ALP_HIP(hipGetLastError());
         return ALP_OK;
     }
     float *cur = ra, *nxt = rb;
-    for (int s = 0; s < sweeps && e == hipSuccess; ++s) {
-        hipLaunchKernelGGL(rz_focal_median_kernel, dim3(grid(total)), dim3(256), 0, st, cur, nxt, nb, width, height);
+    for (int s = 0; s < sweeps; ++s) {
+        if (agg == AGG_MEAN) hipLaunchKernelGGL((rz_focal_kernel<AGG_MEAN>), dim3(grid(total)), dim3(256), 0, st, cur, nxt, nb, width, height);
+        else if (agg == AGG_MAX) hipLaunchKernelGGL((rz_focal_kernel<AGG_MAX>), dim3(grid(total)), dim3(256), 0, st, cur, nxt, nb, width, height);
+        else if (agg == AGG_MIN) hipLaunchKernelGGL((rz_focal_kernel<AGG_MIN>), dim3(grid(total)), dim3(256), 0, st, cur, nxt, nb, width, height);
+        else hipLaunchKernelGGL(rz_focal_median_kernel, dim3(grid(total)), dim3(256), 0, st, cur, nxt, nb, width, height);
         float *t = cur; cur = nxt; nxt = t;
     }
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(rz_to_u8_kernel, dim3(grid(total)), dim3(256), 0, st, cur, total, nodata, out_dev);
-        e = hipGetLastError();
+    if (f32_out) {                 // the float32 raster itself (project.py:479, before the byte conversion)
+        *f32_out = cur;
+        ALP_HIP(hipGetLastError());
+        return ALP_OK;
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(st);          // scratch is freed below
-    hipFree(scratch);
-    if (e != hipSuccess) return fail(ALP_EHIP, "median rasterisation: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(rz_to_u8_kernel, dim3(grid(total)), dim3(256), 0, st, cur, total, nodata, out_dev);
+    ALP_HIP(hipGetLastError());
     return ALP_OK;
 }
 
@@ -660,8 +715,8 @@ extern "C" int alp_render_rasterize(alp_mesh_t *m, const void *array, int array_
     const size_t esize = array_dtype == ALP_U8 ? 1 : array_dtype == ALP_U16 ? 2 : array_dtype == ALP_F32 ? 4 : 8;
     const size_t npix = (size_t)m->w * m->h, arr_bytes = npix * (size_t)channels * esize;
     const size_t total = (size_t)width * height * nb;
-    // values | acc (f64) | cnt (u32) | raster a | raster b | out (u8) | band table | the caller's array
-    const size_t bytes = (size_t)n * nb * 8 + total * (8 + 4 + 4 + 4 + 1) + 64 * 4 + 256 + arr_bytes + 64;
+    // values | raster a | raster b | out (u8) | band table | the caller's array   (the sort buffers: the library scratch)
+    const size_t bytes = (size_t)n * nb * 8 + total * (4 + 4 + 1) + 64 * 4 + 256 + arr_bytes + 64;
     if (bytes > m->rz_work_cap) {
         if (m->rz_work) hipFree(m->rz_work);
         m->rz_work = nullptr;
@@ -671,15 +726,15 @@ extern "C" int alp_render_rasterize(alp_mesh_t *m, const void *array, int array_
     }
     char *dev = m->rz_work;
     double *dv = (double *)dev;
-    double *acc = dv + (size_t)n * nb;
-    unsigned *cnt = (unsigned *)(acc + total);
-    float *ra = (float *)(cnt + total), *rb = ra + total;
+    float *ra = (float *)(dv + (size_t)n * nb), *rb = ra + total;
     unsigned char *out_dev = (unsigned char *)(rb + total);
     int *bands_dev = (int *)(((uintptr_t)(out_dev + total) + 15) & ~(uintptr_t)15);
     char *arr_dev = (char *)(((uintptr_t)(bands_dev + 64) + 255) & ~(uintptr_t)255);
     const double *dx = (const double *)m->rz_points, *dy = dx + n;
     const unsigned *idx = (const unsigned *)(dy + n);
     hipStream_t st = ctx().stream;
+    char *sort_area = nullptr;
+    if (int rc0 = scratch_reserve(rz_sort_bytes(n, nullptr), (void **)&sort_area)) return rc0;
     int rc = upload_chunked(arr_dev, array, arr_bytes);
     hipError_t e = hipSuccess;
     if (!rc) e = hipMemcpyAsync(bands_dev, band_channel, (size_t)nb * sizeof(int), hipMemcpyHostToDevice, st);
@@ -693,14 +748,8 @@ extern "C" int alp_render_rasterize(alp_mesh_t *m, const void *array, int array_
         else if (array_dtype == ALP_F32) ALP_GATHER(float);
         else ALP_GATHER(double);
 #undef ALP_GATHER
-        if (agg == ALP_AGG_MEAN)
-            rc = run_rasterize<AGG_MEAN>(dx, dy, dv, n, (int)nb, x_min, y_max, resolution, (int)width, (int)height, sweeps, nodata, acc, cnt, ra, rb, out_dev);
-        else if (agg == ALP_AGG_MAX)
-            rc = run_rasterize<AGG_MAX>(dx, dy, dv, n, (int)nb, x_min, y_max, resolution, (int)width, (int)height, sweeps, nodata, acc, cnt, ra, rb, out_dev);
-        else if (agg == ALP_AGG_MIN)
-            rc = run_rasterize<AGG_MIN>(dx, dy, dv, n, (int)nb, x_min, y_max, resolution, (int)width, (int)height, sweeps, nodata, acc, cnt, ra, rb, out_dev);
-        else
-            rc = run_rasterize_median(dx, dy, dv, n, (int)nb, x_min, y_max, resolution, (int)width, (int)height, sweeps, nodata, ra, rb, out_dev);
+        rc = run_rasterize(agg, dx, dy, dv, n, (int)nb, x_min, y_max, resolution, (int)width, (int)height, sweeps, nodata, ra, rb, out_dev,
+                           sort_area);
     }
     if (!rc && e == hipSuccess) e = hipMemcpyAsync(out, out_dev, total, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -724,9 +773,9 @@ __global__ __launch_bounds__(256) void rz_interleave_kernel(const double *__rest
 static int rasterize_host_points(const char *who, const double *x, const double *y, const double *values,
                                  const double *const *cols, int64_t n, int64_t nb, double x_min, double y_max,
                                  double resolution, int64_t width, int64_t height, int agg, int sweeps, int nodata,
-                                 uint8_t *out) {
+                                 uint8_t *out, float *out_f32 = nullptr) {
     if (int rc = require_init()) return rc;
-    ALP_REQUIRE(x && y && (values || cols) && out, "NULL argument");
+    ALP_REQUIRE(x && y && (values || cols) && (out || out_f32), "NULL argument");
     ALP_REQUIRE(n >= 1 && nb >= 1 && nb <= 64, "n or band count out of range");
     ALP_REQUIRE(width >= 1 && height >= 1 && width * height <= ((int64_t)1 << 31), "raster size out of range");
     ALP_REQUIRE(resolution > 0, "resolution must be positive");
@@ -739,17 +788,17 @@ static int rasterize_host_points(const char *who, const double *x, const double 
     const size_t total = (size_t)width * height * nb;
     const size_t pts_bytes = (size_t)n * sizeof(double);
     char *dev = nullptr;
-    // x | y | values | acc (f64) | cnt (u32) | raster a | raster b | out (u8); the columns are staged in acc | cnt
-    // (12 bytes per band-cell, cleared afterwards) when they fit, else behind out
-    const bool stage_in_acc = cols && pts_bytes * nb <= total * 12;
-    const size_t bytes = pts_bytes * (2 + nb) + total * (8 + 4 + 4 + 4 + 1) + 64 + ((cols && !stage_in_acc) ? pts_bytes * nb + 64 : 0);
+    // x | y | values | raster a | raster b | out (u8) | sort buffers; the columns are staged in the sort buffers when they
+    // fit (they are interleaved into `values` before the first sort), else behind them
+    const size_t sort_bytes = rz_sort_bytes(n, nullptr);
+    const bool stage_in_sort = cols && pts_bytes * nb <= sort_bytes;
+    const size_t bytes = pts_bytes * (2 + nb) + total * (4 + 4 + 1) + 256 + sort_bytes + ((cols && !stage_in_sort) ? pts_bytes * nb + 64 : 0);
     ALP_HIP(hipMalloc((void **)&dev, bytes));
     double *dx = (double *)dev, *dy = dx + n, *dv = dy + n;
-    double *acc = dv + (size_t)n * nb;
-    unsigned *cnt = (unsigned *)(acc + total);
-    float *ra = (float *)(cnt + total), *rb = ra + total;
+    float *ra = (float *)(dv + (size_t)n * nb), *rb = ra + total;
     unsigned char *out_dev = (unsigned char *)(rb + total);
-    double *planar = stage_in_acc ? acc : (double *)(((uintptr_t)(out_dev + total) + 63) & ~(uintptr_t)63);
+    char *sort_area = (char *)(((uintptr_t)(out_dev + total) + 255) & ~(uintptr_t)255);
+    double *planar = stage_in_sort ? (double *)sort_area : (double *)(((uintptr_t)(sort_area + sort_bytes) + 63) & ~(uintptr_t)63);
     hipStream_t st = ctx().stream;
     hipError_t e = hipMemcpyAsync(dx, x, pts_bytes, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(dy, y, pts_bytes, hipMemcpyHostToDevice, st);
@@ -766,20 +815,12 @@ static int rasterize_host_points(const char *who, const double *x, const double 
             const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, (long long)ctx().cu_count * 8);
             hipLaunchKernelGGL(rz_interleave_kernel, dim3(grid), dim3(256), 0, st, planar, (long long)n, (int)nb, dv);
         }
-        if (agg == ALP_AGG_MEAN)
-            rc = run_rasterize<AGG_MEAN>(dx, dy, dv, n, (int)nb, x_min, y_max, resolution, (int)width, (int)height, sweeps,
-                                         nodata, acc, cnt, ra, rb, out_dev);
-        else if (agg == ALP_AGG_MAX)
-            rc = run_rasterize<AGG_MAX>(dx, dy, dv, n, (int)nb, x_min, y_max, resolution, (int)width, (int)height, sweeps,
-                                        nodata, acc, cnt, ra, rb, out_dev);
-        else if (agg == ALP_AGG_MIN)
-            rc = run_rasterize<AGG_MIN>(dx, dy, dv, n, (int)nb, x_min, y_max, resolution, (int)width, (int)height, sweeps,
-                                        nodata, acc, cnt, ra, rb, out_dev);
-        else
-            rc = run_rasterize_median(dx, dy, dv, n, (int)nb, x_min, y_max, resolution, (int)width, (int)height, sweeps,
-                                      nodata, ra, rb, out_dev);
+        float *f32_dev = nullptr;
+        rc = run_rasterize(agg, dx, dy, dv, n, (int)nb, x_min, y_max, resolution, (int)width, (int)height, sweeps, nodata, ra, rb,
+                           out_dev, sort_area, out_f32 ? &f32_dev : nullptr);
+        if (rc == ALP_OK && out_f32) e = hipMemcpyAsync(out_f32, f32_dev, total * sizeof(float), hipMemcpyDeviceToHost, st);
     }
-    if (e == hipSuccess && rc == ALP_OK) e = hipMemcpyAsync(out, out_dev, total, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && rc == ALP_OK && !out_f32) e = hipMemcpyAsync(out, out_dev, total, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     hipFree(dev);
     if (rc) return rc;
@@ -794,6 +835,13 @@ extern "C" int alp_rasterize_points(const double *x, const double *y, const doub
                                     int agg, int sweeps, int nodata, uint8_t *out) {
     return alp::rasterize_host_points("alp_rasterize_points", x, y, values, nullptr, n, nb, x_min, y_max, resolution, width, height,
                                       agg, sweeps, nodata, out);
+}
+
+extern "C" int alp_rasterize_points_f32(const double *x, const double *y, const double *values, int64_t n, int64_t nb,
+                                        double x_min, double y_max, double resolution, int64_t width, int64_t height,
+                                        int agg, int sweeps, float *out) {
+    return alp::rasterize_host_points("alp_rasterize_points_f32", x, y, values, nullptr, n, nb, x_min, y_max, resolution, width, height,
+                                      agg, sweeps, 0, nullptr, out);
 }
 
 extern "C" int alp_rasterize_columns(const double *x, const double *y, const double *const *columns, int64_t n, int64_t nb,

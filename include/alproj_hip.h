@@ -400,6 +400,11 @@ int alp_render_rasterize(alp_mesh_t *mesh, const void *array, int array_dtype, i
 int alp_rasterize_points(const double *x, const double *y, const double *values, int64_t n, int64_t nb,
                          double x_min, double y_max, double resolution, int64_t width, int64_t height,
                          int agg, int sweeps, int nodata, uint8_t *out);
+/* The float32 raster (nb, height, width) itself, after the sweeps and before the byte conversion (the reference's
+ * `raster_data`, src/alproj/project.py:448-479; NaN = empty): what the parity tests compare with pandas bit for bit. */
+int alp_rasterize_points_f32(const double *x, const double *y, const double *values, int64_t n, int64_t nb,
+                             double x_min, double y_max, double resolution, int64_t width, int64_t height,
+                             int agg, int sweeps, float *out);
 /* The same with the band values as nb separate columns (columns[b][i]: each n contiguous doubles -- how a DataFrame keeps
  * them, so that to_geotiff(df) hands its columns over without the transposed copy df[bands].to_numpy() makes, ~100 ms for
  * 16 M rows x 3 bands); the interleaving happens on the device. */

@@ -325,7 +325,7 @@ def conditioning(xyz, params):
 # compute part of to_geotiff: rasterise + focal fill + uint8
 # --------------------------------------------------------------------------------------
 def rasterize_points(x, y, values, resolution=1.0, interpolate=True, max_dist=1.0, agg_func="mean",
-                     nodata=255):
+                     nodata=255, return_float=False):
     """project.py:420-485 without the file I/O: extent and size (:420-425), pixel indices
     (:435-436), per-band groupby aggregation into a float32 raster (:450-459), NaN-only 3x3
     focal fill with the same aggregation, ceil(max_dist / resolution) sweeps (:462-479), uint8
@@ -369,6 +369,8 @@ def rasterize_points(x, y, values, resolution=1.0, interpolate=True, max_dist=1.
                                         size=3, mode="constant", cval=np.nan)
                 band[mask] = filled[mask]
                 raster[b] = band
+    if return_float:               # the reference's `raster_data` before the byte conversion (project.py:479)
+        return raster, (x_min, y_min, x_max, y_max, width, height)
     nan_mask = np.isnan(raster)
     out = np.clip(np.nan_to_num(raster, nan=0), 0, 255).astype(np.uint8)
     out[nan_mask] = nodata

@@ -7,7 +7,7 @@ import pytest
 
 from oracle import raycast as oray
 from tests import gl_compare as glc
-from tests.render_scenes import GL_SCENES
+from tests.render_scenes import C4_SCENES, GL_SCENES
 
 pytestmark = pytest.mark.gpu
 
@@ -91,3 +91,23 @@ def test_hip_lens_composition_equals_the_references(L, g15):
     ok = inside & agree[sy, sx]
     assert ok.mean() > 0.6
     assert (np.abs(lens[ok] - gl_lens[ok]) <= 1e-5 * np.maximum(np.abs(gl_lens[ok]), 1.0)).all()
+
+
+def test_hip_render_matches_opengl_at_the_references_frame_size(L):
+    """g16: the reference's own persp_proj on a real OpenGL at BASELINE config 4's frame -- 5616 x 3744 (example.py:22) over a
+    6000 x 6000-vertex surface, 72 M triangles, 3 M of them visible -- so that agreement with GL at that size does not rest on
+    transitivity through the frozen C oracle.  The fixture keeps gl_PrimitiveID on every 8th pixel of both axes and GL's image on
+    every 16th; the assertions are those of the small scenes (tests/gl_compare.py), on that lattice."""
+    g16 = np.load(glc.G16, allow_pickle=False)
+    name = "c4_frame_36m"
+    s = C4_SCENES[name]()
+    p = dict(s["params"], **glc.NO_LENS)
+    with L.Mesh(s["vert"], None, None, s["grid"]) as m:
+        m.render_enqueue(L.params_vector(p), s["offsets"], None, coords=True)
+        vis = m.fetch_visibility()
+        img = m.fetch()
+    tri = oray.vis_triangle(vis)
+    assert abs(float((tri >= 0).mean()) - float(g16[f"{name}_covered_fraction"])) < 2e-4       # GL's coverage of the WHOLE frame
+    r = glc.compare_with_gl(name, s, g16, tri, img)
+    glc.report(name, "HIP", r)
+    assert r["pixels"] == 468 * 702 and r["safe"] > 0.9 * r["pixels"] and r["all_same_rate"] > 0.999

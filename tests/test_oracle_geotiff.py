@@ -23,3 +23,17 @@ def test_rasterize_matches_reference(name):
     np.testing.assert_array_equal(raster, g[f"{name}_raster"])
     assert (raster.shape[1], raster.shape[2]) == tuple(g[f"{name}_hw"])
     np.testing.assert_array_equal(np.array(bounds[:4]), g[f"{name}_bounds"])
+
+
+def test_oracle_matches_reference_on_a_million_float_points():
+    """g17 (gen_golden_geotiff_float.py): the reference's to_geotiff on a million clustered float-valued points; the oracle's
+    mean raster byte for byte (the other aggregates of the fixture are held against the device path, tests/test_gpu_rasterize.py)"""
+    from tests.rasterize_cases import FLOAT_CASES, float_points
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g17_geotiff_float.npz"), allow_pickle=False)
+    df = float_points()
+    assert len(df) == int(g["n_points"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        raster, bounds = orc.rasterize_points(df["x"].to_numpy(), df["y"].to_numpy(), df[["R", "G", "B"]].to_numpy(), **FLOAT_CASES["float_mean"])
+    np.testing.assert_array_equal(raster, g["float_mean_raster"])
+    np.testing.assert_array_equal(np.array(bounds[:4]), g["float_mean_bounds"])

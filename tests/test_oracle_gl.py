@@ -51,3 +51,21 @@ def test_lens_composition_of_the_reference_through_opengl(g15):
     plain = orast.render(s["vert"], None, None, dict(s["params"], **glc.NO_LENS), s["offsets"], grid=s["grid"])
     lens = orast.render(s["vert"], None, None, s["params"], s["offsets"], grid=s["grid"])
     glc.check_lens_composition(lens, plain, s["params"])
+
+
+def test_raster_oracle_matches_opengl_at_the_references_frame_size():
+    """g16 (tests/golden/gen_golden_gl_c4.py): the reference's persp_proj through the real GL at 5616 x 3744 over 72 M
+    triangles -- BASELINE config 4's frame.  The frozen oracle shows GL's triangle on every safe pixel of the fixture's
+    1-in-8 lattice and GL's value on its 1-in-16 lattice (a minute of CPU: the float64 ray caster over 72 M triangles)."""
+    from tests.render_scenes import C4_SCENES
+    g16 = np.load(glc.G16, allow_pickle=False)
+    name = "c4_frame_36m"
+    s = C4_SCENES[name]()
+    p = dict(s["params"], **glc.NO_LENS)
+    vis = orast.visibility(s["vert"], None, p, s["offsets"], grid=s["grid"])
+    img = orast.render(s["vert"], None, None, p, s["offsets"], grid=s["grid"])
+    tri = oray.vis_triangle(vis)
+    assert abs(float((tri >= 0).mean()) - float(g16[f"{name}_covered_fraction"])) < 2e-4
+    r = glc.compare_with_gl(name, s, g16, tri, img)
+    glc.report(name, "raster oracle", r)
+    assert r["pixels"] == 468 * 702 and r["safe"] > 0.9 * r["pixels"] and r["all_same_rate"] > 0.999

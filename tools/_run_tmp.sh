@@ -1,0 +1,7 @@
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r04e
+(time python -m pytest tests/test_gpu_rasterize.py -x -q) > gpurun_out/r04e/rz_tests.log 2>&1; tail -6 gpurun_out/r04e/rz_tests.log
+timeout 600 rocprofv3 --kernel-trace -d gpurun_out/r04e/rz -o p -- python3 tools/probe_rasterize.py 100000000 mean median > gpurun_out/r04e/rz.log 2>&1
+tail -8 gpurun_out/r04e/rz.log
+python3 tools/rocpd_summary.py gpurun_out/r04e/rz/p_results.db "" --csv gpurun_out/r04e/rz_kernels.csv | grep -v "raster_\|resolve\|hiz\|tile_\|surface" | head -40
+rm -rf gpurun_out/r04e/rz
