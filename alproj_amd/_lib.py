@@ -284,7 +284,10 @@ class Points:
         check(self._lib.alp_residuals_batch(self._h, as_dp(cand), cand.shape[0], as_dp(out)))
         return out
 
-    def eval_population(self, cand, loss_kind, f_scale=10.0):
+    def eval_population(self, cand, loss_kind, f_scale=10.0, want_argmin=True):
+        """-> (losses (P,), argmin).  ``want_argmin=False``: losses only -- the library then skips the float64 confirmation
+        of near-tied candidates of a float32 set, and the argmin returned is numpy's over the losses as they are (first
+        index on ties, NaN never wins)."""
         cand = np.ascontiguousarray(cand, dtype=np.float64)
         if cand.ndim != 2 or cand.shape[1] != NPARAM:
             raise ValueError("cand must have shape (P, 25)")
@@ -292,7 +295,10 @@ class Points:
         losses = np.empty(P, dtype=np.float64)
         amin = _c_i64()
         check(self._lib.alp_eval_population(self._h, as_dp(cand), P, int(loss_kind), float(f_scale),
-                                            as_dp(losses), ctypes.byref(amin)))
+                                            as_dp(losses), ctypes.byref(amin) if want_argmin else None))
+        if not want_argmin:
+            ok = ~np.isnan(losses)
+            return losses, (int(np.flatnonzero(ok)[np.argmin(losses[ok])]) if ok.any() else 0)
         return losses, int(amin.value)
 
     def eval_population_enqueue(self, cand, loss_kind, f_scale=10.0):

@@ -565,7 +565,9 @@ int alp_eval_population_wait(alp_points_t *p, double *loss_out, int64_t *argmin_
             best_v = l;
         }
     }
-    if (best >= 0 && p->precision == ALP_F32 && P > 1 && best_v < INFINITY) {
+    // (a caller that passes no argmin_out wants the losses only: no confirmation -- CMAOptimizer needs the argmin of its LAST
+    // generation alone, optimize.py:427, and the confirmation costs a float64 pass over every point)
+    if (argmin_out && best >= 0 && p->precision == ALP_F32 && P > 1 && best_v < INFINITY) {
         // candidates whose float32 loss lies within CONFIRM_GAP of the smallest one: if there is
         // more than one, float32 cannot order them -- evaluate (up to CONFIRM_MAX of) them again in
         // float64 arithmetic and take the argmin of those; identical on every rank (the sums are

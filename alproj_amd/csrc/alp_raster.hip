@@ -75,7 +75,7 @@
 #endif
 #if defined(INLINE_LOG2) || defined(FAST_MAX) || defined(COOP_MIN_W) || defined(COOP_MIN_PIX) || defined(GT_W_LOG2) || defined(GT_H_LOG2) || \
     defined(HIZ_SPAN) || defined(GRID_WAVES_PER_EU) || defined(PATCH_MIN_FAST) || defined(PATCH_WORDS_NEAR) || defined(PATCH_WORDS_FAR) ||    \
-    defined(RASTER_BLOCKS_PER_CU) || defined(RESOLVE_BLOCKS_PER_CU) || defined(PARKED_TILES_WGS_PER_CU)
+    defined(RASTER_BLOCKS_PER_CU) || defined(RESOLVE_BLOCKS_PER_CU) || defined(PARKED_TILES_WGS_PER_CU) || defined(PARKED_BY_TILES_DEFAULT)
 #define ALP_DEV_TUNABLES 1
 #ifndef ALP_DEV
 #error "tuning parameter overridden without -DALP_DEV"

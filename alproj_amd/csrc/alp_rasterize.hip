@@ -49,7 +49,8 @@ __device__ __forceinline__ double ord2d(unsigned long long o) {
 // cell (row * width + col, project.py:435-436) and index of every point
 __global__ __launch_bounds__(256) void rz_cell_kernel(const double *__restrict__ x, const double *__restrict__ y, long long n,
                                                       double x_min, double y_max, double res, int width, int height,
-                                                      unsigned *__restrict__ cell, unsigned *__restrict__ idx) {
+                                                      unsigned *__restrict__ cell, unsigned *__restrict__ idx,
+                                                      unsigned char *__restrict__ tile_used, int tiles_x) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         long long col = (long long)((x[i] - x_min) / res);
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(256) void rz_cell_kernel(const double *__restrict__
         row = row < 0 ? 0 : (row > height - 1 ? height - 1 : row);
         cell[i] = (unsigned)(row * width + col);
         idx[i] = (unsigned)i;
+        if (tile_used) tile_used[(row >> 5) * tiles_x + (col >> 6)] = 1;      // RZ_TH = 32, RZ_TW = 64; every writer writes 1
     }
 }
 
@@ -66,14 +68,12 @@ __global__ __launch_bounds__(256) void rz_cell_kernel(const double *__restrict__
 //   mean   libgroupby.group_mean: Kahan summation  y = v - c; t = s + y; c = (t - s) - y; s = t  (c reset to 0 when it
 //          turns NaN: an infinite value), then s / count -- checked against pandas 2.3 bit for bit (tests)
 //   max / min   order-free
-// and its float32 cast (project.py:459) goes into the NaN-filled raster.  The recurrence is sequential, the loads need not
-// be: a WAVE owns 64 consecutive sorted positions; runs of at most RZ_SHORT points that end inside them are walked by their
-// head lane (most cells of a georectified photograph hold one or two pixels), every other run -- next to the camera
-// hundreds or thousands of pixels share a cell -- by the whole wave: 64 points loaded at once, then the recurrence over
-// them with the operands broadcast from lane to lane (a thread walking such a run alone waits for one gather per point:
-// measured 2.9 ms for the 11.7 M points of the 100 M-vertex frame, of which the long runs were nearly all).
-constexpr int RZ_SHORT = 6, RZ_BG = 4;      // bands are taken RZ_BG at a time (their state lives in registers)
-
+// and its float32 cast (project.py:459) goes into the NaN-filled raster.  One thread per run: the recurrence is sequential,
+// the loads are not -- a run is walked eight points at a time, all their gathers in flight together (next to the camera
+// thousands of camera pixels share a cell: with one gather per turn such a run alone took a millisecond, and a wave that
+// ran the recurrence for 64 points with operands broadcast from lane to lane -- every lane computing the same -- took as
+// long: measured 2.9 and 1.07 ms for the 11.7 M points of the 100 M-vertex frame).  A run's end is found by galloping and
+// bisection, not by a load per point.
 template <int AGG>
 struct RzAcc {
     double s = 0.0, comp = 0.0, m = AGG == AGG_MAX ? -INFINITY : INFINITY;
@@ -95,80 +95,194 @@ struct RzAcc {
     __device__ __forceinline__ float result() const { return AGG == AGG_MEAN ? (float)(s / (double)cnt) : (float)m; }
 };
 
-__device__ __forceinline__ double readlane_f64(double v, int src) {
-    const long long u = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)u, src), hi = __builtin_amdgcn_readlane((int)(u >> 32), src);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+template <int AGG, int NB>
+__device__ __forceinline__ void rz_walk_run(const unsigned *__restrict__ idx_s, const double *__restrict__ values, long long i,
+                                            long long j, int nb, int b0, unsigned cell, long long hw, float *__restrict__ raster) {
+    RzAcc<AGG> acc[NB];
+    long long k = i;
+    for (; k + 8 <= j; k += 8) {
+        unsigned id[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) id[u] = idx_s[k + u];
+        double v[8][NB];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int g = 0; g < NB; ++g) v[u][g] = values[(long long)id[u] * nb + b0 + g];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int g = 0; g < NB; ++g) acc[g].take(v[u][g]);
+    }
+    for (; k < j; ++k) {
+        const double *row = values + (long long)idx_s[k] * nb + b0;
+#pragma unroll
+        for (int g = 0; g < NB; ++g) acc[g].take(row[g]);
+    }
+#pragma unroll
+    for (int g = 0; g < NB; ++g)
+        if (acc[g].cnt) raster[(long long)(b0 + g) * hw + cell] = acc[g].result();
 }
 
 template <int AGG>
 __global__ __launch_bounds__(256) void rz_runs_kernel(const unsigned *__restrict__ cell_s, const unsigned *__restrict__ idx_s,
                                                       const double *__restrict__ values, long long n, int nb, long long hw,
                                                       float *__restrict__ raster) {
-    const int lane = (int)(threadIdx.x & 63);
-    const long long nchunks = (n + 63) >> 6;
-    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
-    for (long long ch = wave0; ch < nchunks; ch += nwaves) {
-        const long long base = ch << 6, p = base + lane;
-        const bool in = p < n;
-        const unsigned mycell = in ? cell_s[p] : 0xFFFFFFFFu;
-        const bool head = in && (p == 0 || cell_s[p - 1] != mycell);
-        const unsigned long long heads = __ballot(head);
-        const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1)) << (lane + 1);
-        const int valid = __popcll(__ballot(in));
-        const int nxt = above ? __ffsll((long long)above) - 1 : 64;
-        // does the run that starts here end inside these 64 positions?
-        bool ends_here = nxt < 64 || base + 64 >= n;
-        if (head && !ends_here) ends_here = cell_s[base + 64] != mycell;
-        const int len = (nxt < 64 ? nxt : valid) - lane;
-        const bool shortrun = head && ends_here && len <= RZ_SHORT;
-        if (shortrun) {
-            for (int b0 = 0; b0 < nb; b0 += RZ_BG) {
-                RzAcc<AGG> acc[RZ_BG];
-                for (int e = 0; e < len; ++e) {
-                    const double *row = values + (long long)idx_s[p + e] * nb + b0;
-#pragma unroll
-                    for (int g = 0; g < RZ_BG; ++g)
-                        if (b0 + g < nb) acc[g].take(row[g]);
-                }
-#pragma unroll
-                for (int g = 0; g < RZ_BG; ++g)
-                    if (b0 + g < nb && acc[g].cnt) raster[(long long)(b0 + g) * hw + mycell] = acc[g].result();
-            }
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const unsigned c = cell_s[i];
+        if (i > 0 && cell_s[i - 1] == c) continue;             // not the head of a run
+        long long lo = i, step = 1;                            // cell_s[lo] is in the run
+        while (lo + step < n && cell_s[lo + step] == c) { lo += step; step <<= 1; }
+        long long hi = lo + step < n ? lo + step : n;         // cell_s[hi] is not (or hi == n)
+        while (hi - lo > 1) {
+            const long long mid = lo + ((hi - lo) >> 1);
+            if (cell_s[mid] == c) lo = mid; else hi = mid;
         }
-        unsigned long long todo = __ballot(head && !shortrun);
-        while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)mycell, src);
-            const long long g0 = base + src;
-            for (int b0 = 0; b0 < nb; b0 += RZ_BG) {
-                RzAcc<AGG> acc[RZ_BG];
-                for (long long pos = g0;; pos += 64) {
-                    const long long q = pos + lane;
-                    const bool ok = q < n && cell_s[q] == c;
-                    const unsigned long long bad = __ballot(!ok);
-                    const int f = bad ? __ffsll((long long)bad) - 1 : 64;      // the run's points among these 64: a prefix
-                    if (f == 0) break;
-                    double v[RZ_BG];
-                    const double *row = values + (lane < f ? (long long)idx_s[q] * nb + b0 : 0);
+        int b0 = 0;
+        for (; b0 + 4 <= nb; b0 += 4) rz_walk_run<AGG, 4>(idx_s, values, i, hi, nb, b0, c, hw, raster);
+        if (nb - b0 == 3) rz_walk_run<AGG, 3>(idx_s, values, i, hi, nb, b0, c, hw, raster);
+        else if (nb - b0 == 2) rz_walk_run<AGG, 2>(idx_s, values, i, hi, nb, b0, c, hw, raster);
+        else if (nb - b0 == 1) rz_walk_run<AGG, 1>(idx_s, values, i, hi, nb, b0, c, hw, raster);
+    }
+}
+
+// ---- order-free aggregates in parallel pieces
+// max / min never depend on the order, and neither does the mean of INTEGER-valued bands (image bytes in float64 columns:
+// Kahan's compensation stays exactly 0 and every partial sum below 2^53 is exact).  Then a run need not be walked by one
+// thread -- next to the camera thousands of camera pixels share a cell, and the longest run alone set the kernel's time
+// (1.1 ms of 2.2 for the 100 M-vertex frame).  rz_pieces_kernel: a thread per RZ_SEG consecutive sorted positions walks them,
+// finishes the runs that lie inside and leaves (sum, count) of the at most two pieces that cross its borders;
+// rz_join_kernel: the thread whose segment holds a crossing run's head adds the pieces of the segments after it.
+constexpr int RZ_SEG = 16;
+struct RzPiece {
+    double v;            // sum, or max / min
+    unsigned cnt;
+    unsigned pad;
+};
+
+template <int AGG>
+__device__ __forceinline__ void rz_piece_take(RzPiece &p, double v) {
+    if (v != v) return;
+    ++p.cnt;
+    if constexpr (AGG == AGG_MEAN) p.v += v;
+    else if constexpr (AGG == AGG_MAX) p.v = v > p.v ? v : p.v;
+    else p.v = v < p.v ? v : p.v;
+}
+template <int AGG>
+__device__ __forceinline__ void rz_piece_join(RzPiece &p, const RzPiece &q) {
+    p.cnt += q.cnt;
+    if constexpr (AGG == AGG_MEAN) p.v += q.v;
+    else if constexpr (AGG == AGG_MAX) p.v = q.v > p.v ? q.v : p.v;
+    else p.v = q.v < p.v ? q.v : p.v;
+}
+template <int AGG>
+__device__ __forceinline__ float rz_piece_result(const RzPiece &p) {
+    return AGG == AGG_MEAN ? (float)(p.v / (double)p.cnt) : (float)p.v;
+}
+
+// first[t * nb + b]: the piece that CONTINUES a run from segment t - 1 (it starts at the segment's first position);
+// last[t * nb + b]: the piece that starts a run inside segment t (or at its first position) and continues into t + 1
+template <int AGG, int NB>
+__device__ __forceinline__ void rz_pieces_bands(const unsigned (&cs)[RZ_SEG], const unsigned (&id)[RZ_SEG], unsigned before, unsigned after,
+                                                int count, const double *__restrict__ values, int nb, int b0, long long hw, long long t,
+                                                float *__restrict__ raster, RzPiece *__restrict__ first, RzPiece *__restrict__ last) {
+    const double ident = AGG == AGG_MEAN ? 0.0 : (AGG == AGG_MAX ? -INFINITY : INFINITY);
+    RzPiece pc[NB];
 #pragma unroll
-                    for (int g = 0; g < RZ_BG; ++g) v[g] = (lane < f && b0 + g < nb) ? row[g] : 0.0;
-                    for (int e = 0; e < f; ++e) {
+    for (int g = 0; g < NB; ++g) pc[g] = {ident, 0u, 0u};
+    bool from_head = before != cs[0];
 #pragma unroll
-                        for (int g = 0; g < RZ_BG; ++g)
-                            if (b0 + g < nb) acc[g].take(readlane_f64(v[g], e));
-                    }
-                    if (f < 64) break;
-                }
-                if (lane == 0) {
+    for (int u = 0; u < RZ_SEG; ++u) {
+        if (u >= count) break;
+        const double *row = values + (long long)id[u] * nb + b0;
 #pragma unroll
-                    for (int g = 0; g < RZ_BG; ++g)
-                        if (b0 + g < nb && acc[g].cnt) raster[(long long)(b0 + g) * hw + c] = acc[g].result();
-                }
+        for (int g = 0; g < NB; ++g) rz_piece_take<AGG>(pc[g], row[g]);
+        const unsigned nextc = u + 1 < count ? cs[u + 1 < RZ_SEG ? u + 1 : 0] : after;
+        if (nextc != cs[u]) {                          // the run ends here
+#pragma unroll
+            for (int g = 0; g < NB; ++g) {
+                if (from_head) { if (pc[g].cnt) raster[(long long)(b0 + g) * hw + cs[u]] = rz_piece_result<AGG>(pc[g]); }
+                else first[t * nb + b0 + g] = pc[g];
+                pc[g].v = ident; pc[g].cnt = 0u;
+            }
+            from_head = true;
+        } else if (u + 1 == count) {                   // ... or goes on in the next segment
+#pragma unroll
+            for (int g = 0; g < NB; ++g) {
+                if (from_head) last[t * nb + b0 + g] = pc[g]; else first[t * nb + b0 + g] = pc[g];
             }
         }
     }
+}
+
+template <int AGG>
+__global__ __launch_bounds__(256) void rz_pieces_kernel(const unsigned *__restrict__ cell_s, const unsigned *__restrict__ idx_s,
+                                                        const double *__restrict__ values, long long n, int nb, long long hw,
+                                                        float *__restrict__ raster, RzPiece *__restrict__ first,
+                                                        RzPiece *__restrict__ last) {
+    const long long nseg = (n + RZ_SEG - 1) / RZ_SEG, stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < nseg; t += stride) {
+        const long long p0 = t * RZ_SEG, p1 = p0 + RZ_SEG < n ? p0 + RZ_SEG : n;
+        unsigned cs[RZ_SEG], id[RZ_SEG];
+#pragma unroll
+        for (int u = 0; u < RZ_SEG; ++u) {
+            cs[u] = p0 + u < p1 ? cell_s[p0 + u] : 0xFFFFFFFFu;
+            id[u] = p0 + u < p1 ? idx_s[p0 + u] : 0u;
+        }
+        const unsigned before = p0 > 0 ? cell_s[p0 - 1] : 0xFFFFFFFFu, after = p1 < n ? cell_s[p1] : 0xFFFFFFFFu;
+        const int count = (int)(p1 - p0);
+        int b0 = 0;
+        for (; b0 + 4 <= nb; b0 += 4) rz_pieces_bands<AGG, 4>(cs, id, before, after, count, values, nb, b0, hw, t, raster, first, last);
+        if (nb - b0 == 3) rz_pieces_bands<AGG, 3>(cs, id, before, after, count, values, nb, b0, hw, t, raster, first, last);
+        else if (nb - b0 == 2) rz_pieces_bands<AGG, 2>(cs, id, before, after, count, values, nb, b0, hw, t, raster, first, last);
+        else if (nb - b0 == 1) rz_pieces_bands<AGG, 1>(cs, id, before, after, count, values, nb, b0, hw, t, raster, first, last);
+    }
+}
+
+template <int AGG>
+__global__ __launch_bounds__(256) void rz_join_kernel(const unsigned *__restrict__ cell_s, long long n, int nb, long long hw,
+                                                      float *__restrict__ raster, const RzPiece *__restrict__ first,
+                                                      const RzPiece *__restrict__ last) {
+    const long long nseg = (n + RZ_SEG - 1) / RZ_SEG, stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < nseg; t += stride) {
+        const long long p0 = t * RZ_SEG, p1 = p0 + RZ_SEG;
+        if (p1 >= n) continue;                                   // the last segment: nothing goes on behind it
+        const unsigned c = cell_s[p1 - 1];
+        if (cell_s[p1] != c) continue;                           // no run leaves this segment
+        if (cell_s[p0] == c && p0 > 0 && cell_s[p0 - 1] == c) continue;      // the run's head is in an earlier segment
+        // segments t + 1 ... e: the run fills t + 1 ... e - 1 and ends in e.  Gallop + bisect on "position still in the run".
+        long long lo = p1, step = RZ_SEG;
+        while (lo + step < n && cell_s[lo + step] == c) { lo += step; step <<= 1; }
+        long long hi = lo + step < n ? lo + step : n;
+        while (hi - lo > 1) {
+            const long long mid = lo + ((hi - lo) >> 1);
+            if (cell_s[mid] == c) lo = mid; else hi = mid;
+        }
+        const long long e = lo / RZ_SEG;                       // segment of the run's last position
+        for (int b = 0; b < nb; ++b) {
+            RzPiece acc = last[t * nb + b];
+            long long u = t + 1;
+            for (; u + 4 <= e + 1; u += 4) {
+                const RzPiece q0 = first[u * nb + b], q1 = first[(u + 1) * nb + b], q2 = first[(u + 2) * nb + b], q3 = first[(u + 3) * nb + b];
+                rz_piece_join<AGG>(acc, q0); rz_piece_join<AGG>(acc, q1); rz_piece_join<AGG>(acc, q2); rz_piece_join<AGG>(acc, q3);
+            }
+            for (; u <= e; ++u) rz_piece_join<AGG>(acc, first[u * nb + b]);
+            if (acc.cnt) raster[(long long)b * hw + c] = rz_piece_result<AGG>(acc);
+        }
+    }
+}
+
+// are all band values integers of magnitude below 2^31 (or NaN)?  flag |= 1 otherwise
+__global__ __launch_bounds__(256) void rz_integer_check_kernel(const double *__restrict__ values, long long count,
+                                                               unsigned *__restrict__ flag) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const double v = values[i];
+        if (v == v && !(fabs(v) < 2147483648.0 && v == (double)(long long)v)) bad = true;
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
 // one sweep of the NaN-only 3x3 focal fill
@@ -285,9 +399,28 @@ __device__ __forceinline__ float rz_window_value(const float *__restrict__ s, in
 }
 
 // the float32 raster the run kernels wrote (NaN = empty cell) -> S sweeps of the aggregate's own 3x3 window -> bytes
+// NaN into the float32 raster of the tiles that hold a point (all bands); the tail never reads the others
+__global__ __launch_bounds__(256) void rz_fill_tiles_kernel(float *__restrict__ raster, const unsigned char *__restrict__ tile_used,
+                                                            int nb, int width, int height, int tiles_x) {
+    const int t = (int)blockIdx.x;
+    if (!tile_used[t]) return;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const long long hw = (long long)width * height;
+    const float nan = __int_as_float(0x7fc00000);
+    for (int k = threadIdx.x; k < RZ_TW * RZ_TH * nb; k += 256) {
+        const int b = k / (RZ_TW * RZ_TH), r = (k / RZ_TW) % RZ_TH, c = k % RZ_TW;
+        const int gr = ty * RZ_TH + r, gc = tx * RZ_TW + c;
+        if (gr < height && gc < width) raster[b * hw + (long long)gr * width + gc] = nan;
+    }
+}
+
+// tile_used (or NULL = every tile): one byte per RZ_TW x RZ_TH tile of the raster, non-zero where a point fell -- most of a
+// georectified photograph's bounding box is empty; a tile whose own and eight neighbouring bytes are zero writes nodata
+// without reading anything, and cells of unused neighbours are NaN without being read (they were never filled)
 template <int AGG>
 __global__ __launch_bounds__(256) void rz_tail_kernel(const float *__restrict__ raster, int width, int height, int S,
-                                                      int nodata, int tiles_x, int tiles_y, unsigned char *__restrict__ out) {
+                                                      int nodata, int tiles_x, int tiles_y, unsigned char *__restrict__ out,
+                                                      const unsigned char *__restrict__ tile_used) {
     extern __shared__ float rz_tail_lds[];                   // two rasters of (RZ_TH + 2 S) x (RZ_TW + 2 S) floats: 18 KB at S = 1, 31 KB at S = 8
     __shared__ int s_any;
     const float nan = __int_as_float(0x7fc00000);
@@ -303,13 +436,33 @@ __global__ __launch_bounds__(256) void rz_tail_kernel(const float *__restrict__ 
     float *buf_cur = rz_tail_lds, *buf_nxt = rz_tail_lds + lw * lh;
     const float inv_lw = 1.0f / (float)lw;                       // idx / lw through (idx + 0.5) * (1 / lw): idx < 3840, exact
     if (tid == 0) s_any = 0;
+    // which of the 3 x 3 tiles around this one hold points (bit 3 * (dy + 1) + (dx + 1))
+    unsigned used9 = 0x1FFu;
+    if (tile_used) {
+        used9 = 0;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = ty + dy, xx = tx + dx;
+                if (yy >= 0 && yy < tiles_y && xx >= 0 && xx < tiles_x && tile_used[yy * tiles_x + xx]) used9 |= 1u << (3 * (dy + 1) + dx + 1);
+            }
+    }
+    if (!used9) {                                                // nothing here, nothing a sweep could bring in
+        for (int idx = tid; idx < RZ_TW * RZ_TH; idx += 256) {
+            const int gr = y0 + S + idx / RZ_TW, gc = x0 + S + idx % RZ_TW;
+            if (gr < height && gc < width) out[band_base + (long long)gr * width + gc] = (unsigned char)nodata;
+        }
+        return;
+    }
     __syncthreads();
     bool any = false;
     for (int idx = tid; idx < lw * lh; idx += 256) {
         const int r = (int)(((float)idx + 0.5f) * inv_lw), c = idx - r * lw;
         const int gr = y0 + r, gc = x0 + c;
         float v = nan;                                           // outside the raster: NaN, in every sweep
-        if (gr >= 0 && gr < height && gc >= 0 && gc < width) v = raster[band_base + (long long)gr * width + gc];
+        if (gr >= 0 && gr < height && gc >= 0 && gc < width) {
+            const int dy = r < S ? 0 : (r >= S + RZ_TH ? 2 : 1), dx = c < S ? 0 : (c >= S + RZ_TW ? 2 : 1);
+            if ((used9 >> (3 * dy + dx)) & 1u) v = raster[band_base + (long long)gr * width + gc];
+        }
         buf_cur[idx] = v;
         any |= (v == v);
     }
@@ -484,11 +637,12 @@ namespace alp {
 enum { AGG_MEDIAN = 3 };
 
 template <int AGG>
-static void launch_tail(const float *raster, int nb, int width, int height, int sweeps, int nodata, unsigned char *out_dev) {
+static void launch_tail(const float *raster, int nb, int width, int height, int sweeps, int nodata, unsigned char *out_dev,
+                        const unsigned char *tile_used) {
     const int tiles_x = (width + RZ_TW - 1) / RZ_TW, tiles_y = (height + RZ_TH - 1) / RZ_TH;
     const size_t lds = 2 * sizeof(float) * (size_t)(RZ_TW + 2 * sweeps) * (size_t)(RZ_TH + 2 * sweeps);
     hipLaunchKernelGGL((rz_tail_kernel<AGG>), dim3((unsigned)((long long)tiles_x * tiles_y * nb)), dim3(256), lds, ctx().stream, raster,
-                       width, height, sweeps, nodata, tiles_x, tiles_y, out_dev);
+                       width, height, sweeps, nodata, tiles_x, tiles_y, out_dev, tile_used);
 }
 
 // bytes of device scratch run_rasterize needs for n points (sort buffers + rocPRIM's temporary storage)
@@ -502,8 +656,9 @@ static size_t rz_sort_bytes(long long n, size_t *tmp_out) {
                               (unsigned *)nullptr, count, 0u, 64u, ctx().stream);
     const size_t tmp = std::max(t1, std::max(t2, t3));
     if (tmp_out) *tmp_out = tmp;
-    // cell, idx (x 2: in / out) | 64-bit keys x 2 | third cell array of the two-sort median | flag | temporary storage
-    return (size_t)n * (16 + 16 + 4) + 256 + tmp + 256;
+    // cell, idx (x 2: in / out) | 64-bit keys x 2 | third cell array of the two-sort median | flag | tile bytes (a raster has at most
+    // 2^31 cells = 2^20 tiles) | temporary storage
+    return (size_t)n * (16 + 16 + 4) + 256 + ((size_t)1 << 20) + 256 + tmp + 256;
 }
 
 // dx, dy, dv: the points on the device (values interleaved n x nb); ra, rb: float32 rasters (rb only for the separate-pass
@@ -525,19 +680,53 @@ static int run_rasterize(int agg, const double *dx, const double *dy, const doub
     unsigned long long *key = (unsigned long long *)(idx_s + n), *key_s = key + n;
     unsigned *cell3 = (unsigned *)(key_s + n);
     unsigned *flag = (unsigned *)(((uintptr_t)(cell3 + n) + 63) & ~(uintptr_t)63);
-    void *sort_tmp = (void *)(((uintptr_t)(flag + 16) + 255) & ~(uintptr_t)255);
+    unsigned char *tile_used = (unsigned char *)(flag + 16);
+    void *sort_tmp = (void *)(((uintptr_t)(tile_used + ((size_t)1 << 20)) + 255) & ~(uintptr_t)255);
+    const int tiles_x = (width + RZ_TW - 1) / RZ_TW, tiles_y = (height + RZ_TH - 1) / RZ_TH;
+    // the fused tail reads the tiles that hold points only; the separate-pass path reads every cell
+    const bool fused = sweeps <= RZ_SMAX && !rz_separate_passes() && !f32_out;
     unsigned cell_bits = 1;
     while (cell_bits < 32 && (1ll << cell_bits) < hw) ++cell_bits;
-    hipLaunchKernelGGL(rz_fill_nan_kernel, dim3(grid(total)), dim3(256), 0, st, ra, total);
-    hipLaunchKernelGGL(rz_cell_kernel, dim3(grid(n)), dim3(256), 0, st, dx, dy, n, x_min, y_max, res, width, height, cell, idx);
+    if (fused) {
+        ALP_HIP(hipMemsetAsync(tile_used, 0, (size_t)tiles_x * tiles_y, st));
+    } else {
+        ALP_HIP(hipMemsetD32Async((hipDeviceptr_t)ra, 0x7fc00000, (size_t)total, st));      // NaN everywhere (the runtime's fill)
+    }
+    hipLaunchKernelGGL(rz_cell_kernel, dim3(grid(n)), dim3(256), 0, st, dx, dy, n, x_min, y_max, res, width, height, cell, idx,
+                       fused ? tile_used : nullptr, tiles_x);
+    if (fused) hipLaunchKernelGGL(rz_fill_tiles_kernel, dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, st, ra, tile_used, nb, width, height, tiles_x);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && agg != AGG_MEDIAN) {
         size_t t = tmp;
         e = rocprim::radix_sort_pairs(sort_tmp, t, cell, cell_s, idx, idx_s, count, 0u, cell_bits, st);      // stable: a run keeps the rows' order
+        // the order-free cases go through parallel pieces (the pieces live where the median keeps its 64-bit keys)
+        const long long nseg = (n + RZ_SEG - 1) / RZ_SEG;
+        bool pieces = (size_t)nseg * nb * 2 * sizeof(RzPiece) <= (size_t)n * 16 && !getenv("ALP_RZ_SEQUENTIAL");
+        if (e == hipSuccess && pieces && agg == AGG_MEAN) {
+            e = hipMemsetAsync(flag, 0, sizeof(unsigned), st);
+            unsigned not_int = 1;
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(rz_integer_check_kernel, dim3(grid(n * nb)), dim3(256), 0, st, dv, n * nb, flag);
+                e = hipMemcpyAsync(&not_int, flag, sizeof(unsigned), hipMemcpyDeviceToHost, st);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            pieces = !not_int;
+        }
         if (e == hipSuccess) {
-            if (agg == AGG_MEAN) hipLaunchKernelGGL((rz_runs_kernel<AGG_MEAN>), dim3(grid(n)), dim3(256), 0, st, cell_s, idx_s, dv, n, nb, hw, ra);
+            RzPiece *first = (RzPiece *)key, *last = first + (size_t)nseg * nb;
+            const unsigned gs = grid(nseg);
+#define ALP_RZ_PIECES(A)                                                                                                      \
+    do {                                                                                                                      \
+        hipLaunchKernelGGL((rz_pieces_kernel<A>), dim3(gs), dim3(256), 0, st, cell_s, idx_s, dv, n, nb, hw, ra, first, last); \
+        hipLaunchKernelGGL((rz_join_kernel<A>), dim3(gs), dim3(256), 0, st, cell_s, n, nb, hw, ra, first, last);              \
+    } while (0)
+            if (agg == AGG_MEAN && pieces) ALP_RZ_PIECES(AGG_MEAN);
+            else if (agg == AGG_MEAN) hipLaunchKernelGGL((rz_runs_kernel<AGG_MEAN>), dim3(grid(n)), dim3(256), 0, st, cell_s, idx_s, dv, n, nb, hw, ra);
+            else if (agg == AGG_MAX && pieces) ALP_RZ_PIECES(AGG_MAX);
             else if (agg == AGG_MAX) hipLaunchKernelGGL((rz_runs_kernel<AGG_MAX>), dim3(grid(n)), dim3(256), 0, st, cell_s, idx_s, dv, n, nb, hw, ra);
+            else if (pieces) ALP_RZ_PIECES(AGG_MIN);
             else hipLaunchKernelGGL((rz_runs_kernel<AGG_MIN>), dim3(grid(n)), dim3(256), 0, st, cell_s, idx_s, dv, n, nb, hw, ra);
+#undef ALP_RZ_PIECES
             e = hipGetLastError();
         }
     } else if (e == hipSuccess) {
@@ -570,11 +759,11 @@ static int run_rasterize(int agg, const double *dx, const double *dy, const doub
         }
     }
     if (e != hipSuccess) return fail(ALP_EHIP, "rasterisation: %s", hipGetErrorString(e));
-    if (sweeps <= RZ_SMAX && !rz_separate_passes() && !f32_out) {
-        if (agg == AGG_MEAN) launch_tail<AGG_MEAN>(ra, nb, width, height, sweeps, nodata, out_dev);
-        else if (agg == AGG_MAX) launch_tail<AGG_MAX>(ra, nb, width, height, sweeps, nodata, out_dev);
-        else if (agg == AGG_MIN) launch_tail<AGG_MIN>(ra, nb, width, height, sweeps, nodata, out_dev);
-        else launch_tail<AGG_MEDIAN_FOCAL>(ra, nb, width, height, sweeps, nodata, out_dev);
+    if (fused) {
+        if (agg == AGG_MEAN) launch_tail<AGG_MEAN>(ra, nb, width, height, sweeps, nodata, out_dev, tile_used);
+        else if (agg == AGG_MAX) launch_tail<AGG_MAX>(ra, nb, width, height, sweeps, nodata, out_dev, tile_used);
+        else if (agg == AGG_MIN) launch_tail<AGG_MIN>(ra, nb, width, height, sweeps, nodata, out_dev, tile_used);
+        else launch_tail<AGG_MEDIAN_FOCAL>(ra, nb, width, height, sweeps, nodata, out_dev, tile_used);
         ALP_HIP(hipGetLastError());
         return ALP_OK;
     }
@@ -627,9 +816,18 @@ __global__ __launch_bounds__(256) void rz_bounds_kernel(const double *__restrict
         lo_x = a < lo_x ? a : lo_x; lo_y = b < lo_y ? b : lo_y;
         hi_x = c > hi_x ? c : hi_x; hi_y = d > hi_y ? d : hi_y;
     }
+    // one atomic per workgroup and word (a wave each cost 227 us of same-address traffic for 11.7 M points)
+    __shared__ unsigned long long s_b[4][4];
     if ((threadIdx.x & 63) == 0) {
-        atomicMin(out + 0, lo_x); atomicMin(out + 1, lo_y);
-        atomicMax(out + 2, hi_x); atomicMax(out + 3, hi_y);
+        unsigned long long *o = s_b[threadIdx.x >> 6];
+        o[0] = lo_x; o[1] = lo_y; o[2] = hi_x; o[3] = hi_y;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int k = (int)threadIdx.x;
+        unsigned long long r = s_b[0][k];
+        for (int w = 1; w < 4; ++w) r = (k < 2) ? (s_b[w][k] < r ? s_b[w][k] : r) : (s_b[w][k] > r ? s_b[w][k] : r);
+        if (k < 2) atomicMin(out + k, r); else atomicMax(out + k, r);
     }
 }
 

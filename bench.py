@@ -226,7 +226,9 @@ def pmc_traffic(name):
 
 
 def cma_loop(L, CMA, pts, base, targets, bounds_fn, pop, loss_kind, f_scale, seed=1234):
-    """One CMA-ES optimiser over the resident point set: returns (generation closure, state dict)."""
+    """One CMA-ES optimiser over the resident point set: returns (generation closure, state dict).  A generation is what
+    CMAOptimizer.optimize does for every generation but its last: ask, evaluate (losses; the argmin with its float64
+    confirmation of near ties is only needed -- and only asked for -- after the LAST generation, optimize.py:427), tell."""
     bounds = bounds_fn(base, targets)
     lower, upper = bounds[:, 0], bounds[:, 1]
     cols = [L.PARAM_KEYS.index(t) for t in targets]
@@ -242,7 +244,7 @@ def cma_loop(L, CMA, pts, base, targets, bounds_fn, pop, loss_kind, f_scale, see
         cand = np.tile(basev, (pop, 1))
         cand[:, cols] = X * (upper - lower) + lower
         t1 = time.perf_counter()
-        losses, amin = pts.eval_population(cand, loss_kind, f_scale)
+        losses, amin = pts.eval_population(cand, loss_kind, f_scale, want_argmin=False)
         t2 = time.perf_counter()
         opt.tell_population(X, losses)
         t3 = time.perf_counter()

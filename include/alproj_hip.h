@@ -182,6 +182,9 @@ int alp_residuals_batch(alp_points_t *pts, const double *cand, int64_t B, double
  * of those candidates are evaluated again in float64 arithmetic on the stored points before
  * the index is returned (the north star's "argmin bit-exact"); loss_out then holds the
  * float64 re-evaluations for THOSE candidates and the float32-path losses for all others.
+ * argmin_out == NULL: losses only, no confirmation pass (the reference uses the argmin of the LAST
+ * generation only, src/alproj/optimize.py:427; every earlier generation needs the losses for
+ * CMA.tell and nothing else).
  */
 int alp_eval_population(alp_points_t *pts, const double *cand, int64_t P, int loss_kind,
                         double f_scale, double *loss_out, int64_t *argmin_out);

@@ -66,7 +66,7 @@ def main():
         """what alproj_amd._lib.Points is to the optimisers, on this rank's shard"""
         precision, n = _lib.ALP_F64, hi - lo
 
-        def eval_population(self, cand, kind, f_scale):
+        def eval_population(self, cand, kind, f_scale, want_argmin=True):
             sums = np.empty(len(cand))
             for i, c in enumerate(cand):
                 p = orc.vector_to_params(c)

@@ -128,7 +128,7 @@ def _single_process_lsq(points=slice(None)):
     class AllPoints:
         precision, n = _lib.ALP_F64, len(xyz)
 
-        def eval_population(self, cand, kind, f_scale):
+        def eval_population(self, cand, kind, f_scale, want_argmin=True):
             return np.array([orc.mean_distance(uv, orc.project_points(xyz, orc.vector_to_params(c))) for c in cand]), 0
 
         def residuals(self, vec):

@@ -106,9 +106,9 @@ def test_optimisers_take_rank0s_seed_and_candidates_on_the_device(monkeypatch):
     monkeypatch.setattr(aopt, "CMA", SpyCMA)
     real_eval = L.Points.eval_population
 
-    def spy_eval(self, cand, kind, f_scale=10.0):
-        events.append(("eval", np.array(cand, copy=True)))
-        return real_eval(self, cand, kind, f_scale)
+    def spy_eval(self, cand, kind, f_scale=10.0, want_argmin=True):
+        events.append(("eval", np.array(cand, copy=True), want_argmin))
+        return real_eval(self, cand, kind, f_scale, want_argmin)
 
     monkeypatch.setattr(L.Points, "eval_population", spy_eval)
     o = aopt.CMAOptimizer(obj, img, init)
@@ -117,6 +117,8 @@ def test_optimisers_take_rank0s_seed_and_candidates_on_the_device(monkeypatch):
     params, err = o.optimize(generation=gens, sigma=0.3, population_size=pop, f_scale=10.0, seed=None, progress=False, precision="f64")
     kinds = [e[0] for e in events]
     assert kinds == ["bcast", "cma"] + ["bcast", "eval", "tell"] * gens + ["eval"]
+    # the argmin (with its float64 confirmation on float32 sets) is asked for in the LAST generation only (optimize.py:427)
+    assert [e[2] for e in events if e[0] == "eval"] == [False] * (gens - 1) + [True, True]
     assert events[0][1:] == ("uint64", (1,)) and events[1][1] == 424242           # the sampler is built from rank 0's seed
     bounds = aopt.bounds_to_array(init, o.target_params)
     cols = [L.PARAM_KEYS.index(t) for t in o.target_params]
