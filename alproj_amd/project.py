@@ -401,8 +401,11 @@ class ReverseProjection:
         _write_geotiff(raster, bounds, output_path, crs, bands, nodata)
 
     def close(self):
-        if self._owns and self.mesh is not None:
-            self.mesh.close()
+        if self.mesh is not None:
+            if self._owns:
+                self.mesh.close()
+            elif getattr(self.mesh, "_h", None) and hasattr(self.mesh, "trim"):
+                self.mesh.trim()          # somebody else's mesh (a handle, the opt-in cache): give back the rasterisation work area
         self.mesh = None
 
     def __enter__(self):

@@ -215,7 +215,7 @@ def parity_report(got, ref, w):
 def pmc_traffic(name):
     """HBM bytes per launch measured with rocprofv3 --pmc in separate passes (FETCH_SIZE x2 on gfx950 +
     WRITE_SIZE, as MI355X_MICROARCH.md prescribes); the newest committed round wins."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         f = os.path.join(PROFILES, f"{rnd}_{name}_pmc_traffic.json")
         if os.path.exists(f):
             try:
