@@ -28,9 +28,23 @@ __global__ __launch_bounds__(256) void surface_zmin_kernel(const Z *__restrict__
                                                            unsigned long long *__restrict__ out) {
     double m = __builtin_inf();
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    // 16 bytes per lane and turn (one dword per lane ran at 2.1 TB/s: 0.19 ms for the 400 MB of a 10 000 x 10 000 DSM)
+    constexpr int V = 16 / (int)sizeof(Z);
+    struct alignas(16) Pack { Z v[V]; };
+    const long long nv = n / V;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nv; k += stride) {
+        const Pack p = reinterpret_cast<const Pack *>(dsm)[k];       // hipMalloc'ed: 256-byte aligned
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            double z = (double)p.v[j];
+            if (z < 0) z = 0;                // surface.py:175
+            if (z > z_max) z = z_max;        // surface.py:176
+            m = z < m ? z : m;               // a NaN elevation never becomes the minimum (numpy would return NaN)
+        }
+    }
+    for (long long i = nv * V + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const double z = surface_z(dsm, i, z_max);
-        m = z < m ? z : m;                   // a NaN elevation never becomes the minimum (numpy would return NaN)
+        m = z < m ? z : m;
     }
     for (int d = 32; d >= 1; d >>= 1) {
         const double o = __shfl_xor(m, d);

@@ -70,7 +70,10 @@ class Hub:
         conns = [None] * self.world
         try:
             # the listening socket gets a timeout so that a rank which never starts does not park the hub for ever
-            self.listener._listener._socket.settimeout(COLLECTIVE_TIMEOUT_S)
+            try:
+                self.listener._listener._socket.settimeout(COLLECTIVE_TIMEOUT_S)
+            except AttributeError:      # another Python's Listener internals: the launcher's wall-clock limit still holds
+                pass
             for _ in range(self.world):
                 c = self.listener.accept()
                 op, rank = c.recv()
@@ -233,14 +236,19 @@ class Control:
             self._announce = None
 
 
+try:        # resolved HERE, in the parent: between fork and exec a child must not import or dlopen anything
+    import ctypes as _ctypes
+    _prctl = _ctypes.CDLL("libc.so.6", use_errno=True).prctl
+except Exception:       # not Linux / no libc by that name: ranks then notice a dead launcher at their next collective
+    _prctl = None
+_SIGTERM = int(signal.SIGTERM)
+
+
 def _die_with_parent():
-    """preexec of a child: SIGTERM when the parent goes away (Linux PR_SET_PDEATHSIG), so that no rank outlives a
-    killed launcher and keeps a GPU busy"""
-    try:
-        import ctypes
-        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM)
-    except Exception:
-        pass
+    """preexec of a child: SIGTERM when the parent goes away (Linux PR_SET_PDEATHSIG = 1), so that no rank outlives a
+    killed launcher and keeps a GPU busy.  One call of an already loaded C function, nothing else."""
+    if _prctl is not None:
+        _prctl(1, _SIGTERM)
 
 
 def _stop(procs, grace_s=5.0):

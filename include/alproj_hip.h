@@ -106,7 +106,8 @@ const char *alp_build_flags(void);
 
 /* ---------------------------------------------------------------- multi-GPU (RCCL) ---- */
 /* One process per GPU.  Rank 0 calls alp_comm_unique_id and ships the 128 bytes to the
- * other ranks by any means (the Python side uses the torchrun rendezvous); every rank then
+ * other ranks by any means (the Python side: a localhost socket served by its own launcher, alproj_amd/launch.py, a
+ * shared file, or a torch.distributed process group -- alproj_amd/dist.py); every rank then
  * calls alp_comm_init.  With a communicator present, alp_eval_population sums the
  * per-candidate partial losses and the vertex counts of all ranks with ONE
  * ncclAllReduce(sum, double, P+1) per call, on the library stream. */
