@@ -50,7 +50,14 @@ __global__ __launch_bounds__(256) void surface_zmin_kernel(const Z *__restrict__
         const double o = __shfl_xor(m, d);
         m = o < m ? o : m;
     }
-    if ((threadIdx.x & 63) == 0) atomicMin(out, (unsigned long long)__double_as_longlong(m));
+    // one atomic per workgroup: 8 192 waves on one address took longer than reading the DSM
+    __shared__ double s_m[4];
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) m = s_m[w] < m ? s_m[w] : m;
+        atomicMin(out, (unsigned long long)__double_as_longlong(m));
+    }
 }
 
 template <typename Z, typename A>
@@ -199,7 +206,7 @@ int alp_mesh_from_rasters(const void *dsm, int dsm_dtype, int64_t rows, int64_t 
     hipError_t e = hipMemcpyAsync(zmin_dev, &inf_bits, 8, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
         KTimeScope kt;
-        const dim3 grid((unsigned)(ctx().cu_count * 8));
+        const dim3 grid((unsigned)(ctx().cu_count * 4));
         if (dsm_dtype == ALP_F32)
             hipLaunchKernelGGL(surface_zmin_kernel<float>, grid, dim3(256), 0, st, (const float *)dsm_dev, (long long)n, z_max, zmin_dev);
         else

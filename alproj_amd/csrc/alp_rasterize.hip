@@ -513,39 +513,54 @@ __device__ __forceinline__ unsigned f2ord(float f) {
 }
 __device__ __forceinline__ float ord2f(unsigned o) { return __uint_as_float((o >> 31) ? (o & 0x7fffffffu) : ~o); }
 
-__global__ __launch_bounds__(256) void rz_median_key32_kernel(const unsigned *__restrict__ cell, const double *__restrict__ values,
-                                                              long long n, int nb, int band, unsigned long long *__restrict__ key,
-                                                              unsigned *__restrict__ not_f32) {
+// what kind of values does the band hold?  flag bit 0: some value is not a float32; bit 1: some value is not an integer in
+// [0, 65535] (image bytes and 16-bit samples are: their composite key needs 16 value bits, two radix passes fewer)
+__global__ __launch_bounds__(256) void rz_median_check_kernel(const double *__restrict__ values, long long n, int nb, int band,
+                                                              unsigned *__restrict__ flag) {
     const long long stride = (long long)gridDim.x * blockDim.x;
-    bool bad = false;
+    unsigned bad = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const double val = values[i * nb + band];
-        const float f = (float)val;
-        if (val == val && (double)f != val) bad = true;
-        // NaN: behind every cell (cells are below 2^31)
-        key[i] = val != val ? ~0ull : (((unsigned long long)cell[i] << 32) | (unsigned long long)f2ord(f));
+        if (val != val) continue;
+        if ((double)(float)val != val) bad |= 1u;
+        if (!(val >= 0.0 && val <= 65535.0 && val == (double)(unsigned)val)) bad |= 2u;
     }
-    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(not_f32, 1u);
+    for (int m = 32; m >= 1; m >>= 1) bad |= (unsigned)__shfl_xor((int)bad, m, 64);
+    if (bad && (threadIdx.x & 63) == 0) atomicOr(flag, bad);
 }
 
+// VBITS = 32: key = cell : order-preserving float32 bits; VBITS = 16: key = cell : the integer itself
+template <int VBITS>
+__global__ __launch_bounds__(256) void rz_median_key_kernel(const unsigned *__restrict__ cell, const double *__restrict__ values,
+                                                            long long n, int nb, int band, unsigned long long *__restrict__ key) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double val = values[i * nb + band];
+        const unsigned long long lo = VBITS == 32 ? (unsigned long long)f2ord((float)val) : (unsigned long long)(unsigned)val;
+        key[i] = val != val ? ~0ull : (((unsigned long long)cell[i] << VBITS) | lo);      // NaN: behind every cell (cells are below 2^31)
+    }
+}
+
+template <int VBITS>
 __global__ __launch_bounds__(256) void rz_median_runs32_kernel(const unsigned long long *__restrict__ key_s, long long n,
                                                                float *__restrict__ raster_band) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const unsigned long long k0 = key_s[i];
-        const unsigned c = (unsigned)(k0 >> 32);
-        if (k0 == ~0ull || (i > 0 && (unsigned)(key_s[i - 1] >> 32) == c)) continue;      // NaN tail, or not the head of a run
+        const unsigned c = (unsigned)(k0 >> VBITS);
+        if (k0 == ~0ull || (i > 0 && (unsigned)(key_s[i - 1] >> VBITS) == c)) continue;      // NaN tail, or not the head of a run
         // the run's end: gallop, then bisect (a load per element would cost a run of thousands a millisecond)
         long long lo = i, step = 1;                            // key_s[lo] is in the run
-        while (lo + step < n && (unsigned)(key_s[lo + step] >> 32) == c) { lo += step; step <<= 1; }
+        while (lo + step < n && key_s[lo + step] != ~0ull && (unsigned)(key_s[lo + step] >> VBITS) == c) { lo += step; step <<= 1; }
         long long hi = lo + step < n ? lo + step : n;         // key_s[hi] is not (or hi == n)
         while (hi - lo > 1) {
             const long long mid = lo + ((hi - lo) >> 1);
-            if ((unsigned)(key_s[mid] >> 32) == c) lo = mid; else hi = mid;
+            if (key_s[mid] != ~0ull && (unsigned)(key_s[mid] >> VBITS) == c) lo = mid; else hi = mid;
         }
         const long long k = hi - i;
-        const double a = (double)ord2f((unsigned)key_s[i + (k - 1) / 2]);
-        const double b = (double)ord2f((unsigned)key_s[i + k / 2]);
+        const unsigned long long ka = key_s[i + (k - 1) / 2], kb = key_s[i + k / 2];
+        const double a = VBITS == 32 ? (double)ord2f((unsigned)ka) : (double)(unsigned)(ka & 0xFFFFull);
+        const double b = VBITS == 32 ? (double)ord2f((unsigned)kb) : (double)(unsigned)(kb & 0xFFFFull);
         raster_band[c] = (float)((k & 1) ? a : (a + b) / 2);
     }
 }
@@ -733,16 +748,22 @@ static int run_rasterize(int agg, const double *dx, const double *dy, const doub
         for (int b = 0; b < nb && e == hipSuccess; ++b) {
             e = hipMemsetAsync(flag, 0, sizeof(unsigned), st);
             if (e != hipSuccess) break;
-            hipLaunchKernelGGL(rz_median_key32_kernel, dim3(grid(n)), dim3(256), 0, st, cell, dv, n, nb, b, key, flag);
-            unsigned not_f32 = 0;
-            e = hipMemcpyAsync(&not_f32, flag, sizeof(unsigned), hipMemcpyDeviceToHost, st);
+            hipLaunchKernelGGL(rz_median_check_kernel, dim3(grid(n)), dim3(256), 0, st, dv, n, nb, b, flag);
+            unsigned kind = 3;
+            e = hipMemcpyAsync(&kind, flag, sizeof(unsigned), hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) break;
             size_t t = tmp;
-            if (!not_f32) {
-                e = rocprim::radix_sort_keys(sort_tmp, t, key, key_s, count, 0u, 64u, st);      // the NaN keys (all ones) end up last
+            if (!(kind & 2u)) {             // integers below 2^16: cell : value in cell_bits + 16 bits (the NaN keys, all ones, end up last)
+                hipLaunchKernelGGL(rz_median_key_kernel<16>, dim3(grid(n)), dim3(256), 0, st, cell, dv, n, nb, b, key);
+                e = rocprim::radix_sort_keys(sort_tmp, t, key, key_s, count, 0u, std::min(64u, cell_bits + 17u), st);
                 if (e != hipSuccess) break;
-                hipLaunchKernelGGL(rz_median_runs32_kernel, dim3(grid(n)), dim3(256), 0, st, key_s, n, ra + b * hw);
+                hipLaunchKernelGGL(rz_median_runs32_kernel<16>, dim3(grid(n)), dim3(256), 0, st, key_s, n, ra + b * hw);
+            } else if (!(kind & 1u)) {      // float32 values
+                hipLaunchKernelGGL(rz_median_key_kernel<32>, dim3(grid(n)), dim3(256), 0, st, cell, dv, n, nb, b, key);
+                e = rocprim::radix_sort_keys(sort_tmp, t, key, key_s, count, 0u, 64u, st);
+                if (e != hipSuccess) break;
+                hipLaunchKernelGGL(rz_median_runs32_kernel<32>, dim3(grid(n)), dim3(256), 0, st, key_s, n, ra + b * hw);
             } else {
                 // values that are not float32: by value (64-bit keys), then stably by cell
                 hipLaunchKernelGGL(rz_median_keys_kernel, dim3(grid(n)), dim3(256), 0, st, cell, dv, n, nb, b, key, idx, cell3);
