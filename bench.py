@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--no-dropin", action="store_true", help="skip the reference-typed sim_image + reverse_proj call pair (9.6 GB of host arrays)")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the SURVEY 8(f) rows f1-f4 and the full-size pipeline")
     ap.add_argument("--launch-timeout", type=float, default=3000.0, help="wall-clock limit of a self-launched multi-rank job (s)")
+    ap.add_argument("--debug-share-device", action="store_true",
+                    help="DEVELOPMENT: all ranks use device 0 and no RCCL communicator is made (RCCL refuses two ranks on one GPU): "
+                         "walks the multi-rank control flow of this script on a 1-GPU box; the line it prints is marked and means nothing")
     ap.add_argument("--launch-selftest", action="store_true", help="run the launch / control plane with a stub worker (no GPU, no library)")
     ap.add_argument("--selftest-fail-rank", type=int, default=-1, help="selftest: this rank exits with code 7 after the first barrier")
     ap.add_argument("--selftest-hang-rank", type=int, default=-1, help="selftest: this rank never reaches the second barrier")
@@ -482,9 +485,15 @@ def main():
     from alproj_amd.optimize import bounds_to_array      # the product's own host logic
     from oracle import ref_numpy as orc       # checker (parity spot check) and cpu_baseline only
 
-    adist.init_comm(ctl.rank, ctl.world, ctl.bcast_bytes, ctl.local_rank)
+    if args.debug_share_device:
+        L.init(0)
+        ctl.bcast_bytes(b"\0" * 128)             # the id's trip is still made
+    else:
+        adist.init_comm(ctl.rank, ctl.world, ctl.bcast_bytes, ctl.local_rank)
     info = L.device_info()
     comm_rank, comm_world = L.comm_info()
+    if args.debug_share_device:
+        comm_rank, comm_world = ctl.rank, ctl.world
     # the communicator the LIBRARY reports must be the job: a rank that fell back to a world of its own would add
     # nothing to the all-reduce and the line would still look plausible
     print(f"bench.py: rank {ctl.rank}/{ctl.world} on device {ctl.local_rank} ({info.get('pci_bus_id')}): rccl rank {comm_rank} of {comm_world}",
@@ -571,7 +580,8 @@ def main():
         "parity": parity,
         "device": info, "setup_s": t_gen,
         # the communicator the library itself reports (ncclCommInitRank succeeded on every rank), and where every rank ran
-        "rccl": {"rank": comm_rank, "nranks": comm_world, "ranks": rank_devices},
+        "rccl": {"rank": comm_rank, "nranks": comm_world, "ranks": rank_devices} if not args.debug_share_device else
+                "NONE: --debug-share-device (all ranks on device 0, no communicator: this line is a control-flow check, not a measurement)",
         # SURVEY 8(d) c2 asks for the end-to-end figure beside the kernel figure; it is never `value`
         "pcie_inclusive": {"upload_s": t_up, "upload_s_second_time": t_up2,
                            "upload_gb_per_s_second_time": xyz_l.nbytes / t_up2 / 1e9, "fetch_uv_s": t_fetch,

@@ -22,7 +22,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 99)
 L.init(0)
 warnings.simplefilter("ignore")
 t_end = time.time() + budget
-n_cases = 0
+n_cases = n_f32 = 0
 names = ["R", "G", "B", "N"]
 while time.time() < t_end:
     n = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 1000, 5000, 40_000]))
@@ -34,7 +34,17 @@ while time.time() < t_end:
     xy = centres[which] + jitter
     x, y = 1000.0 + xy[:, 0], 5000.0 + xy[:, 1]
     nb = int(rng.integers(1, 5))
-    vals = rng.integers(0, 256, (n, nb)).astype(np.float64) if rng.random() < 0.6 else rng.uniform(-20, 300, (n, nb))
+    kind = rng.random()
+    if kind < 0.45:
+        vals = rng.integers(0, 256, (n, nb)).astype(np.float64)                    # image bytes
+    elif kind < 0.6:
+        vals = rng.integers(0, 65536, (n, nb)).astype(np.float64)                  # 16-bit samples
+    elif kind < 0.8:
+        vals = rng.uniform(-20, 300, (n, nb))
+    elif kind < 0.9:
+        vals = rng.uniform(-20, 300, (n, nb)).astype(np.float32).astype(np.float64)   # float32 values in float64 columns
+    else:
+        vals = 10.0 ** rng.uniform(-6, 6, (n, nb)) * rng.choice([-1.0, 1.0], (n, nb))  # mixed magnitudes: the ORDER of a sum shows
     if rng.random() < 0.4 and n > 3:
         vals[rng.integers(0, n, max(1, n // 20)), rng.integers(0, nb)] = np.nan
     res = float(rng.choice([0.5, 1.0, 2.0, 3.3]))
@@ -62,5 +72,16 @@ while time.time() < t_end:
         print(f"MISMATCH: n {n} nb {nb} res {res} agg {agg} interp {interp} max_dist {max_dist} nodata {nodata}: {len(bad)} bytes differ, first {bad[:3].tolist()} "
               f"got {got[tuple(bad[0])]} want {want[tuple(bad[0])]}", flush=True)
         sys.exit(1)
+    if rng.random() < 0.5:          # sharper than bytes: the float32 raster before the byte conversion, every bit
+        wf, _ = orc.rasterize_points(x, y, df[bands].to_numpy(), res, interp, max_dist, agg, nodata, return_float=True)
+        gf, _ = L.rasterize_points_f32(x, y, df[bands].to_numpy(), res, interp, max_dist, agg)
+        same = (gf.view(np.uint32) == wf.view(np.uint32)) | (np.isnan(gf) & np.isnan(wf))
+        if not same.all():
+            bad = np.argwhere(~same)
+            print(f"FLOAT32 MISMATCH: n {n} nb {nb} res {res} agg {agg} interp {interp} max_dist {max_dist}: {len(bad)} cells differ, first {bad[:3].tolist()} "
+                  f"got {gf[tuple(bad[0])]!r} want {wf[tuple(bad[0])]!r}", flush=True)
+            sys.exit(1)
+        n_f32 += 1
     n_cases += 1
-print(f"fuzz_rasterize: {n_cases} random cases, every raster byte-identical to the pandas / scipy restatement of the reference")
+print(f"fuzz_rasterize: {n_cases} random cases, every raster byte-identical to the pandas / scipy restatement of the reference; "
+      f"{n_f32} of them also compared as float32 rasters before the byte conversion: every bit equal")
