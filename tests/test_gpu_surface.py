@@ -281,3 +281,31 @@ def test_index_arrays_that_are_not_a_filtered_grid_stay_explicit(L, case):
         assert m.fetch_arrays()[2].all()                                          # no mask: not converted
         m.render_enqueue(L.params_vector(p), s["offsets"])
         np.testing.assert_array_equal(m.fetch_visibility(), ref)
+
+
+@pytest.mark.parametrize("shape", [(10, 6), (7, 12), (9, 5), (64, 2), (5, 8), (33, 33)])
+@pytest.mark.parametrize("dsm_dtype", [np.float32, np.float64])
+def test_mesh_from_rasters_any_shape(L, shape, dsm_dtype):
+    """alp_mesh_from_rasters on rasters that are not square (the reference's own index formula only works for square ones,
+    quirk Q15; its vertex and colour arrays, surface.py:173-193, 211, are defined for any shape): float64 coordinate minus
+    float64 offset then the float32 cast, clamped elevations, normalised colours, the validity mask -- bit for bit the numpy
+    expressions"""
+    rows, cols = shape
+    rng = np.random.default_rng(rows * 100 + cols)
+    dsm = (1500 + rng.normal(0, 30, (rows, cols))).astype(dsm_dtype)
+    dsm[0, 0] = -5.0                                           # clamped to 0 (surface.py:175)
+    aerial = rng.integers(0, 256, (3, rows, cols), dtype=np.uint8)
+    nodata = rng.random((rows, cols)) < 0.1
+    t = (2.0, 0.0, 732000.0, 0.0, -2.0, 4048000.0 + 2.0 * rows)
+    zmax = float(np.float32(1530.0))
+    mesh, off = L.Mesh.from_rasters(dsm, t, zmax, aerial, 255.0, nodata)
+    with mesh:
+        vert, col, valid = mesh.fetch_arrays()
+    z = np.clip(dsm.astype(np.float64), 0, zmax)                                       # :175-176
+    xx, yy = np.meshgrid(np.arange(cols) * t[0] + t[2], np.arange(rows) * t[4] + t[5])   # :179-181
+    ev = np.stack([xx.ravel(), z.ravel(), yy.ravel()], axis=1)                         # :189-190 (X, Z, Y)
+    eoff = ev.min(axis=0)                                                              # :211
+    np.testing.assert_array_equal(off, eoff)
+    np.testing.assert_array_equal(vert, (ev - eoff).astype(np.float32))
+    np.testing.assert_array_equal(col, (aerial.reshape(3, -1).T.astype(np.float64) / 255.0).astype(np.float32))
+    np.testing.assert_array_equal(valid, ~nodata.ravel())
