@@ -608,12 +608,6 @@ __global__ __launch_bounds__(256) void rz_median_runs_kernel(const unsigned *__r
     }
 }
 
-__global__ __launch_bounds__(256) void rz_fill_nan_kernel(float *__restrict__ p, long long total) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
-        p[i] = __int_as_float(0x7fc00000);
-}
-
 __global__ __launch_bounds__(256) void rz_focal_median_kernel(const float *__restrict__ src, float *__restrict__ dst,
                                                               int nb, int width, int height) {
     const long long hw = (long long)width * height;
