@@ -513,23 +513,28 @@ __device__ __forceinline__ unsigned f2ord(float f) {
 }
 __device__ __forceinline__ float ord2f(unsigned o) { return __uint_as_float((o >> 31) ? (o & 0x7fffffffu) : ~o); }
 
-// what kind of values does the band hold?  flag bit 0: some value is not a float32; bit 1: some value is not an integer in
-// [0, 65535] (image bytes and 16-bit samples are: their composite key needs 16 value bits, two radix passes fewer)
-__global__ __launch_bounds__(256) void rz_median_check_kernel(const double *__restrict__ values, long long n, int nb, int band,
+// what kind of values do the bands hold?  flag[band] bit 0: some value is not a float32; bit 1: some value is not an integer in
+// [0, 65535]; bit 2: not an integer in [0, 255] (image bytes and 16-bit samples: their composite key needs 8 / 16 value bits, three
+// / two radix passes fewer).  All bands in one launch: one wait of the host instead of one per band.
+__global__ __launch_bounds__(256) void rz_median_check_kernel(const double *__restrict__ values, long long count, int nb,
                                                               unsigned *__restrict__ flag) {
     const long long stride = (long long)gridDim.x * blockDim.x;
-    unsigned bad = 0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const double val = values[i * nb + band];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const double val = values[i];
         if (val != val) continue;
+        unsigned bad = 0;
         if ((double)(float)val != val) bad |= 1u;
-        if (!(val >= 0.0 && val <= 65535.0 && val == (double)(unsigned)val)) bad |= 2u;
+        const bool whole = val >= 0.0 && val <= 65535.0 && val == (double)(unsigned)val;
+        if (!whole) bad |= 6u;
+        else if (val > 255.0) bad |= 4u;
+        if (bad) {
+            unsigned *f = flag + (int)(i % nb);
+            if ((*f & bad) != bad) atomicOr(f, bad);           // a plain look first: the word settles after a few writers
+        }
     }
-    for (int m = 32; m >= 1; m >>= 1) bad |= (unsigned)__shfl_xor((int)bad, m, 64);
-    if (bad && (threadIdx.x & 63) == 0) atomicOr(flag, bad);
 }
 
-// VBITS = 32: key = cell : order-preserving float32 bits; VBITS = 16: key = cell : the integer itself
+// VBITS = 32: key = cell : order-preserving float32 bits; VBITS = 16 / 8: key = cell : the integer itself
 template <int VBITS>
 __global__ __launch_bounds__(256) void rz_median_key_kernel(const unsigned *__restrict__ cell, const double *__restrict__ values,
                                                             long long n, int nb, int band, unsigned long long *__restrict__ key) {
@@ -559,8 +564,8 @@ __global__ __launch_bounds__(256) void rz_median_runs32_kernel(const unsigned lo
         }
         const long long k = hi - i;
         const unsigned long long ka = key_s[i + (k - 1) / 2], kb = key_s[i + k / 2];
-        const double a = VBITS == 32 ? (double)ord2f((unsigned)ka) : (double)(unsigned)(ka & 0xFFFFull);
-        const double b = VBITS == 32 ? (double)ord2f((unsigned)kb) : (double)(unsigned)(kb & 0xFFFFull);
+        const double a = VBITS == 32 ? (double)ord2f((unsigned)ka) : (double)(unsigned)(ka & ((1ull << VBITS) - 1ull));
+        const double b = VBITS == 32 ? (double)ord2f((unsigned)kb) : (double)(unsigned)(kb & ((1ull << VBITS) - 1ull));
         raster_band[c] = (float)((k & 1) ? a : (a + b) / 2);
     }
 }
@@ -739,16 +744,25 @@ static int run_rasterize(int agg, const double *dx, const double *dy, const doub
             e = hipGetLastError();
         }
     } else if (e == hipSuccess) {
+        // one flag word per band (nb <= 64), parked at the head of the sorted-key buffer: the first sort writes that buffer only after the
+        // flags have been read
+        unsigned *kinds_dev = (unsigned *)key_s;
+        unsigned kinds[64];
+        e = hipMemsetAsync(kinds_dev, 0, (size_t)nb * sizeof(unsigned), st);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(rz_median_check_kernel, dim3(grid(n * nb)), dim3(256), 0, st, dv, n * nb, nb, kinds_dev);
+            e = hipMemcpyAsync(kinds, kinds_dev, (size_t)nb * sizeof(unsigned), hipMemcpyDeviceToHost, st);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
         for (int b = 0; b < nb && e == hipSuccess; ++b) {
-            e = hipMemsetAsync(flag, 0, sizeof(unsigned), st);
-            if (e != hipSuccess) break;
-            hipLaunchKernelGGL(rz_median_check_kernel, dim3(grid(n)), dim3(256), 0, st, dv, n, nb, b, flag);
-            unsigned kind = 3;
-            e = hipMemcpyAsync(&kind, flag, sizeof(unsigned), hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
-            if (e != hipSuccess) break;
+            const unsigned kind = kinds[b];
             size_t t = tmp;
-            if (!(kind & 2u)) {             // integers below 2^16: cell : value in cell_bits + 16 bits (the NaN keys, all ones, end up last)
+            if (!(kind & 4u)) {             // bytes: cell : value in cell_bits + 8 bits (the NaN keys, all ones, end up last)
+                hipLaunchKernelGGL(rz_median_key_kernel<8>, dim3(grid(n)), dim3(256), 0, st, cell, dv, n, nb, b, key);
+                e = rocprim::radix_sort_keys(sort_tmp, t, key, key_s, count, 0u, std::min(64u, cell_bits + 9u), st);
+                if (e != hipSuccess) break;
+                hipLaunchKernelGGL(rz_median_runs32_kernel<8>, dim3(grid(n)), dim3(256), 0, st, key_s, n, ra + b * hw);
+            } else if (!(kind & 2u)) {      // integers below 2^16: cell : value in cell_bits + 16 bits
                 hipLaunchKernelGGL(rz_median_key_kernel<16>, dim3(grid(n)), dim3(256), 0, st, cell, dv, n, nb, b, key);
                 e = rocprim::radix_sort_keys(sort_tmp, t, key, key_s, count, 0u, std::min(64u, cell_bits + 17u), st);
                 if (e != hipSuccess) break;
