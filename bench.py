@@ -496,7 +496,9 @@ def main():
         comm_rank, comm_world = ctl.rank, ctl.world
     # the communicator the LIBRARY reports must be the job: a rank that fell back to a world of its own would add
     # nothing to the all-reduce and the line would still look plausible
-    print(f"bench.py: rank {ctl.rank}/{ctl.world} on device {ctl.local_rank} ({info.get('pci_bus_id')}): rccl rank {comm_rank} of {comm_world}",
+    device = 0 if args.debug_share_device else ctl.local_rank
+    print(f"bench.py: rank {ctl.rank}/{ctl.world} on device {device} ({info.get('pci_bus_id')}): rccl rank {comm_rank} of {comm_world}"
+          + (" [--debug-share-device: no communicator]" if args.debug_share_device else ""),
           file=sys.stderr, flush=True)
     if comm_world != args.gpus or comm_rank != ctl.rank:
         print(f"bench.py: RCCL communicator has {comm_world} ranks (this one is {comm_rank}) but --gpus is {args.gpus}",
@@ -505,7 +507,7 @@ def main():
     if L.build_flags():
         print(f"bench.py: libalproj_hip.so was built with development switches: {L.build_flags()}", file=sys.stderr)
         sys.exit(4)
-    rank_devices = ctl.gather({"rank": ctl.rank, "device": ctl.local_rank, "pci_bus_id": info.get("pci_bus_id"),
+    rank_devices = ctl.gather({"rank": ctl.rank, "device": device, "pci_bus_id": info.get("pci_bus_id"),
                                "rccl_rank": comm_rank, "rccl_nranks": comm_world, "pid": os.getpid()})
 
     # ---------------------------------------------------------------- workload
