@@ -29,14 +29,14 @@ namespace alp {
 
 enum { AGG_MEAN = 0, AGG_MAX = 1, AGG_MIN = 2 };
 
-// ALP_RZ_SEPARATE_PASSES=1: finalize / sweep / conversion as separate kernels whatever the sweep count (the path for more than
-// RZ_SMAX sweeps); the tests run both and compare bytes
+// ALP_RZ_SEPARATE_PASSES=1: sweeps and byte conversion as separate kernels over the whole float32 raster whatever the sweep
+// count (the path for more than RZ_SMAX sweeps); the tests run both and compare bytes
 static bool rz_separate_passes() {
     const char *e = getenv("ALP_RZ_SEPARATE_PASSES");
     return e && e[0] == '1';
 }
 
-// order-preserving map double -> uint64 (so that integer atomicMax/Min order like the doubles)
+// order-preserving map double -> uint64 (radix-sort keys of the median; the bounds of the rasterisation plan)
 __device__ __forceinline__ unsigned long long d2ord(double d) {
     const unsigned long long u = (unsigned long long)__double_as_longlong(d);
     return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
@@ -343,13 +343,12 @@ __global__ __launch_bounds__(256) void rz_to_u8_kernel(const float *__restrict__
 }
 
 // ------------------------------------------------------------------ fused tail
-// finalize + up to RZ_SMAX focal sweeps + uint8 in ONE pass over the raster: a workgroup owns a tile of RZ_TW x RZ_TH cells,
-// forms the float32 raster of the tile and a halo of S cells in LDS (a cell S sweeps later depends on the cells within S of
-// it, nothing else), sweeps there -- each sweep is valid on a region one cell smaller all round -- and writes bytes only.
+// up to RZ_SMAX focal sweeps + uint8 in ONE pass over the raster: a workgroup owns a tile of RZ_TW x RZ_TH cells, loads the
+// float32 raster of the tile and a halo of S cells into LDS (a cell S sweeps later depends on the cells within S of it,
+// nothing else), sweeps there -- each sweep is valid on a region one cell smaller all round -- and writes bytes only.
 // Every value is formed by the expressions of the separate kernels above (which stay as the path for more sweeps), so the
-// bytes are the same; the raster no longer crosses HBM as float32 three times (finalize, sweep, conversion: 2.24 ms of the
-// 3.79 ms of the 3 x 8088 x 9786 raster of bench.py's f2 leg), and a tile whose cells and halo are all empty -- most of a
-// georectified photograph's bounding box -- skips its sweeps.
+// bytes are the same; the raster does not cross HBM as float32 once per sweep and once more for the conversion, and a
+// tile whose own and neighbouring tiles hold no point -- most of a georectified photograph's bounding box -- reads nothing.
 constexpr int RZ_TW = 64, RZ_TH = 32, RZ_SMAX = 8;
 enum { AGG_MEDIAN_FOCAL = 3 };
 
