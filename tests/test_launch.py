@@ -175,3 +175,34 @@ def test_host_digest_sees_every_word_and_ignores_the_thread_count():
         assert _lib.host_hash64(v) != du
     assert _lib.host_hash64(u[:0]) != _lib.host_hash64(np.zeros(1, np.uint8))
     assert _lib.host_hash64(np.zeros(8, np.uint8)) != _lib.host_hash64(np.zeros(9, np.uint8))
+
+
+def test_ranks_that_disagree_on_the_collective_are_told_so():
+    hub = launch.Hub(2).start()
+    errs = [None, None]
+
+    def rank(r, op):
+        c = launch.Control(r, 2, r, launch.Control._connect(lambda: (hub.address, hub.authkey), r, 30.0))
+        try:
+            c.barrier() if op == "barrier" else c.max(1.0)
+        except launch.LaunchError as e:
+            errs[r] = str(e)
+
+    th = [threading.Thread(target=rank, args=(0, "barrier")), threading.Thread(target=rank, args=(1, "max"))]
+    [t.start() for t in th]
+    [t.join(30) for t in th]
+    hub.join(5)
+    assert all(e and "disagree" in e for e in errs) and "disagree" in hub.error
+
+
+def test_spawn_returns_the_first_failing_code_and_zero_otherwise(tmp_path):
+    """launch.spawn itself (what bench.py's launcher calls) on two tiny scripts"""
+    ok = tmp_path / "ok.py"
+    ok.write_text("import os, sys\nsys.path.insert(0, %r)\nfrom alproj_amd import launch\nc = launch.Control.from_env()\n"
+                  "v = c.gather(c.rank)\nc.close()\nassert v == list(range(c.world))\n" % ROOT)
+    bad = tmp_path / "bad.py"
+    bad.write_text("import os, sys, time\nsys.exit(5) if os.environ['RANK'] == '2' else time.sleep(60)\n")
+    assert launch.spawn([sys.executable, str(ok)], 4, timeout_s=60) == 0
+    t0 = time.time()
+    assert launch.spawn([sys.executable, str(bad)], 3, timeout_s=60, log=open(os.devnull, "w")) == 5
+    assert time.time() - t0 < 30                                  # the sleeping ranks were ended, not waited for
