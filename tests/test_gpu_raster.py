@@ -80,6 +80,35 @@ def test_visibility_bit_exact(L, scene, name, detect, monkeypatch):
         assert (ref != 0).mean() > 0.3
 
 
+@pytest.mark.parametrize("name", ["tilt_roll", "low_near_plane", "inside_looking_north", "tele"])
+def test_index_kernel_with_mask_shuffled_array_and_near_plane(L, scene, name, monkeypatch):
+    """the per-triangle index kernel on an array no grid detector can use -- shuffled, with a vertex mask, with triangles that
+    cross the near plane: the oracle's visibility, triangle ids in the caller's numbering"""
+    monkeypatch.setenv("ALP_NO_GRID_DETECT", "1")
+    p = dict(scene["params"])
+    d = dict(POSES[name] if name in POSES else MORE_POSES[name])
+    p["x"] += d.pop("dx", 0.0)
+    p["y"] += d.pop("dy", 0.0)
+    p["z"] += d.pop("dz", 0.0)
+    p.update(d)
+    rng = np.random.default_rng(5)
+    ind = scene["ind"].astype(np.int32)[rng.permutation(len(scene["ind"]))]
+    valid = rng.random(len(scene["vert"])) > 0.03
+    keep = valid[ind].all(axis=1)
+    ref = orast.visibility(scene["vert"], ind[keep], p, scene["offsets"])
+    ids = np.flatnonzero(keep)                  # the oracle numbers the kept triangles 0..K-1, the device the caller's array
+    with L.Mesh(scene["vert"], None, ind) as m:
+        m.set_valid(valid)
+        m.render_enqueue(L.params_vector(p), scene["offsets"])
+        got = m.fetch_visibility()
+    hit = ref != 0
+    np.testing.assert_array_equal(got != 0, hit)
+    np.testing.assert_array_equal(got[hit] >> np.uint64(32), ref[hit] >> np.uint64(32))
+    tri_dev = 0xFFFFFFFF - (got[hit] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    tri_ref = 0xFFFFFFFF - (ref[hit] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    np.testing.assert_array_equal(tri_dev, ids[tri_ref])
+
+
 def test_implicit_grid_and_int32_indices(L, scene):
     p = pose(scene, "tilt_roll")
     n = scene["n"]
