@@ -50,7 +50,7 @@ __device__ __forceinline__ double ord2d(unsigned long long o) {
 __global__ __launch_bounds__(256) void rz_cell_kernel(const double *__restrict__ x, const double *__restrict__ y, long long n,
                                                       double x_min, double y_max, double res, int width, int height,
                                                       unsigned *__restrict__ cell, unsigned *__restrict__ idx,
-                                                      unsigned char *__restrict__ tile_used, int tiles_x) {
+                                                      unsigned char *__restrict__ tile_used, int tiles_x) {      // idx NULL: the slot holds packed band values
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         long long col = (long long)((x[i] - x_min) / res);
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void rz_cell_kernel(const double *__restrict__
         col = col < 0 ? 0 : (col > width - 1 ? width - 1 : col);
         row = row < 0 ? 0 : (row > height - 1 ? height - 1 : row);
         cell[i] = (unsigned)(row * width + col);
-        idx[i] = (unsigned)i;
+        if (idx) idx[i] = (unsigned)i;
         if (tile_used) tile_used[(row >> 5) * tiles_x + (col >> 6)] = 1;      // RZ_TH = 32, RZ_TW = 64; every writer writes 1
     }
 }
@@ -183,7 +183,9 @@ __device__ __forceinline__ float rz_piece_result(const RzPiece &p) {
 
 // first[t * nb + b]: the piece that CONTINUES a run from segment t - 1 (it starts at the segment's first position);
 // last[t * nb + b]: the piece that starts a run inside segment t (or at its first position) and continues into t + 1
-template <int AGG, int NB>
+// PACKED: `id` is not the point's index but its (at most four) byte-valued band values, one byte each -- the sort carried them
+// along as its payload, nothing is gathered (image bytes: the reference's own use, project.py:364 on a uint8 photograph)
+template <int AGG, int NB, bool PACKED>
 __device__ __forceinline__ void rz_pieces_bands(const unsigned (&cs)[RZ_SEG], const unsigned (&id)[RZ_SEG], unsigned before, unsigned after,
                                                 int count, const double *__restrict__ values, int nb, int b0, long long hw, long long t,
                                                 float *__restrict__ raster, RzPiece *__restrict__ first, RzPiece *__restrict__ last) {
@@ -195,9 +197,14 @@ __device__ __forceinline__ void rz_pieces_bands(const unsigned (&cs)[RZ_SEG], co
 #pragma unroll
     for (int u = 0; u < RZ_SEG; ++u) {
         if (u >= count) break;
-        const double *row = values + (long long)id[u] * nb + b0;
+        if constexpr (PACKED) {
 #pragma unroll
-        for (int g = 0; g < NB; ++g) rz_piece_take<AGG>(pc[g], row[g]);
+            for (int g = 0; g < NB; ++g) rz_piece_take<AGG>(pc[g], (double)((id[u] >> (8 * (b0 + g))) & 0xFFu));
+        } else {
+            const double *row = values + (long long)id[u] * nb + b0;
+#pragma unroll
+            for (int g = 0; g < NB; ++g) rz_piece_take<AGG>(pc[g], row[g]);
+        }
         const unsigned nextc = u + 1 < count ? cs[u + 1 < RZ_SEG ? u + 1 : 0] : after;
         if (nextc != cs[u]) {                          // the run ends here
 #pragma unroll
@@ -216,7 +223,7 @@ __device__ __forceinline__ void rz_pieces_bands(const unsigned (&cs)[RZ_SEG], co
     }
 }
 
-template <int AGG>
+template <int AGG, bool PACKED = false>
 __global__ __launch_bounds__(256) void rz_pieces_kernel(const unsigned *__restrict__ cell_s, const unsigned *__restrict__ idx_s,
                                                         const double *__restrict__ values, long long n, int nb, long long hw,
                                                         float *__restrict__ raster, RzPiece *__restrict__ first,
@@ -233,10 +240,10 @@ __global__ __launch_bounds__(256) void rz_pieces_kernel(const unsigned *__restri
         const unsigned before = p0 > 0 ? cell_s[p0 - 1] : 0xFFFFFFFFu, after = p1 < n ? cell_s[p1] : 0xFFFFFFFFu;
         const int count = (int)(p1 - p0);
         int b0 = 0;
-        for (; b0 + 4 <= nb; b0 += 4) rz_pieces_bands<AGG, 4>(cs, id, before, after, count, values, nb, b0, hw, t, raster, first, last);
-        if (nb - b0 == 3) rz_pieces_bands<AGG, 3>(cs, id, before, after, count, values, nb, b0, hw, t, raster, first, last);
-        else if (nb - b0 == 2) rz_pieces_bands<AGG, 2>(cs, id, before, after, count, values, nb, b0, hw, t, raster, first, last);
-        else if (nb - b0 == 1) rz_pieces_bands<AGG, 1>(cs, id, before, after, count, values, nb, b0, hw, t, raster, first, last);
+        for (; b0 + 4 <= nb; b0 += 4) rz_pieces_bands<AGG, 4, PACKED>(cs, id, before, after, count, values, nb, b0, hw, t, raster, first, last);
+        if (nb - b0 == 3) rz_pieces_bands<AGG, 3, PACKED>(cs, id, before, after, count, values, nb, b0, hw, t, raster, first, last);
+        else if (nb - b0 == 2) rz_pieces_bands<AGG, 2, PACKED>(cs, id, before, after, count, values, nb, b0, hw, t, raster, first, last);
+        else if (nb - b0 == 1) rz_pieces_bands<AGG, 1, PACKED>(cs, id, before, after, count, values, nb, b0, hw, t, raster, first, last);
     }
 }
 
@@ -273,16 +280,30 @@ __global__ __launch_bounds__(256) void rz_join_kernel(const unsigned *__restrict
     }
 }
 
-// are all band values integers of magnitude below 2^31 (or NaN)?  flag |= 1 otherwise
+// what do the bands hold?  flag bit 0: some value is not an integer of magnitude below 2^31; bit 1: some value is not a byte
+// (an integer in [0, 255]; NaN is not a byte either: a packed value has no way to say "skip me")
 __global__ __launch_bounds__(256) void rz_integer_check_kernel(const double *__restrict__ values, long long count,
                                                                unsigned *__restrict__ flag) {
     const long long stride = (long long)gridDim.x * blockDim.x;
-    bool bad = false;
+    unsigned bad = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
         const double v = values[i];
-        if (v == v && !(fabs(v) < 2147483648.0 && v == (double)(long long)v)) bad = true;
+        if (v != v) { bad |= 2u; continue; }
+        if (!(fabs(v) < 2147483648.0 && v == (double)(long long)v)) bad |= 3u;
+        else if (!(v >= 0.0 && v <= 255.0)) bad |= 2u;
     }
-    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+    for (int m = 32; m >= 1; m >>= 1) bad |= (unsigned)__shfl_xor((int)bad, m, 64);
+    if (bad && (threadIdx.x & 63) == 0 && (*flag & bad) != bad) atomicOr(flag, bad);
+}
+
+// byte-valued bands (nb <= 4), interleaved float64 -> one packed word per point: the sort's payload
+__global__ __launch_bounds__(256) void rz_pack_kernel(const double *__restrict__ values, long long n, int nb, unsigned *__restrict__ packed) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        unsigned w = 0;
+        for (int b = 0; b < nb; ++b) w |= ((unsigned)values[i * nb + b] & 0xFFu) << (8 * b);
+        packed[i] = w;
+    }
 }
 
 // one sweep of the NaN-only 3x3 focal fill
@@ -356,20 +377,35 @@ template <int AGG>
 __device__ __forceinline__ float rz_window_value(const float *__restrict__ s, int lw, int at) {
     const float nan = __int_as_float(0x7fc00000);
     if constexpr (AGG == AGG_MEDIAN_FOCAL) {
+        // the window's values in order, its NaN behind them as +inf: a 25-exchange network for nine (no loop whose length
+        // differs from lane to lane: the insertion sort of rz_focal_median_kernel took 0.36 ms of the 100 M-vertex frame's tail,
+        // this 0.1x).  Equal values (and +-0) may come out in another order than there: the same numbers, and the tail writes bytes
         float w[9];
-        int have = 0;
+        int have = 0, k = 0;
 #pragma unroll
         for (int dr = -1; dr <= 1; ++dr)
 #pragma unroll
-            for (int dc = -1; dc <= 1; ++dc) {
+            for (int dc = -1; dc <= 1; ++dc, ++k) {
                 const float val = s[at + dr * lw + dc];
-                if (val != val) continue;
-                int k = have++;                                   // insertion sort of at most 9 values
-                while (k > 0 && w[k - 1] > val) { w[k] = w[k - 1]; --k; }
-                w[k] = val;
+                const bool ok = val == val;
+                have += ok;
+                w[k] = ok ? val : INFINITY;
             }
         if (!have) return nan;
-        return (have & 1) ? w[have / 2] : (float)(((double)w[have / 2 - 1] + (double)w[have / 2]) / 2);
+#define RZ_CE(i, j) { const float lo = w[i] < w[j] ? w[i] : w[j], hi = w[i] < w[j] ? w[j] : w[i]; w[i] = lo; w[j] = hi; }
+        RZ_CE(0, 3) RZ_CE(1, 7) RZ_CE(2, 5) RZ_CE(4, 8)
+        RZ_CE(0, 7) RZ_CE(2, 4) RZ_CE(3, 8) RZ_CE(5, 6)
+        RZ_CE(0, 2) RZ_CE(1, 3) RZ_CE(4, 5) RZ_CE(7, 8)
+        RZ_CE(1, 4) RZ_CE(3, 6) RZ_CE(5, 7)
+        RZ_CE(0, 1) RZ_CE(2, 4) RZ_CE(3, 5) RZ_CE(6, 8)
+        RZ_CE(2, 3) RZ_CE(4, 5) RZ_CE(6, 7)
+        RZ_CE(1, 2) RZ_CE(3, 4) RZ_CE(5, 6)
+#undef RZ_CE
+        const int ka = (have - 1) >> 1, kb = have >> 1;
+        float a = w[0], b = w[0];
+#pragma unroll
+        for (int u = 1; u < 9; ++u) { a = ka == u ? w[u] : a; b = kb == u ? w[u] : b; }
+        return (have & 1) ? a : (float)(((double)a + (double)b) / 2);
     } else {
         double w[9];
         int k = 0, have = 0;
@@ -399,105 +435,116 @@ __device__ __forceinline__ float rz_window_value(const float *__restrict__ s, in
 
 // the float32 raster the run kernels wrote (NaN = empty cell) -> S sweeps of the aggregate's own 3x3 window -> bytes
 // NaN into the float32 raster of the tiles that hold a point (all bands); the tail never reads the others
-__global__ __launch_bounds__(256) void rz_fill_tiles_kernel(float *__restrict__ raster, const unsigned char *__restrict__ tile_used,
-                                                            int nb, int width, int height, int tiles_x) {
-    const int t = (int)blockIdx.x;
-    if (!tile_used[t]) return;
-    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+// (the tiles: rz_tile_list_kernel's list; an entry = tile number | the 3 x 3 neighbourhood's "holds a point" bits << 20, bit 4 the
+// tile itself)
+constexpr int RZ_TILE_BITS = 20;
+__global__ __launch_bounds__(256) void rz_fill_tiles_kernel(float *__restrict__ raster, const unsigned *__restrict__ list,
+                                                            const unsigned *__restrict__ list_count, int nb, int width, int height,
+                                                            int tiles_x) {
+    const unsigned count = *list_count;
     const long long hw = (long long)width * height;
     const float nan = __int_as_float(0x7fc00000);
-    for (int k = threadIdx.x; k < RZ_TW * RZ_TH * nb; k += 256) {
-        const int b = k / (RZ_TW * RZ_TH), r = (k / RZ_TW) % RZ_TH, c = k % RZ_TW;
-        const int gr = ty * RZ_TH + r, gc = tx * RZ_TW + c;
-        if (gr < height && gc < width) raster[b * hw + (long long)gr * width + gc] = nan;
+    for (unsigned e = blockIdx.x; e < count; e += gridDim.x) {
+        const unsigned entry = list[e];
+        if (!((entry >> (RZ_TILE_BITS + 4)) & 1u)) continue;
+        const int t = (int)(entry & ((1u << RZ_TILE_BITS) - 1u));
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        for (int k = threadIdx.x; k < RZ_TW * RZ_TH * nb; k += 256) {
+            const int b = k / (RZ_TW * RZ_TH), r = (k / RZ_TW) % RZ_TH, c = k % RZ_TW;
+            const int gr = ty * RZ_TH + r, gc = tx * RZ_TW + c;
+            if (gr < height && gc < width) raster[b * hw + (long long)gr * width + gc] = nan;
+        }
     }
 }
 
-// tile_used (or NULL = every tile): one byte per RZ_TW x RZ_TH tile of the raster, non-zero where a point fell -- most of a
-// georectified photograph's bounding box is empty; a tile whose own and eight neighbouring bytes are zero writes nodata
-// without reading anything, and cells of unused neighbours are NaN without being read (they were never filled)
+// the tiles a sweep can reach -- those with a point in their own or one of their eight neighbouring tiles -- as a compact list
+// (any order): the fill and the tail walk it instead of launching a workgroup per tile of a mostly empty raster
+__global__ __launch_bounds__(256) void rz_tile_list_kernel(const unsigned char *__restrict__ tile_used, int tiles_x, int tiles_y,
+                                                           unsigned *__restrict__ list, unsigned *__restrict__ list_count) {
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= tiles_x * tiles_y) return;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    unsigned used9 = 0;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = ty + dy, xx = tx + dx;
+            if (yy >= 0 && yy < tiles_y && xx >= 0 && xx < tiles_x && tile_used[yy * tiles_x + xx]) used9 |= 1u << (3 * (dy + 1) + dx + 1);
+        }
+    if (used9) list[atomicAdd(list_count, 1u)] = (unsigned)t | (used9 << RZ_TILE_BITS);
+}
+
+// list: the tiles a sweep can reach (rz_tile_list_kernel) -- most of a georectified photograph's bounding box is empty; the
+// other tiles keep the nodata launch_tail filled `out` with (one wide fill instead of byte stores tile by tile), and cells
+// of neighbouring tiles without points are NaN without being read (they were never filled)
 template <int AGG>
 __global__ __launch_bounds__(256) void rz_tail_kernel(const float *__restrict__ raster, int width, int height, int S,
-                                                      int nodata, int tiles_x, int tiles_y, unsigned char *__restrict__ out,
-                                                      const unsigned char *__restrict__ tile_used) {
+                                                      int nodata, int tiles_x, int nb, unsigned char *__restrict__ out,
+                                                      const unsigned *__restrict__ list, const unsigned *__restrict__ list_count) {
     extern __shared__ float rz_tail_lds[];                   // two rasters of (RZ_TH + 2 S) x (RZ_TW + 2 S) floats: 18 KB at S = 1, 31 KB at S = 8
     __shared__ int s_any;
     const float nan = __int_as_float(0x7fc00000);
     const int tid = (int)threadIdx.x;
     const long long hw = (long long)width * height;
-    int t = (int)blockIdx.x;
-    const int tx = t % tiles_x;
-    t /= tiles_x;
-    const int ty = t % tiles_y;
-    const long long band_base = (long long)(t / tiles_y) * hw;
-    const int x0 = tx * RZ_TW - S, y0 = ty * RZ_TH - S;        // raster position of LDS cell (0, 0)
     const int lw = RZ_TW + 2 * S, lh = RZ_TH + 2 * S;
-    float *buf_cur = rz_tail_lds, *buf_nxt = rz_tail_lds + lw * lh;
     const float inv_lw = 1.0f / (float)lw;                       // idx / lw through (idx + 0.5) * (1 / lw): idx < 3840, exact
-    if (tid == 0) s_any = 0;
-    // which of the 3 x 3 tiles around this one hold points (bit 3 * (dy + 1) + (dx + 1))
-    unsigned used9 = 0x1FFu;
-    if (tile_used) {
-        used9 = 0;
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int yy = ty + dy, xx = tx + dx;
-                if (yy >= 0 && yy < tiles_y && xx >= 0 && xx < tiles_x && tile_used[yy * tiles_x + xx]) used9 |= 1u << (3 * (dy + 1) + dx + 1);
+    const unsigned work = list_count[0] * (unsigned)nb;          // (tile, band) pairs, the bands of a tile next to each other
+    for (unsigned item = blockIdx.x; item < work; item += gridDim.x) {
+        __syncthreads();                                             // the previous item's LDS is read no more
+        if (tid == 0) s_any = 0;
+        __syncthreads();
+        const unsigned entry = list[item / (unsigned)nb];
+        const int t = (int)(entry & ((1u << RZ_TILE_BITS) - 1u));
+        const unsigned used9 = entry >> RZ_TILE_BITS;                // which of the 3 x 3 tiles around this one hold points (bit 3 * (dy + 1) + (dx + 1))
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const long long band_base = (long long)(item % (unsigned)nb) * hw;
+        const int x0 = tx * RZ_TW - S, y0 = ty * RZ_TH - S;        // raster position of LDS cell (0, 0)
+        float *buf_cur = rz_tail_lds, *buf_nxt = rz_tail_lds + lw * lh;
+        bool any = false;
+        for (int idx = tid; idx < lw * lh; idx += 256) {
+            const int r = (int)(((float)idx + 0.5f) * inv_lw), c = idx - r * lw;
+            const int gr = y0 + r, gc = x0 + c;
+            float v = nan;                                           // outside the raster: NaN, in every sweep
+            if (gr >= 0 && gr < height && gc >= 0 && gc < width) {
+                const int dy = r < S ? 0 : (r >= S + RZ_TH ? 2 : 1), dx = c < S ? 0 : (c >= S + RZ_TW ? 2 : 1);
+                if ((used9 >> (3 * dy + dx)) & 1u) v = raster[band_base + (long long)gr * width + gc];
             }
-    }
-    if (!used9) {                                                // nothing here, nothing a sweep could bring in
-        for (int idx = tid; idx < RZ_TW * RZ_TH; idx += 256) {
-            const int gr = y0 + S + idx / RZ_TW, gc = x0 + S + idx % RZ_TW;
-            if (gr < height && gc < width) out[band_base + (long long)gr * width + gc] = (unsigned char)nodata;
+            buf_cur[idx] = v;
+            any |= (v == v);
         }
-        return;
-    }
-    __syncthreads();
-    bool any = false;
-    for (int idx = tid; idx < lw * lh; idx += 256) {
-        const int r = (int)(((float)idx + 0.5f) * inv_lw), c = idx - r * lw;
-        const int gr = y0 + r, gc = x0 + c;
-        float v = nan;                                           // outside the raster: NaN, in every sweep
-        if (gr >= 0 && gr < height && gc >= 0 && gc < width) {
-            const int dy = r < S ? 0 : (r >= S + RZ_TH ? 2 : 1), dx = c < S ? 0 : (c >= S + RZ_TW ? 2 : 1);
-            if ((used9 >> (3 * dy + dx)) & 1u) v = raster[band_base + (long long)gr * width + gc];
-        }
-        buf_cur[idx] = v;
-        any |= (v == v);
-    }
-    if (any) s_any = 1;
-    __syncthreads();
-    if (s_any) {
-        for (int s = 0; s < S; ++s) {
-            const int rw = lw - 2 * (s + 1), rh = lh - 2 * (s + 1);
-            const float inv_rw = 1.0f / (float)rw;
-            for (int idx = tid; idx < rw * rh; idx += 256) {
-                int r = (int)(((float)idx + 0.5f) * inv_rw), c = idx - r * rw;
-                r += s + 1;
-                c += s + 1;
-                const int at = r * lw + c;
-                float o = buf_cur[at];
-                if (o != o) {
-                    const int gr = y0 + r, gc = x0 + c;
-                    if (gr >= 0 && gr < height && gc >= 0 && gc < width) o = rz_window_value<AGG>(buf_cur, lw, at);
+        if (any) s_any = 1;
+        __syncthreads();
+        if (s_any) {
+            for (int s = 0; s < S; ++s) {
+                const int rw = lw - 2 * (s + 1), rh = lh - 2 * (s + 1);
+                const float inv_rw = 1.0f / (float)rw;
+                for (int idx = tid; idx < rw * rh; idx += 256) {
+                    int r = (int)(((float)idx + 0.5f) * inv_rw), c = idx - r * rw;
+                    r += s + 1;
+                    c += s + 1;
+                    const int at = r * lw + c;
+                    float o = buf_cur[at];
+                    if (o != o) {
+                        const int gr = y0 + r, gc = x0 + c;
+                        if (gr >= 0 && gr < height && gc >= 0 && gc < width) o = rz_window_value<AGG>(buf_cur, lw, at);
+                    }
+                    buf_nxt[at] = o;
                 }
-                buf_nxt[at] = o;
+                __syncthreads();
+                float *const done = buf_cur;
+                buf_cur = buf_nxt;
+                buf_nxt = done;
             }
-            __syncthreads();
-            float *const done = buf_cur;
-            buf_cur = buf_nxt;
-            buf_nxt = done;
         }
-    }
-    for (int idx = tid; idx < RZ_TW * RZ_TH; idx += 256) {
-        const int r = idx / RZ_TW, c = idx % RZ_TW;
-        const int gr = y0 + S + r, gc = x0 + S + c;
-        if (gr >= height || gc >= width) continue;
-        const float v = buf_cur[(r + S) * lw + c + S];
-        unsigned char o;
-        if (v != v) o = (unsigned char)nodata;
-        else o = (unsigned char)(v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v));      // clip, then truncate
-        out[band_base + (long long)gr * width + gc] = o;
+        for (int idx = tid; idx < RZ_TW * RZ_TH; idx += 256) {
+            const int r = idx / RZ_TW, c = idx % RZ_TW;
+            const int gr = y0 + S + r, gc = x0 + S + c;
+            if (gr >= height || gc >= width) continue;
+            const float v = buf_cur[(r + S) * lw + c + S];
+            unsigned char o;
+            if (v != v) o = (unsigned char)nodata;
+            else o = (unsigned char)(v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v));      // clip, then truncate
+            out[band_base + (long long)gr * width + gc] = o;
+        }
     }
 }
 
@@ -514,18 +561,21 @@ __device__ __forceinline__ float ord2f(unsigned o) { return __uint_as_float((o >
 
 // what kind of values do the bands hold?  flag[band] bit 0: some value is not a float32; bit 1: some value is not an integer in
 // [0, 65535]; bit 2: not an integer in [0, 255] (image bytes and 16-bit samples: their composite key needs 8 / 16 value bits, three
-// / two radix passes fewer).  All bands in one launch: one wait of the host instead of one per band.
+// / two radix passes fewer); bit 3: some value is NaN (bytes without one can ride the sort as its payload: rz_median_packed_kernel).
+// All bands in one launch: one wait of the host instead of one per band.
 __global__ __launch_bounds__(256) void rz_median_check_kernel(const double *__restrict__ values, long long count, int nb,
                                                               unsigned *__restrict__ flag) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
         const double val = values[i];
-        if (val != val) continue;
         unsigned bad = 0;
-        if ((double)(float)val != val) bad |= 1u;
-        const bool whole = val >= 0.0 && val <= 65535.0 && val == (double)(unsigned)val;
-        if (!whole) bad |= 6u;
-        else if (val > 255.0) bad |= 4u;
+        if (val != val) bad = 8u;
+        else {
+            if ((double)(float)val != val) bad |= 1u;
+            const bool whole = val >= 0.0 && val <= 65535.0 && val == (double)(unsigned)val;
+            if (!whole) bad |= 6u;
+            else if (val > 255.0) bad |= 4u;
+        }
         if (bad) {
             unsigned *f = flag + (int)(i % nb);
             if ((*f & bad) != bad) atomicOr(f, bad);           // a plain look first: the word settles after a few writers
@@ -566,6 +616,129 @@ __global__ __launch_bounds__(256) void rz_median_runs32_kernel(const unsigned lo
         const double a = VBITS == 32 ? (double)ord2f((unsigned)ka) : (double)(unsigned)(ka & ((1ull << VBITS) - 1ull));
         const double b = VBITS == 32 ? (double)ord2f((unsigned)kb) : (double)(unsigned)(kb & ((1ull << VBITS) - 1ull));
         raster_band[c] = (float)((k & 1) ? a : (a + b) / 2);
+    }
+}
+
+// ---- byte-valued bands (at most four, no NaN): ONE sort by cell with the packed values as its payload (the mean's sort), then
+// the middle value(s) of every run are SELECTED from its words -- the order inside a run does not matter to a median.  A run
+// of up to 16 points (nearly all: the frame's cells hold 1.5 points on average) is sorted in the registers of the thread at
+// its head (a bitonic network over its bytes, padded with 256); a longer one (the 100 M-vertex frame: 138 000 of 1.74 M runs,
+// up to 671 points, holding 46 % of the points) is taken by the whole wave: its bytes are counted into a 256-bin histogram in
+// LDS, four bins to a lane, and a prefix sum over the lanes finds the bin of the middle.  (A list of the long runs for a
+// second kernel, appended to with one atomic per run: 1.1 ms -- the 138 000 atomics on one word.)
+template <int N>
+__device__ __forceinline__ void rz_sort_small(unsigned (&a)[N]) {
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const unsigned lo = a[i] < a[l] ? a[i] : a[l], hi = a[i] < a[l] ? a[l] : a[i];
+                    a[i] = up ? lo : hi;
+                    a[l] = up ? hi : lo;
+                }
+            }
+}
+template <int N>
+__device__ __forceinline__ unsigned rz_pick(const unsigned (&a)[N], int k) {
+    unsigned r = a[0];
+#pragma unroll
+    for (int u = 1; u < N; ++u) r = k == u ? a[u] : r;
+    return r;
+}
+__device__ __forceinline__ float rz_middle(unsigned lo, unsigned hi, long long len) {       // pandas' median of a group: its middle
+    return (float)((len & 1) ? (double)lo : ((double)lo + (double)hi) / 2);                 // value, or the mean of the two
+}
+template <int N>
+__device__ __forceinline__ void rz_median_small(const unsigned *__restrict__ pay_s, long long i, int len, int nb, unsigned cell,
+                                                long long hw, float *__restrict__ raster) {
+    unsigned w[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) w[u] = u < len ? pay_s[i + u] : 0u;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (g >= nb) break;
+        unsigned a[N];
+#pragma unroll
+        for (int u = 0; u < N; ++u) a[u] = u < len ? ((w[u] >> (8 * g)) & 0xFFu) : 256u;
+        rz_sort_small<N>(a);
+        raster[(long long)g * hw + cell] = rz_middle(rz_pick<N>(a, (len - 1) >> 1), rz_pick<N>(a, len >> 1), len);
+    }
+}
+
+// one wave (a workgroup of 64) per 64 consecutive sorted positions: the heads among them take their runs
+__global__ __launch_bounds__(64) void rz_median_packed_kernel(const unsigned *__restrict__ cell_s, const unsigned *__restrict__ pay_s,
+                                                              long long n, int nb, long long hw, float *__restrict__ raster) {
+    __shared__ unsigned hist[4][256];
+    const int lane = (int)threadIdx.x;
+    const long long chunks = (n + 63) >> 6;
+    for (long long ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
+        const long long base = ch << 6, i = base + lane;
+        const unsigned c = i < n ? cell_s[i] : 0xFFFFFFFFu;
+        const bool head = i < n && (i == 0 || cell_s[i - 1] != c);
+        const unsigned long long heads = __ballot(head);
+        long long hi = i + 1;
+        if (head) {
+            const unsigned long long later = lane < 63 ? heads >> (lane + 1) : 0ull;
+            if (later) hi = i + 1 + __builtin_ctzll(later);           // the next head among the 64
+            else {                                                      // the run reaches the end of the 64: gallop, then bisect (rz_runs_kernel)
+                long long lo = base + 63 < n ? base + 63 : n - 1, step = 1;
+                while (lo + step < n && cell_s[lo + step] == c) { lo += step; step <<= 1; }
+                hi = lo + step < n ? lo + step : n;
+                while (hi - lo > 1) {
+                    const long long mid = lo + ((hi - lo) >> 1);
+                    if (cell_s[mid] == c) lo = mid; else hi = mid;
+                }
+            }
+        }
+        const unsigned len = head ? (unsigned)(hi - i) : 0u;
+        if (len == 1) {
+            const unsigned w = pay_s[i];
+            for (int g = 0; g < nb; ++g) raster[(long long)g * hw + c] = (float)((w >> (8 * g)) & 0xFFu);
+        } else if (len == 2) {
+            const unsigned w0 = pay_s[i], w1 = pay_s[i + 1];
+            for (int g = 0; g < nb; ++g) raster[(long long)g * hw + c] = rz_middle((w0 >> (8 * g)) & 0xFFu, (w1 >> (8 * g)) & 0xFFu, 2);
+        } else if (len > 2 && len <= 4) rz_median_small<4>(pay_s, i, (int)len, nb, c, hw, raster);
+        else if (len > 4 && len <= 8) rz_median_small<8>(pay_s, i, (int)len, nb, c, hw, raster);
+        else if (len > 8 && len <= 16) rz_median_small<16>(pay_s, i, (int)len, nb, c, hw, raster);
+        // the longer runs, one after the other, by the whole wave
+        unsigned long long longs = __ballot(len > 16u);
+        while (longs) {
+            const int src = __builtin_ctzll(longs);
+            longs &= longs - 1;
+            const long long ri = base + src;
+            const unsigned rlen = __shfl(len, src), rcell = __shfl(c, src);
+            for (int q = lane; q < nb * 256; q += 64) (&hist[0][0])[q] = 0u;
+            __syncthreads();
+            for (unsigned j = (unsigned)lane; j < rlen; j += 64u) {
+                const unsigned w = pay_s[ri + j];
+                for (int g = 0; g < nb; ++g) atomicAdd(&hist[g][(w >> (8 * g)) & 0xFFu], 1u);
+            }
+            __syncthreads();
+            for (int g = 0; g < nb; ++g) {
+                const uint4 cnt = *(const uint4 *)&hist[g][4 * lane];      // this lane's four bins
+                const unsigned sum = cnt.x + cnt.y + cnt.z + cnt.w;
+                unsigned upto = sum;                                        // inclusive prefix over the lanes
+                for (int d = 1; d < 64; d <<= 1) {
+                    const unsigned o = __shfl_up(upto, d);
+                    if (lane >= d) upto += o;
+                }
+                const unsigned before = upto - sum;
+                unsigned mid[2];
+                for (int q = 0; q < 2; ++q) {
+                    const unsigned k = q == 0 ? (rlen - 1u) >> 1 : rlen >> 1;      // the k-th smallest (from 0)
+                    unsigned v = 4u * (unsigned)lane, r = k - before;
+                    if (r >= cnt.x) { r -= cnt.x; ++v; if (r >= cnt.y) { r -= cnt.y; ++v; if (r >= cnt.z) ++v; } }
+                    mid[q] = __shfl(v, __builtin_ctzll(__ballot(before <= k && k < upto)));
+                }
+                if (lane == 0) raster[(long long)g * hw + rcell] = rz_middle(mid[0], mid[1], (long long)rlen);
+            }
+            __syncthreads();                                                // the histograms are read no more
+        }
     }
 }
 
@@ -651,11 +824,18 @@ enum { AGG_MEDIAN = 3 };
 
 template <int AGG>
 static void launch_tail(const float *raster, int nb, int width, int height, int sweeps, int nodata, unsigned char *out_dev,
-                        const unsigned char *tile_used) {
+                        const unsigned *list, const unsigned *list_count) {
     const int tiles_x = (width + RZ_TW - 1) / RZ_TW, tiles_y = (height + RZ_TH - 1) / RZ_TH;
     const size_t lds = 2 * sizeof(float) * (size_t)(RZ_TW + 2 * sweeps) * (size_t)(RZ_TH + 2 * sweeps);
-    hipLaunchKernelGGL((rz_tail_kernel<AGG>), dim3((unsigned)((long long)tiles_x * tiles_y * nb)), dim3(256), lds, ctx().stream, raster,
-                       width, height, sweeps, nodata, tiles_x, tiles_y, out_dev, tile_used);
+    const long long items = (long long)tiles_x * tiles_y * nb;
+    // 32 workgroups per CU, four times what is resident: a tile at the edge of the points costs many times one inside them
+    // (every NaN cell next to a value takes the 3 x 3 window), so the hardware's dispatcher evens the shares out (measured on the
+    // 100 M-vertex frame, mean / median tail: 139 / 566 us at 8 per CU, 103 / 358 at 32, 109 / 369 at 128; a work counter drawn
+    // from with an atomic: 197 / 368 -- profiles/r04_f2_kernel_breakdown.txt)
+    const unsigned grid = (unsigned)std::min<long long>(items, (long long)ctx().cu_count * 32);
+    (void)hipMemsetAsync(out_dev, nodata & 0xFF, (size_t)width * height * nb, ctx().stream);       // an error: hipGetLastError below
+    hipLaunchKernelGGL((rz_tail_kernel<AGG>), dim3(grid), dim3(256), lds, ctx().stream, raster, width, height, sweeps, nodata, tiles_x,
+                       nb, out_dev, list, list_count);
 }
 
 // bytes of device scratch run_rasterize needs for n points (sort buffers + rocPRIM's temporary storage)
@@ -669,16 +849,29 @@ static size_t rz_sort_bytes(long long n, size_t *tmp_out) {
                               (unsigned *)nullptr, count, 0u, 64u, ctx().stream);
     const size_t tmp = std::max(t1, std::max(t2, t3));
     if (tmp_out) *tmp_out = tmp;
-    // cell, idx (x 2: in / out) | 64-bit keys x 2 | third cell array of the two-sort median | flag | tile bytes (a raster has at most
-    // 2^31 cells = 2^20 tiles) | temporary storage
-    return (size_t)n * (16 + 16 + 4) + 256 + ((size_t)1 << 20) + 256 + tmp + 256;
+    // cell, idx (x 2: in / out) | 64-bit keys x 2 | third cell array of the two-sort median | flag, tile count | tile bytes, tile
+    // list (at most 2^RZ_TILE_BITS tiles: the fused tail's condition) | temporary storage
+    return (size_t)n * (16 + 16 + 4) + 256 + ((size_t)5 << RZ_TILE_BITS) + 256 + tmp + 256;
 }
 
 // dx, dy, dv: the points on the device (values interleaved n x nb); ra, rb: float32 rasters (rb only for the separate-pass
 // path); `sort_area`: rz_sort_bytes(n) bytes.  agg: AGG_MEAN / _MAX / _MIN / AGG_MEDIAN.
+// do the order-free pieces fit where the median keeps its 64-bit keys?  (they do unless the table is tiny or very wide)
+static bool rz_pieces_fit(int agg, long long n, int nb) {
+    const long long nseg = (n + RZ_SEG - 1) / RZ_SEG;
+    return agg != AGG_MEDIAN && (size_t)nseg * nb * 2 * sizeof(RzPiece) <= (size_t)n * 16 && !getenv("ALP_RZ_SEQUENTIAL");
+}
+// may byte-valued bands ride through the sort as its payload?
+static bool rz_can_pack(int agg, long long n, int nb) {
+    return nb <= 4 && (agg == AGG_MEDIAN || rz_pieces_fit(agg, n, nb)) && !getenv("ALP_RZ_NO_PACKED");
+}
+static unsigned *rz_payload_slot(char *sort_area, long long n) { return (unsigned *)sort_area + 2 * n; }
+
 static int run_rasterize(int agg, const double *dx, const double *dy, const double *dv, long long n, int nb, double x_min,
                          double y_max, double res, int width, int height, int sweeps, int nodata, float *ra, float *rb,
-                         unsigned char *out_dev, char *sort_area, float **f32_out = nullptr) {
+                         unsigned char *out_dev, char *sort_area, float **f32_out = nullptr, bool packed_ready = false) {
+    // packed_ready: the bands are bytes (nb <= 4) and the caller has already put their packed words into the sort's payload slot
+    // (rz_payload_slot); dv is not read then
     hipStream_t st = ctx().stream;
     const long long hw = (long long)width * height, total = hw * nb;
     const int cu = ctx().cu_count;
@@ -693,45 +886,69 @@ static int run_rasterize(int agg, const double *dx, const double *dy, const doub
     unsigned long long *key = (unsigned long long *)(idx_s + n), *key_s = key + n;
     unsigned *cell3 = (unsigned *)(key_s + n);
     unsigned *flag = (unsigned *)(((uintptr_t)(cell3 + n) + 63) & ~(uintptr_t)63);
-    unsigned char *tile_used = (unsigned char *)(flag + 16);
-    void *sort_tmp = (void *)(((uintptr_t)(tile_used + ((size_t)1 << 20)) + 255) & ~(uintptr_t)255);
+    unsigned *tile_count = flag + 8;
+    unsigned *tile_list = flag + 16;
+    unsigned char *tile_used = (unsigned char *)(tile_list + ((size_t)1 << RZ_TILE_BITS));
+    void *sort_tmp = (void *)(((uintptr_t)(tile_used + ((size_t)1 << RZ_TILE_BITS)) + 255) & ~(uintptr_t)255);
     const int tiles_x = (width + RZ_TW - 1) / RZ_TW, tiles_y = (height + RZ_TH - 1) / RZ_TH;
-    // the fused tail reads the tiles that hold points only; the separate-pass path reads every cell
-    const bool fused = sweeps <= RZ_SMAX && !rz_separate_passes() && !f32_out;
+    // the fused tail reads the tiles that hold points only; the separate-pass path reads every cell (and takes the rasters of
+    // more tiles than the list holds: a raster one cell wide and 2^31 tall has 2^26 of them)
+    const bool fused = sweeps <= RZ_SMAX && !rz_separate_passes() && !f32_out && (long long)tiles_x * tiles_y <= (1ll << RZ_TILE_BITS);
     unsigned cell_bits = 1;
     while (cell_bits < 32 && (1ll << cell_bits) < hw) ++cell_bits;
     if (fused) {
         ALP_HIP(hipMemsetAsync(tile_used, 0, (size_t)tiles_x * tiles_y, st));
+        ALP_HIP(hipMemsetAsync(tile_count, 0, sizeof(unsigned), st));
     } else {
         ALP_HIP(hipMemsetD32Async((hipDeviceptr_t)ra, 0x7fc00000, (size_t)total, st));      // NaN everywhere (the runtime's fill)
     }
-    hipLaunchKernelGGL(rz_cell_kernel, dim3(grid(n)), dim3(256), 0, st, dx, dy, n, x_min, y_max, res, width, height, cell, idx,
-                       fused ? tile_used : nullptr, tiles_x);
-    if (fused) hipLaunchKernelGGL(rz_fill_tiles_kernel, dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, st, ra, tile_used, nb, width, height, tiles_x);
+    // the order-free cases go through parallel pieces (the pieces live where the median keeps its 64-bit keys); byte-valued bands
+    // (at most four) travel through the sort as its payload
+    const long long nseg = (n + RZ_SEG - 1) / RZ_SEG;
+    bool pieces = rz_pieces_fit(agg, n, nb);
+    bool packed = packed_ready;
+    if (packed_ready && !rz_can_pack(agg, n, nb)) return fail(ALP_EINVAL, "rasterisation: packed band values on a path that does not take them");
+    unsigned kinds[64];             // the median's look at its bands (rz_median_check_kernel)
+    unsigned *const kinds_dev = (unsigned *)key_s;
+    if (!packed_ready && agg == AGG_MEDIAN) {
+        ALP_HIP(hipMemsetAsync(kinds_dev, 0, (size_t)nb * sizeof(unsigned), st));
+        hipLaunchKernelGGL(rz_median_check_kernel, dim3(grid(n * nb)), dim3(256), 0, st, dv, n * nb, nb, kinds_dev);
+        ALP_HIP(hipMemcpyAsync(kinds, kinds_dev, (size_t)nb * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        ALP_HIP(hipStreamSynchronize(st));
+        packed = rz_can_pack(agg, n, nb);
+        for (int b = 0; b < nb; ++b) packed = packed && !(kinds[b] & (4u | 8u));
+        if (packed) hipLaunchKernelGGL(rz_pack_kernel, dim3(grid(n)), dim3(256), 0, st, dv, n, nb, idx);
+    }
+    if (!packed_ready && agg != AGG_MEDIAN && pieces && (agg == AGG_MEAN || nb <= 4)) {
+        unsigned kind = 3;
+        ALP_HIP(hipMemsetAsync(flag, 0, sizeof(unsigned), st));
+        hipLaunchKernelGGL(rz_integer_check_kernel, dim3(grid(n * nb)), dim3(256), 0, st, dv, n * nb, flag);
+        ALP_HIP(hipMemcpyAsync(&kind, flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        ALP_HIP(hipStreamSynchronize(st));
+        packed = rz_can_pack(agg, n, nb) && !(kind & 2u);
+        if (agg == AGG_MEAN && (kind & 1u)) pieces = false;        // a float-valued mean: pandas' order (rz_runs_kernel)
+        if (packed) hipLaunchKernelGGL(rz_pack_kernel, dim3(grid(n)), dim3(256), 0, st, dv, n, nb, idx);
+    }
+    hipLaunchKernelGGL(rz_cell_kernel, dim3(grid(n)), dim3(256), 0, st, dx, dy, n, x_min, y_max, res, width, height, cell,
+                       packed ? (unsigned *)nullptr : idx, fused ? tile_used : nullptr, tiles_x);
+    if (fused) {
+        const int tiles = tiles_x * tiles_y;
+        hipLaunchKernelGGL(rz_tile_list_kernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, st, tile_used, tiles_x, tiles_y, tile_list, tile_count);
+        hipLaunchKernelGGL(rz_fill_tiles_kernel, dim3((unsigned)std::min(tiles, cu * 8)), dim3(256), 0, st, ra, tile_list, tile_count, nb, width,
+                           height, tiles_x);
+    }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && agg != AGG_MEDIAN) {
         size_t t = tmp;
         e = rocprim::radix_sort_pairs(sort_tmp, t, cell, cell_s, idx, idx_s, count, 0u, cell_bits, st);      // stable: a run keeps the rows' order
-        // the order-free cases go through parallel pieces (the pieces live where the median keeps its 64-bit keys)
-        const long long nseg = (n + RZ_SEG - 1) / RZ_SEG;
-        bool pieces = (size_t)nseg * nb * 2 * sizeof(RzPiece) <= (size_t)n * 16 && !getenv("ALP_RZ_SEQUENTIAL");
-        if (e == hipSuccess && pieces && agg == AGG_MEAN) {
-            e = hipMemsetAsync(flag, 0, sizeof(unsigned), st);
-            unsigned not_int = 1;
-            if (e == hipSuccess) {
-                hipLaunchKernelGGL(rz_integer_check_kernel, dim3(grid(n * nb)), dim3(256), 0, st, dv, n * nb, flag);
-                e = hipMemcpyAsync(&not_int, flag, sizeof(unsigned), hipMemcpyDeviceToHost, st);
-            }
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
-            pieces = !not_int;
-        }
         if (e == hipSuccess) {
             RzPiece *first = (RzPiece *)key, *last = first + (size_t)nseg * nb;
             const unsigned gs = grid(nseg);
-#define ALP_RZ_PIECES(A)                                                                                                      \
-    do {                                                                                                                      \
-        hipLaunchKernelGGL((rz_pieces_kernel<A>), dim3(gs), dim3(256), 0, st, cell_s, idx_s, dv, n, nb, hw, ra, first, last); \
-        hipLaunchKernelGGL((rz_join_kernel<A>), dim3(gs), dim3(256), 0, st, cell_s, n, nb, hw, ra, first, last);              \
+#define ALP_RZ_PIECES(A)                                                                                                                  \
+    do {                                                                                                                                  \
+        if (packed) hipLaunchKernelGGL((rz_pieces_kernel<A, true>), dim3(gs), dim3(256), 0, st, cell_s, idx_s, dv, n, nb, hw, ra, first, last); \
+        else hipLaunchKernelGGL((rz_pieces_kernel<A, false>), dim3(gs), dim3(256), 0, st, cell_s, idx_s, dv, n, nb, hw, ra, first, last);       \
+        hipLaunchKernelGGL((rz_join_kernel<A>), dim3(gs), dim3(256), 0, st, cell_s, n, nb, hw, ra, first, last);                          \
     } while (0)
             if (agg == AGG_MEAN && pieces) ALP_RZ_PIECES(AGG_MEAN);
             else if (agg == AGG_MEAN) hipLaunchKernelGGL((rz_runs_kernel<AGG_MEAN>), dim3(grid(n)), dim3(256), 0, st, cell_s, idx_s, dv, n, nb, hw, ra);
@@ -742,17 +959,17 @@ static int run_rasterize(int agg, const double *dx, const double *dy, const doub
 #undef ALP_RZ_PIECES
             e = hipGetLastError();
         }
-    } else if (e == hipSuccess) {
-        // one flag word per band (nb <= 64), parked at the head of the sorted-key buffer: the first sort writes that buffer only after the
-        // flags have been read
-        unsigned *kinds_dev = (unsigned *)key_s;
-        unsigned kinds[64];
-        e = hipMemsetAsync(kinds_dev, 0, (size_t)nb * sizeof(unsigned), st);
+    } else if (e == hipSuccess && packed) {
+        size_t t = tmp;
+        e = rocprim::radix_sort_pairs(sort_tmp, t, cell, cell_s, idx, idx_s, count, 0u, cell_bits, st);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(rz_median_check_kernel, dim3(grid(n * nb)), dim3(256), 0, st, dv, n * nb, nb, kinds_dev);
-            e = hipMemcpyAsync(kinds, kinds_dev, (size_t)nb * sizeof(unsigned), hipMemcpyDeviceToHost, st);
+            const unsigned chunks = (unsigned)std::min<long long>((n + 63) / 64, (long long)cu * 256);
+            hipLaunchKernelGGL(rz_median_packed_kernel, dim3(chunks), dim3(64), 0, st, cell_s, idx_s, n, nb, hw, ra);
+            e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    } else if (e == hipSuccess) {
+        // (the flag words, one per band (nb <= 64), were parked at the head of the sorted-key buffer: the first sort writes that buffer
+        // only now, after they have been read)
         for (int b = 0; b < nb && e == hipSuccess; ++b) {
             const unsigned kind = kinds[b];
             size_t t = tmp;
@@ -788,10 +1005,10 @@ static int run_rasterize(int agg, const double *dx, const double *dy, const doub
     }
     if (e != hipSuccess) return fail(ALP_EHIP, "rasterisation: %s", hipGetErrorString(e));
     if (fused) {
-        if (agg == AGG_MEAN) launch_tail<AGG_MEAN>(ra, nb, width, height, sweeps, nodata, out_dev, tile_used);
-        else if (agg == AGG_MAX) launch_tail<AGG_MAX>(ra, nb, width, height, sweeps, nodata, out_dev, tile_used);
-        else if (agg == AGG_MIN) launch_tail<AGG_MIN>(ra, nb, width, height, sweeps, nodata, out_dev, tile_used);
-        else launch_tail<AGG_MEDIAN_FOCAL>(ra, nb, width, height, sweeps, nodata, out_dev, tile_used);
+        if (agg == AGG_MEAN) launch_tail<AGG_MEAN>(ra, nb, width, height, sweeps, nodata, out_dev, tile_list, tile_count);
+        else if (agg == AGG_MAX) launch_tail<AGG_MAX>(ra, nb, width, height, sweeps, nodata, out_dev, tile_list, tile_count);
+        else if (agg == AGG_MIN) launch_tail<AGG_MIN>(ra, nb, width, height, sweeps, nodata, out_dev, tile_list, tile_count);
+        else launch_tail<AGG_MEDIAN_FOCAL>(ra, nb, width, height, sweeps, nodata, out_dev, tile_list, tile_count);
         ALP_HIP(hipGetLastError());
         return ALP_OK;
     }
@@ -858,6 +1075,21 @@ __global__ __launch_bounds__(256) void rz_gather_bands_kernel(const A *__restric
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const A *px = array + (long long)idx[i] * channels;
         for (int b = 0; b < nb; ++b) values[i * nb + b] = (double)px[band_channel[b]];
+    }
+}
+
+// the same for a uint8 photograph and at most four bands: one packed word per point, straight into the sort's payload slot
+__global__ __launch_bounds__(256) void rz_gather_packed_kernel(const unsigned char *__restrict__ array, const unsigned *__restrict__ idx,
+                                                               long long n, int channels, int nb, const int *__restrict__ band_channel,
+                                                               unsigned *__restrict__ packed) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    int ch[4];
+    for (int b = 0; b < 4; ++b) ch[b] = b < nb ? band_channel[b] : 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const unsigned char *px = array + (long long)idx[i] * channels;
+        unsigned w = 0;
+        for (int b = 0; b < nb; ++b) w |= (unsigned)px[ch[b]] << (8 * b);
+        packed[i] = w;
     }
 }
 
@@ -960,13 +1192,16 @@ extern "C" int alp_render_rasterize(alp_mesh_t *m, const void *array, int array_
         const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, (long long)ctx().cu_count * 8);
 #define ALP_GATHER(A) hipLaunchKernelGGL(rz_gather_bands_kernel<A>, dim3(grid), dim3(256), 0, st, (const A *)arr_dev, idx, (long long)n, \
                                          (int)channels, (int)nb, bands_dev, dv)
-        if (array_dtype == ALP_U8) ALP_GATHER(unsigned char);
+        const bool packed = array_dtype == ALP_U8 && rz_can_pack(agg, n, (int)nb);
+        if (packed) hipLaunchKernelGGL(rz_gather_packed_kernel, dim3(grid), dim3(256), 0, st, (const unsigned char *)arr_dev, idx, (long long)n,
+                                       (int)channels, (int)nb, bands_dev, rz_payload_slot(sort_area, n));
+        else if (array_dtype == ALP_U8) ALP_GATHER(unsigned char);
         else if (array_dtype == ALP_U16) ALP_GATHER(unsigned short);
         else if (array_dtype == ALP_F32) ALP_GATHER(float);
         else ALP_GATHER(double);
 #undef ALP_GATHER
         rc = run_rasterize(agg, dx, dy, dv, n, (int)nb, x_min, y_max, resolution, (int)width, (int)height, sweeps, nodata, ra, rb, out_dev,
-                           sort_area);
+                           sort_area, nullptr, packed);
     }
     if (!rc && e == hipSuccess) e = hipMemcpyAsync(out, out_dev, total, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
