@@ -314,19 +314,23 @@ int frame_valid_count(alp_mesh *m, int64_t *count) {
         m->compact_counts = nullptr;
         m->compact_offsets = nullptr;
         m->compact_cap = 0;
-        ALP_HIP(hipMalloc((void **)&m->compact_counts, (size_t)chunks * sizeof(unsigned)));
-        ALP_HIP(hipMalloc((void **)&m->compact_offsets, (size_t)(chunks + 1) * sizeof(unsigned long long)));
+        // counts | the chunks' extents (four floats each);  offsets | the total | the frame's extent (four floats)
+        ALP_HIP(hipMalloc((void **)&m->compact_counts, (size_t)chunks * (sizeof(unsigned) + 4 * sizeof(float)) + 16));
+        ALP_HIP(hipMalloc((void **)&m->compact_offsets, (size_t)(chunks + 3) * sizeof(unsigned long long)));
         m->compact_cap = chunks;
     }
     hipStream_t st = ctx().stream;
     ktime_begin();
-    hipLaunchKernelGGL(valid_count_kernel, dim3(chunks), dim3(256), 0, st, m->image, npix, m->compact_counts);
-    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, st, m->compact_counts, chunks, m->compact_offsets);
+    float *span = (float *)(((uintptr_t)(m->compact_counts + chunks) + 15) & ~(uintptr_t)15);
+    hipLaunchKernelGGL(valid_count_kernel, dim3(chunks), dim3(256), 0, st, m->image, npix, m->compact_counts, span);
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, st, m->compact_counts, chunks, m->compact_offsets, span);
     ktime_end();
     ALP_HIP(hipGetLastError());
-    unsigned long long total = 0;
-    ALP_HIP(hipMemcpyAsync(&total, m->compact_offsets + chunks, sizeof(total), hipMemcpyDeviceToHost, st));
+    unsigned long long tail[3] = {0, 0, 0};      // the total, then the extent of channels 0 and 2 over the survivors
+    ALP_HIP(hipMemcpyAsync(tail, m->compact_offsets + chunks, sizeof(tail), hipMemcpyDeviceToHost, st));
     ALP_HIP(hipStreamSynchronize(st));
+    const unsigned long long total = tail[0];
+    memcpy(m->valid_span, tail + 1, sizeof(m->valid_span));
     m->valid_total = (int64_t)total;
     *count = m->valid_total;
     return ALP_OK;

@@ -107,6 +107,7 @@ struct alp_mesh {
     unsigned *compact_counts = nullptr;
     unsigned long long *compact_offsets = nullptr;
     int compact_cap = 0;
+    float valid_span[4] = {0, 0, 0, 0};      // frame_valid_count: min / max of channel 0, min / max of channel 2 over the pixels that see the surface
     int64_t valid_total = -1;
     int64_t valid_total_planes = 0;     // plane length of the planar form of frame_valid_write
     // alp_render_rasterize_plan -> alp_render_rasterize: the compacted points of the current frame (device):

@@ -89,31 +89,75 @@ __global__ __launch_bounds__(256) void distance_mask_kernel(const double *__rest
     keep[i] = k ? 1 : 0;
 }
 
+// also, per chunk, the extent of the survivors' channels 0 and 2 (min x, max x, min y, max y -> span[4 * chunk ..]; +-inf
+// for a chunk without one): to_geotiff's bounds (project.py:420-423) are these plus the offsets -- x -> (double)x + o only
+// grows with x, so the minimum of the sums is the sum at the minimum -- and cost no pass of their own over the table
 __global__ __launch_bounds__(256) void valid_count_kernel(const float *__restrict__ img, long long npix,
-                                                          unsigned *__restrict__ counts) {
+                                                          unsigned *__restrict__ counts, float *__restrict__ span) {
     __shared__ unsigned s[4];
+    __shared__ float s_span[4][4];
     const long long base = (long long)blockIdx.x * COMPACT_CHUNK;
     unsigned c = 0;
+    float x_lo = INFINITY, x_hi = -INFINITY, y_lo = INFINITY, y_hi = -INFINITY;
     for (int k = threadIdx.x; k < COMPACT_CHUNK; k += 256) {
         const long long p = base + k;
-        if (p < npix && img[p * 3] > 0.0f) ++c;
+        if (p >= npix) continue;
+        const float x = img[p * 3];
+        if (x > 0.0f) {
+            const float y = img[p * 3 + 2];
+            ++c;
+            x_lo = fminf(x_lo, x); x_hi = fmaxf(x_hi, x);
+            y_lo = fminf(y_lo, y); y_hi = fmaxf(y_hi, y);
+        }
     }
-    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+    for (int m = 32; m >= 1; m >>= 1) {
+        c += __shfl_xor(c, m, 64);
+        x_lo = fminf(x_lo, __shfl_xor(x_lo, m, 64)); x_hi = fmaxf(x_hi, __shfl_xor(x_hi, m, 64));
+        y_lo = fminf(y_lo, __shfl_xor(y_lo, m, 64)); y_hi = fmaxf(y_hi, __shfl_xor(y_hi, m, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        s[w] = c;
+        s_span[w][0] = x_lo; s_span[w][1] = x_hi; s_span[w][2] = y_lo; s_span[w][3] = y_hi;
+    }
     __syncthreads();
     if (threadIdx.x == 0) counts[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+    if (threadIdx.x < 4) {
+        const int k = (int)threadIdx.x;
+        const float a = s_span[0][k], b = s_span[1][k], d = s_span[2][k], e = s_span[3][k];
+        span[4 * (long long)blockIdx.x + k] = (k & 1) ? fmaxf(fmaxf(a, b), fmaxf(d, e)) : fminf(fminf(a, b), fminf(d, e));
+    }
 }
 
-// exclusive scan of n counts (n up to a few ten thousand) by one workgroup; total -> offsets[n]
+// exclusive scan of n counts (n up to a few ten thousand) by one workgroup; total -> offsets[n]; the chunks' extents
+// joined -> the four floats behind it (offsets[n + 1], [n + 2])
 __global__ __launch_bounds__(1024) void scan_counts_kernel(const unsigned *__restrict__ counts, int n,
-                                                           unsigned long long *__restrict__ offsets) {
+                                                           unsigned long long *__restrict__ offsets, const float *__restrict__ span) {
     __shared__ unsigned long long s[1024];
+    __shared__ float s_span[16][4];
     const int per = (n + 1023) / 1024;
     const int lo = threadIdx.x * per, hi = min(n, lo + per);
     unsigned long long sum = 0;
-    for (int i = lo; i < hi; ++i) sum += counts[i];
+    float e[4] = {INFINITY, -INFINITY, INFINITY, -INFINITY};
+    for (int i = lo; i < hi; ++i) {
+        sum += counts[i];
+        const float4 sp = *(const float4 *)(span + 4 * (long long)i);
+        e[0] = fminf(e[0], sp.x); e[1] = fmaxf(e[1], sp.y); e[2] = fminf(e[2], sp.z); e[3] = fmaxf(e[3], sp.w);
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        e[0] = fminf(e[0], __shfl_xor(e[0], m, 64)); e[1] = fmaxf(e[1], __shfl_xor(e[1], m, 64));
+        e[2] = fminf(e[2], __shfl_xor(e[2], m, 64)); e[3] = fmaxf(e[3], __shfl_xor(e[3], m, 64));
+    }
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 4; ++k) s_span[threadIdx.x >> 6][k] = e[k];
     s[threadIdx.x] = sum;
     __syncthreads();
+    if (threadIdx.x < 4) {
+        const int k = (int)threadIdx.x;
+        float r = s_span[0][k];
+        for (int w = 1; w < 16; ++w) r = (k & 1) ? fmaxf(r, s_span[w][k]) : fminf(r, s_span[w][k]);
+        ((float *)(offsets + n + 1))[k] = r;
+    }
     for (int d = 1; d < 1024; d <<= 1) {                 // Hillis-Steele inclusive scan
         unsigned long long t = threadIdx.x >= d ? s[threadIdx.x - d] : 0;
         __syncthreads();
