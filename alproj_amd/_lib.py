@@ -6,6 +6,7 @@ can be initialised, the first call that needs the device raises ``AlprojHipError
 import ctypes
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -21,6 +22,63 @@ PARAM_KEYS = ("x", "y", "z", "fov", "pan", "tilt", "roll", "a1", "a2",
               "k1", "k2", "k3", "k4", "k5", "k6", "p1", "p2",
               "s1", "s2", "s3", "s4", "w", "h", "cx", "cy")
 DIST_KEYS = PARAM_KEYS[7:21]
+
+
+# ---- recycled result memory
+# A large result (the 237 MB raster of a georectified photograph, a 63 MB simulated image, the columns of a reverse_proj
+# table) lands in a fresh numpy array; the device -> host copy into pages nobody has touched yet runs at 8-13 GB/s -- the
+# kernel hands them out one fault at a time -- against 56 GB/s into pages that exist (tools/d2h_rate.hip).  So the memory of
+# a result the caller has dropped (the array AND every view of it) is kept, up to a cap, and the next result of the same
+# size is written into it: a series of photographs through one camera model pays for its pages once.  The arrays behave
+# like np.empty's except for ``flags.owndata``.  set_result_pool(0) turns it off.
+_POOL_MIN = 8 << 20
+_pool_cap = 4 << 30
+_pool = {}
+_pool_bytes = 0
+_pool_lock = threading.Lock()
+POOL_STATS = {"hits": 0, "misses": 0}
+
+
+def set_result_pool(cap_bytes):
+    """Keep at most ``cap_bytes`` of dropped result memory for reuse (default 4 GiB; 0: none, and what is kept is released)."""
+    global _pool_cap, _pool_bytes
+    with _pool_lock:
+        _pool_cap = int(cap_bytes)
+        if _pool_bytes > _pool_cap:
+            _pool.clear()
+            _pool_bytes = 0
+
+
+def _pool_release(backing):
+    global _pool_bytes
+    with _pool_lock:
+        if _pool_bytes + backing.nbytes <= _pool_cap:
+            _pool.setdefault(backing.nbytes, []).append(backing)
+            _pool_bytes += backing.nbytes
+
+
+def result_empty(shape, dtype):
+    """np.empty(shape, dtype) for a result the device writes in full; large ones come from recycled memory."""
+    global _pool_bytes
+    dtype = np.dtype(dtype)
+    shape = (int(shape),) if np.isscalar(shape) else tuple(int(v) for v in shape)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    if nbytes < _POOL_MIN or nbytes > _pool_cap:
+        return np.empty(shape, dtype=dtype)
+    with _pool_lock:
+        free = _pool.get(nbytes)
+        backing = free.pop() if free else None
+        if backing is not None:
+            _pool_bytes -= nbytes
+            POOL_STATS["hits"] += 1
+        else:
+            POOL_STATS["misses"] += 1
+    if backing is None:
+        backing = np.empty(nbytes, dtype=np.uint8)
+    # the array and all its views hold `window`; when the last of them is gone the memory goes back to the pool
+    window = (ctypes.c_ubyte * nbytes).from_address(backing.ctypes.data)
+    weakref.finalize(window, _pool_release, backing).atexit = False
+    return np.frombuffer(window, dtype=dtype).reshape(shape)
 
 
 class AlprojHipError(RuntimeError):
@@ -257,21 +315,21 @@ class Points:
         check(self._lib.alp_project(self._h, as_dp(pvec)))
 
     def fetch(self, dtype=np.float64):
-        u = np.empty(self.n, dtype=dtype)
-        v = np.empty(self.n, dtype=dtype)
+        u = result_empty(self.n, dtype)
+        v = result_empty(self.n, dtype)
         check(self._lib.alp_projected_fetch(self._h, u.ctypes.data_as(_c_void_p),
                                             v.ctypes.data_as(_c_void_p), dtype_code(u)))
         return u, v
 
     def fetch_strided(self, first, stride, count):
-        u = np.empty(count, dtype=np.float64)
-        v = np.empty(count, dtype=np.float64)
+        u = result_empty(count, np.float64)
+        v = result_empty(count, np.float64)
         check(self._lib.alp_projected_fetch_strided(self._h, first, stride, count, as_dp(u), as_dp(v)))
         return u, v
 
     def residuals(self, pvec):
         pvec = np.ascontiguousarray(pvec, dtype=np.float64)
-        out = np.empty(2 * self.n, dtype=np.float64)
+        out = result_empty(2 * self.n, np.float64)
         check(self._lib.alp_residuals(self._h, as_dp(pvec), as_dp(out)))
         return out
 
@@ -280,7 +338,7 @@ class Points:
         cand = np.ascontiguousarray(cand, dtype=np.float64)
         if cand.ndim != 2 or cand.shape[1] != NPARAM:
             raise ValueError("cand must have shape (B, 25)")
-        out = np.empty((cand.shape[0], 2 * self.n), dtype=np.float64)
+        out = result_empty((cand.shape[0], 2 * self.n), np.float64)
         check(self._lib.alp_residuals_batch(self._h, as_dp(cand), cand.shape[0], as_dp(out)))
         return out
 
@@ -402,7 +460,7 @@ class Mesh:
 
     def fetch_u8(self, scale=255.0, reverse_channels=True):
         """The last frame as (h, w, 3) uint8 = (image * scale).astype(uint8), channels reversed: sim_image's tail"""
-        out = np.empty(self.shape, dtype=np.uint8)
+        out = result_empty(self.shape, np.uint8)
         check(self._lib.alp_render_fetch_u8(self._h, float(scale), int(bool(reverse_channels)),
                                             out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))))
         return out
@@ -457,9 +515,9 @@ class Mesh:
 
     def fetch_arrays(self):
         """(vert, value, valid) of the resident mesh as numpy arrays (inspection / tests)."""
-        vert = np.empty((self.n_vert, 3), dtype=np.float32)
-        value = np.empty((self.n_vert, 3), dtype=np.float32)
-        valid = np.empty(self.n_vert, dtype=np.uint8)
+        vert = result_empty((self.n_vert, 3), np.float32)
+        value = result_empty((self.n_vert, 3), np.float32)
+        valid = result_empty(self.n_vert, np.uint8)
         check(self._lib.alp_mesh_fetch(self._h, as_fp(vert), as_fp(value),
                                        valid.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))))
         return vert, value, valid.astype(bool)
@@ -489,12 +547,12 @@ class Mesh:
         self.shape = (int(pvec[22]), int(pvec[21]), 3)
 
     def fetch(self):
-        out = np.empty(self.shape, dtype=np.float32)
+        out = result_empty(self.shape, np.float32)
         check(self._lib.alp_render_fetch(self._h, as_fp(out)))
         return out
 
     def fetch_visibility(self):
-        out = np.empty(self.shape[:2], dtype=np.uint64)
+        out = result_empty(self.shape[:2], np.uint64)
         check(self._lib.alp_render_fetch_visibility(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
         return out
 
@@ -517,8 +575,8 @@ class Mesh:
         surface (first channel > 0), row-major; xyz = channels (0, 2, 1) + offsets, float64."""
         n = _c_i64()
         check(self._lib.alp_render_valid_count(self._h, ctypes.byref(n)))
-        idx = np.empty(n.value, dtype=np.uint32)
-        xyz = np.empty((n.value, 3), dtype=np.float64)
+        idx = result_empty(n.value, np.uint32)
+        xyz = result_empty((n.value, 3), np.float64)
         off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.float64)
         check(self._lib.alp_render_fetch_valid(self._h, None if off is None else as_dp(off),
                                                idx.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), as_dp(xyz)))
@@ -543,7 +601,7 @@ class Mesh:
         if array.ndim != 3 or array.shape[:2] != tuple(self.shape[:2]):
             raise ValueError("array must have shape (h, w, channels) of the rendered frame")
         bc = np.ascontiguousarray(band_channel, dtype=np.int32)
-        out = np.empty((len(bc), int(height), int(width)), dtype=np.uint8)
+        out = result_empty((len(bc), int(height), int(width)), np.uint8)
         check(self._lib.alp_render_rasterize(self._h, array.ctypes.data_as(_c_void_p), codes[array.dtype], array.shape[2],
                                              bc.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), len(bc), float(x_min),
                                              float(y_max), float(resolution), int(width), int(height), int(agg),
@@ -556,8 +614,8 @@ class Mesh:
         n = _c_i64()
         check(self._lib.alp_render_valid_count(self._h, ctypes.byref(n)))
         M = int(n.value)
-        idx = np.empty(M, dtype=np.uint32)
-        block = np.empty((3 + int(extra_rows), M), dtype=np.float64)
+        idx = result_empty(M, np.uint32)
+        block = result_empty((3 + int(extra_rows), M), np.float64)
         off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.float64)
         check(self._lib.alp_render_fetch_valid_planes(self._h, None if off is None else as_dp(off),
                                                       idx.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
@@ -577,10 +635,10 @@ class Mesh:
         n = _c_i64()
         check(self._lib.alp_render_valid_count(self._h, ctypes.byref(n)))
         M = int(n.value)
-        labels = np.empty(M, dtype=np.int64)
-        u = np.empty(M, dtype=np.int16)
-        v = np.empty(M, dtype=np.int16)
-        block = np.empty((3 + C, M), dtype=np.float64)
+        labels = result_empty(M, np.int64)
+        u = result_empty(M, np.int16)
+        v = result_empty(M, np.int16)
+        block = result_empty((3 + C, M), np.float64)
         off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.float64)
         i16 = ctypes.POINTER(ctypes.c_int16)
         check(self._lib.alp_render_fetch_valid_table(self._h, None if off is None else as_dp(off), array.ctypes.data_as(_c_void_p),
@@ -595,7 +653,7 @@ class Mesh:
         v = np.ascontiguousarray(v, dtype=np.int32)
         if u.shape != v.shape or u.ndim != 1:
             raise ValueError("u and v must be 1-D arrays of the same length")
-        xyz = np.empty((len(u), 3), dtype=np.float64)
+        xyz = result_empty((len(u), 3), np.float64)
         off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.float64)
         ip = ctypes.POINTER(ctypes.c_int32)
         check(self._lib.alp_render_gather(self._h, u.ctypes.data_as(ip), v.ctypes.data_as(ip), len(u),
@@ -635,7 +693,7 @@ def rasterize_points_f32(x, y, values, resolution=1.0, interpolate=True, max_dis
     if width <= 0 or height <= 0:
         raise ValueError(f"Invalid raster dimensions: width={width}, height={height}")
     sweeps = int(np.ceil(max_dist / resolution)) if (interpolate and max_dist > 0) else 0
-    out = np.empty((values.shape[1], height, width), dtype=np.float32)
+    out = result_empty((values.shape[1], height, width), np.float32)
     check(lib().alp_rasterize_points_f32(as_dp(x), as_dp(y), as_dp(values), len(x), values.shape[1], float(x_min), float(y_max),
                                          float(resolution), width, height, AGG_CODES[agg_func], sweeps, as_fp(out)))
     return out, (x_min, y_min, x_max, y_max, width, height)
@@ -667,7 +725,7 @@ def cma_sample(mean, sigma, BD, bounds, P, n_max_resampling, seed, generation, r
     if bounds is not None:
         b = np.asarray(bounds, dtype=np.float64)
         lo, hi = np.ascontiguousarray(b[:, 0]), np.ascontiguousarray(b[:, 1])
-    x = np.empty((int(P), D), dtype=np.float64)
+    x = result_empty((int(P), D), np.float64)
     tries = np.empty(int(P), dtype=np.int32) if return_tries else None
     check(lib().alp_cma_sample(as_dp(mean), float(sigma), as_dp(BD), None if lo is None else as_dp(lo),
                                None if hi is None else as_dp(hi), D, int(P), int(n_max_resampling),
@@ -681,8 +739,8 @@ def distort_map(h, w, coeffs):
     cf = np.ascontiguousarray(coeffs, dtype=np.float64)
     if cf.shape != (14,):
         raise ValueError("distort_coeffs must have 14 entries")
-    mx = np.empty((int(h), int(w)), dtype=np.float32)
-    my = np.empty((int(h), int(w)), dtype=np.float32)
+    mx = result_empty((int(h), int(w)), np.float32)
+    my = result_empty((int(h), int(w)), np.float32)
     check(lib().alp_distort_map(int(h), int(w), as_dp(cf), as_fp(mx), as_fp(my)))
     return mx, my
 
@@ -751,7 +809,7 @@ def comm_allgather(array):
     check(lib().alp_comm_allgather_counts(array.nbytes, counts))
     row = array.strides[0] if array.ndim > 1 else array.itemsize
     total = sum(counts)
-    out = np.empty((total // row,) + array.shape[1:], dtype=array.dtype)
+    out = result_empty((total // row,) + array.shape[1:], array.dtype)
     check(lib().alp_comm_allgatherv(array.ctypes.data_as(_c_void_p), out.ctypes.data_as(_c_void_p), counts))
     return out
 

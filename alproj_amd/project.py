@@ -338,7 +338,7 @@ class ReverseProjection:
                 idx, block = mesh.fetch_valid_block(self.offsets, C)
             else:                               # a host stand-in of the mesh (tests of this host half)
                 idx, xyz = mesh.fetch_valid(self.offsets)
-                block = np.empty((3 + C, len(idx)), dtype=np.float64)
+                block = _lib.result_empty((3 + C, len(idx)), np.float64)
                 block[:3] = xyz.T
             t1 = time.perf_counter()
             flat = array.reshape(-1, array.shape[2])
@@ -466,7 +466,7 @@ def rasterize(df, resolution=1.0, bands=["R", "G", "B"], interpolate=True, max_d
     cols = [np.ascontiguousarray(df[b].to_numpy(dtype=np.float64)) for b in bands]
     col_ptrs = (_lib.ctypes.c_void_p * len(cols))(*[c.ctypes.data for c in cols])
     sweeps = int(np.ceil(max_dist / resolution)) if (interpolate and max_dist > 0) else 0
-    out = np.empty((len(bands), height, width), dtype=np.uint8)
+    out = _lib.result_empty((len(bands), height, width), np.uint8)
     _lib.check(_lib.lib().alp_rasterize_columns(
         _lib.as_dp(x), _lib.as_dp(y), col_ptrs, len(x), len(bands), float(x_min), float(y_max),
         float(resolution), width, height, _AGG[agg_func], sweeps, int(nodata),

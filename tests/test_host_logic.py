@@ -207,3 +207,45 @@ def test_resident_mesh_cache_keys():
     del vert, view
     gc.collect()
     assert key[0]() is None and not aproj._same(key, other)        # the array is gone: the weak reference says so
+
+
+def test_result_memory_is_recycled_only_when_nobody_holds_it():
+    """_lib.result_empty: a large result's memory goes back to the pool when the array AND every view of it are gone, the next
+    result of that size is written into it (touched pages: the device -> host copy runs 4-7 x faster into them); while anything
+    still refers to the memory it is never handed out again; small results, a pool of size 0 and results beyond the cap are
+    plain np.empty"""
+    import gc
+    from alproj_amd import _lib as L
+    old_cap = L._pool_cap
+    try:
+        L.set_result_pool(0)
+        L.set_result_pool(64 << 20)
+        a = L.result_empty((3, 2000, 2000), np.uint8)
+        assert a.shape == (3, 2000, 2000) and a.dtype == np.uint8 and a.flags.writeable and a.flags.c_contiguous
+        a[:] = 7
+        where = a.ctypes.data
+        row = a[1, 5]                                  # a view of a view
+        frame = pd.DataFrame({"v": a.reshape(-1)[:1000]}, copy=False)
+        del a
+        gc.collect()
+        b = L.result_empty((3, 2000, 2000), np.uint8)
+        assert b.ctypes.data != where                  # `row` still sees the first array's memory
+        assert (row == 7).all()
+        del row, frame
+        gc.collect()
+        c = L.result_empty((12_000_000,), np.uint8)    # same size in bytes: the first array's memory, whatever the shape
+        assert c.ctypes.data == where
+        f = L.result_empty((1_500_000,), np.float64)   # 12 MB as float64
+        assert f.dtype == np.float64 and f.flags.aligned
+        del b, c, f
+        gc.collect()
+        assert L._pool_bytes == 3 * 12_000_000
+        small = L.result_empty((1000, 3), np.float64)
+        assert small.flags.owndata
+        big = L.result_empty((65 << 20,), np.uint8)    # beyond the cap: never kept
+        assert big.flags.owndata
+        L.set_result_pool(0)
+        assert L._pool_bytes == 0 and L.result_empty((3, 2000, 2000), np.uint8).flags.owndata
+    finally:
+        L.set_result_pool(0)
+        L.set_result_pool(old_cap)
