@@ -417,10 +417,12 @@ def next_rows_leg(L, syn, orc, df, ras_dev=None):
             k_ms, _ = L.kernel_time_ms()
             total = raster.size
             npts = len(df)
-            # round 4 (sort-based, fixed order): points in (x, y, 3 values: float64), (cell, index) written, four 8-bit passes of
-            # the pair sort (16 B read + written per pass), the runs read back; per band-cell: float32 raster filled and read
-            # once, one byte out.  `frac_at_round3_bytes`: against the 6.4 GB the accumulator design of round 3 was priced at.
-            alg = npts * (16 + 8 * 3) + npts * 8 + npts * 16 * 4 + npts * 8 + total * (4 + 4 + 1) if agg == "mean" else None
+            # round 4 (sort-based, fixed order; byte-valued bands ride the sort as its payload): points in (x, y, 3 values: float64),
+            # the values read once more by the byte check and once by the packing, (cell, packed values) written, four 8-bit passes
+            # of the pair sort (16 B read + written per pass), the runs read back; per band-cell: one byte filled and (the tiles that
+            # hold points: a twelfth of this raster, not counted) a float32 written, read and its byte written again.
+            # `frac_at_round3_bytes`: against the 6.4 GB the accumulator design of round 3 was priced at.
+            alg = npts * (16 + 8 * 3) + npts * 8 * 3 * 2 + npts * 8 + npts * 16 * 4 + npts * 8 + total if agg == "mean" else None
             f2[agg] = {"call_ms_incl_transfers": wall * 1e3, "kernel_ms": k_ms, "raster": list(raster.shape),
                        "mpoints_per_s_kernel": npts / (k_ms / 1e3) / 1e6}
             if agg == "mean":
@@ -430,7 +432,7 @@ def next_rows_leg(L, syn, orc, df, ras_dev=None):
             if alg:
                 f2[agg]["roofline"] = {"bound": "hbm", "algorithmic_bytes": alg, "achieved": alg / (k_ms / 1e3) / 1e9, "peak": HBM_PEAK / 1e9,
                                        "unit": "GB/s", "frac": alg / (k_ms / 1e3) / HBM_PEAK,
-                                       "kernel": "rz_cell_kernel + rocPRIM radix_sort_pairs + rz_runs_kernel (Kahan sums in row order) + fill + rz_tail_kernel"}
+                                       "kernel": "rz_integer_check + rz_pack + rz_cell + rocPRIM radix_sort_pairs + rz_pieces<packed> + rz_join + fill + rz_tail (of the 1.1 ms the sort takes 0.41)"}
         # numpy / pandas port of the reference on a 600 m x 600 m window of the same table (its 3x3 focal pass is a Python lambda per pixel)
         x0, y0 = df["x"].min(), df["y"].median()
         win = df[(df["x"] < x0 + 600) & (np.abs(df["y"] - y0) < 300)]
