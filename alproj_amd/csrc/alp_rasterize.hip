@@ -818,6 +818,15 @@ namespace alp {
 
 enum { AGG_MEDIAN = 3 };
 
+// The (cell, payload) pair sort with NINE bits per onesweep pass (workgroups of 1024 x 8 items): a raster of up to 2^27 cells
+// is sorted in three passes where the library's tuned gfx950 configuration (8 bits) takes four, and a pass costs no more --
+// 11.7 M pairs, 27-bit keys: 0.273 ms against 0.432; 30 bits 0.348 against 0.431; 18 bits 0.199 against 0.329
+// (tools/sort_rate.hip: 6, 7, 9, 10, 12 items, 512 threads, 10 and 7 bits all measured slower).  The 64-bit composite keys of a
+// median whose bands are not bytes take it too: 59 bits 0.602 ms against 0.672.
+using RzPairSort = rocprim::radix_sort_config<
+    rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, 9, rocprim::block_radix_rank_algorithm::match>>;
+
 template <int AGG>
 static void launch_tail(const float *raster, int nb, int width, int height, int sweeps, int nodata, unsigned char *out_dev,
                         const unsigned *list, const unsigned *list_count) {
@@ -838,9 +847,9 @@ static void launch_tail(const float *raster, int nb, int width, int height, int 
 static size_t rz_sort_bytes(long long n, size_t *tmp_out) {
     size_t t1 = 0, t2 = 0, t3 = 0;
     const size_t count = (size_t)n;
-    rocprim::radix_sort_pairs(nullptr, t1, (unsigned *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr, count, 0u, 32u,
+    rocprim::radix_sort_pairs<RzPairSort>(nullptr, t1, (unsigned *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr, count, 0u, 32u,
                               ctx().stream);
-    rocprim::radix_sort_keys(nullptr, t2, (unsigned long long *)nullptr, (unsigned long long *)nullptr, count, 0u, 64u, ctx().stream);
+    rocprim::radix_sort_keys<RzPairSort>(nullptr, t2, (unsigned long long *)nullptr, (unsigned long long *)nullptr, count, 0u, 64u, ctx().stream);
     rocprim::radix_sort_pairs(nullptr, t3, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (unsigned *)nullptr,
                               (unsigned *)nullptr, count, 0u, 64u, ctx().stream);
     const size_t tmp = std::max(t1, std::max(t2, t3));
@@ -936,7 +945,7 @@ static int run_rasterize(int agg, const double *dx, const double *dy, const doub
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && agg != AGG_MEDIAN) {
         size_t t = tmp;
-        e = rocprim::radix_sort_pairs(sort_tmp, t, cell, cell_s, idx, idx_s, count, 0u, cell_bits, st);      // stable: a run keeps the rows' order
+        e = rocprim::radix_sort_pairs<RzPairSort>(sort_tmp, t, cell, cell_s, idx, idx_s, count, 0u, cell_bits, st);      // stable: a run keeps the rows' order
         if (e == hipSuccess) {
             RzPiece *first = (RzPiece *)key, *last = first + (size_t)nseg * nb;
             const unsigned gs = grid(nseg);
@@ -957,7 +966,7 @@ static int run_rasterize(int agg, const double *dx, const double *dy, const doub
         }
     } else if (e == hipSuccess && packed) {
         size_t t = tmp;
-        e = rocprim::radix_sort_pairs(sort_tmp, t, cell, cell_s, idx, idx_s, count, 0u, cell_bits, st);
+        e = rocprim::radix_sort_pairs<RzPairSort>(sort_tmp, t, cell, cell_s, idx, idx_s, count, 0u, cell_bits, st);
         if (e == hipSuccess) {
             const unsigned chunks = (unsigned)std::min<long long>((n + 63) / 64, (long long)cu * 256);
             hipLaunchKernelGGL(rz_median_packed_kernel, dim3(chunks), dim3(64), 0, st, cell_s, idx_s, n, nb, hw, ra);
@@ -971,17 +980,17 @@ static int run_rasterize(int agg, const double *dx, const double *dy, const doub
             size_t t = tmp;
             if (!(kind & 4u)) {             // bytes: cell : value in cell_bits + 8 bits (the NaN keys, all ones, end up last)
                 hipLaunchKernelGGL(rz_median_key_kernel<8>, dim3(grid(n)), dim3(256), 0, st, cell, dv, n, nb, b, key);
-                e = rocprim::radix_sort_keys(sort_tmp, t, key, key_s, count, 0u, std::min(64u, cell_bits + 9u), st);
+                e = rocprim::radix_sort_keys<RzPairSort>(sort_tmp, t, key, key_s, count, 0u, std::min(64u, cell_bits + 9u), st);
                 if (e != hipSuccess) break;
                 hipLaunchKernelGGL(rz_median_runs32_kernel<8>, dim3(grid(n)), dim3(256), 0, st, key_s, n, ra + b * hw);
             } else if (!(kind & 2u)) {      // integers below 2^16: cell : value in cell_bits + 16 bits
                 hipLaunchKernelGGL(rz_median_key_kernel<16>, dim3(grid(n)), dim3(256), 0, st, cell, dv, n, nb, b, key);
-                e = rocprim::radix_sort_keys(sort_tmp, t, key, key_s, count, 0u, std::min(64u, cell_bits + 17u), st);
+                e = rocprim::radix_sort_keys<RzPairSort>(sort_tmp, t, key, key_s, count, 0u, std::min(64u, cell_bits + 17u), st);
                 if (e != hipSuccess) break;
                 hipLaunchKernelGGL(rz_median_runs32_kernel<16>, dim3(grid(n)), dim3(256), 0, st, key_s, n, ra + b * hw);
             } else if (!(kind & 1u)) {      // float32 values
                 hipLaunchKernelGGL(rz_median_key_kernel<32>, dim3(grid(n)), dim3(256), 0, st, cell, dv, n, nb, b, key);
-                e = rocprim::radix_sort_keys(sort_tmp, t, key, key_s, count, 0u, 64u, st);
+                e = rocprim::radix_sort_keys<RzPairSort>(sort_tmp, t, key, key_s, count, 0u, 64u, st);
                 if (e != hipSuccess) break;
                 hipLaunchKernelGGL(rz_median_runs32_kernel<32>, dim3(grid(n)), dim3(256), 0, st, key_s, n, ra + b * hw);
             } else {
@@ -992,7 +1001,7 @@ static int run_rasterize(int agg, const double *dx, const double *dy, const doub
                 hipLaunchKernelGGL(rz_gather_cell_kernel, dim3(grid(n)), dim3(256), 0, st, idx_s, cell3, n, cell_s);
                 t = tmp;
                 unsigned *cell_s2 = (unsigned *)key;           // the value keys are spent
-                e = rocprim::radix_sort_pairs(sort_tmp, t, cell_s, cell_s2, idx_s, idx, count, 0u, 32u, st);
+                e = rocprim::radix_sort_pairs<RzPairSort>(sort_tmp, t, cell_s, cell_s2, idx_s, idx, count, 0u, 32u, st);
                 if (e != hipSuccess) break;
                 hipLaunchKernelGGL(rz_median_runs_kernel, dim3(grid(n)), dim3(256), 0, st, cell_s2, idx, dv, n, nb, b, ra + b * hw);
             }
