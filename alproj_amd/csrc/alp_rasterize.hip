@@ -12,14 +12,18 @@
 //   project.py:483-485  NaN -> nodata, clip to [0, 255], truncate to uint8
 // The GeoTIFF file itself (rasterio) stays on the host side of the ABI.
 //
-// Kernels (round 4: sort-based, no atomics, no accumulators): the cell of every point, ONE stable radix sort of (cell, point)
-// shared by all bands, then a thread per run of equal cells walks its points IN THEIR ORIGINAL ORDER and forms pandas'
-// aggregate -- for the mean the Kahan-compensated float64 sum of libgroupby's group_mean, so that the float64 value, its
-// float32 cast and the truncated byte are the reference's for ANY band values, not only for byte-valued ones (the atomics of
-// rounds 2-3 added in arrival order: exact for integers below 2^53, one ulp off for general floats); the median sorts one
-// composite 64-bit key (cell : order-preserving float32 value) per band.  Then the fused tail (float32 raster -> focal
-// sweeps in LDS -> bytes) or, for more than RZ_SMAX sweeps, separate sweep / conversion kernels.  The 3x3 mean adds its
-// window in numpy's order (pairwise block of 8, then the ninth).
+// Kernels (round 4: sort-based, no atomics, no accumulators; rasterize_runs.h, rasterize_median.h, rasterize_tail.h): the
+// cell of every point, ONE stable radix sort of (cell, point) shared by all bands, then per run of equal cells pandas' aggregate:
+//   * band values of any kind, mean: a thread per run walks its points IN THEIR ORIGINAL ORDER with the Kahan-compensated
+//     float64 sum of libgroupby's group_mean -- the float64 value, its float32 cast and the truncated byte are the reference's
+//     (the atomics of rounds 2-3 added in arrival order: exact for integers below 2^53, one ulp off for general floats);
+//   * max / min, and the mean of integer-valued bands: order-free pieces of 16 sorted positions + a join;
+//   * byte-valued bands (at most four, no NaN -- a uint8 photograph, the reference's use): the values ride the sort as its
+//     32-bit payload instead of the point index, nothing is gathered, and the median selects from the same one sort;
+//   * any other median: one sort of a composite 64-bit key (cell : value) per band.
+// Then the fused tail (float32 raster -> focal sweeps in LDS -> bytes) over the tiles that hold points or, for more than
+// RZ_SMAX sweeps, separate sweep / conversion kernels.  The 3x3 mean adds its window in numpy's order (pairwise block of 8,
+// then the ninth).
 #include "alp_raster_internal.h"
 
 #include <algorithm>
@@ -42,773 +46,10 @@ __device__ __forceinline__ unsigned long long d2ord(double d) {
     return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
 
-// cell (row * width + col, project.py:435-436) and index of every point
-__global__ __launch_bounds__(256) void rz_cell_kernel(const double *__restrict__ x, const double *__restrict__ y, long long n,
-                                                      double x_min, double y_max, double res, int width, int height,
-                                                      unsigned *__restrict__ cell, unsigned *__restrict__ idx,
-                                                      unsigned char *__restrict__ tile_used, int tiles_x) {      // idx NULL: the slot holds packed band values
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        long long col = (long long)((x[i] - x_min) / res);
-        long long row = (long long)((y_max - y[i]) / res);
-        col = col < 0 ? 0 : (col > width - 1 ? width - 1 : col);
-        row = row < 0 ? 0 : (row > height - 1 ? height - 1 : row);
-        cell[i] = (unsigned)(row * width + col);
-        if (idx) idx[i] = (unsigned)i;
-        if (tile_used) tile_used[(row >> 5) * tiles_x + (col >> 6)] = 1;      // RZ_TH = 32, RZ_TW = 64; every writer writes 1
-    }
-}
-
-// Runs of equal cell in the (stably) cell-sorted order: the points of a run are the rows of one pandas group in their
-// original order.  Each run is aggregated band by band, skipping NaN like pandas does:
-//   mean   libgroupby.group_mean: Kahan summation  y = v - c; t = s + y; c = (t - s) - y; s = t  (c reset to 0 when it
-//          turns NaN: an infinite value), then s / count -- checked against pandas 2.3 bit for bit (tests)
-//   max / min   order-free
-// and its float32 cast (project.py:459) goes into the NaN-filled raster.  One thread per run: the recurrence is sequential,
-// the loads are not -- a run is walked eight points at a time, all their gathers in flight together (next to the camera
-// thousands of camera pixels share a cell: with one gather per turn such a run alone took a millisecond, and a wave that
-// ran the recurrence for 64 points with operands broadcast from lane to lane -- every lane computing the same -- took as
-// long: measured 2.9 and 1.07 ms for the 11.7 M points of the 100 M-vertex frame).  A run's end is found by galloping and
-// bisection, not by a load per point.
-template <int AGG>
-struct RzAcc {
-    double s = 0.0, comp = 0.0, m = AGG == AGG_MAX ? -INFINITY : INFINITY;
-    long long cnt = 0;
-    __device__ __forceinline__ void take(double v) {
-        if (v != v) return;
-        ++cnt;
-        if constexpr (AGG == AGG_MEAN) {
-            const double yv = v - comp, t = s + yv;
-            comp = (t - s) - yv;
-            if (comp != comp) comp = 0.0;
-            s = t;
-        } else if constexpr (AGG == AGG_MAX) {
-            m = v > m ? v : m;
-        } else {
-            m = v < m ? v : m;
-        }
-    }
-    __device__ __forceinline__ float result() const { return AGG == AGG_MEAN ? (float)(s / (double)cnt) : (float)m; }
-};
-
-template <int AGG, int NB>
-__device__ __forceinline__ void rz_walk_run(const unsigned *__restrict__ idx_s, const double *__restrict__ values, long long i,
-                                            long long j, int nb, int b0, unsigned cell, long long hw, float *__restrict__ raster) {
-    RzAcc<AGG> acc[NB];
-    long long k = i;
-    for (; k + 8 <= j; k += 8) {
-        unsigned id[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) id[u] = idx_s[k + u];
-        double v[8][NB];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int g = 0; g < NB; ++g) v[u][g] = values[(long long)id[u] * nb + b0 + g];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int g = 0; g < NB; ++g) acc[g].take(v[u][g]);
-    }
-    for (; k < j; ++k) {
-        const double *row = values + (long long)idx_s[k] * nb + b0;
-#pragma unroll
-        for (int g = 0; g < NB; ++g) acc[g].take(row[g]);
-    }
-#pragma unroll
-    for (int g = 0; g < NB; ++g)
-        if (acc[g].cnt) raster[(long long)(b0 + g) * hw + cell] = acc[g].result();
-}
-
-template <int AGG>
-__global__ __launch_bounds__(256) void rz_runs_kernel(const unsigned *__restrict__ cell_s, const unsigned *__restrict__ idx_s,
-                                                      const double *__restrict__ values, long long n, int nb, long long hw,
-                                                      float *__restrict__ raster) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const unsigned c = cell_s[i];
-        if (i > 0 && cell_s[i - 1] == c) continue;             // not the head of a run
-        long long lo = i, step = 1;                            // cell_s[lo] is in the run
-        while (lo + step < n && cell_s[lo + step] == c) { lo += step; step <<= 1; }
-        long long hi = lo + step < n ? lo + step : n;         // cell_s[hi] is not (or hi == n)
-        while (hi - lo > 1) {
-            const long long mid = lo + ((hi - lo) >> 1);
-            if (cell_s[mid] == c) lo = mid; else hi = mid;
-        }
-        int b0 = 0;
-        for (; b0 + 4 <= nb; b0 += 4) rz_walk_run<AGG, 4>(idx_s, values, i, hi, nb, b0, c, hw, raster);
-        if (nb - b0 == 3) rz_walk_run<AGG, 3>(idx_s, values, i, hi, nb, b0, c, hw, raster);
-        else if (nb - b0 == 2) rz_walk_run<AGG, 2>(idx_s, values, i, hi, nb, b0, c, hw, raster);
-        else if (nb - b0 == 1) rz_walk_run<AGG, 1>(idx_s, values, i, hi, nb, b0, c, hw, raster);
-    }
-}
-
-// ---- order-free aggregates in parallel pieces
-// max / min never depend on the order, and neither does the mean of INTEGER-valued bands (image bytes in float64 columns:
-// Kahan's compensation stays exactly 0 and every partial sum below 2^53 is exact).  Then a run need not be walked by one
-// thread -- next to the camera thousands of camera pixels share a cell, and the longest run alone set the kernel's time
-// (1.1 ms of 2.2 for the 100 M-vertex frame).  rz_pieces_kernel: a thread per RZ_SEG consecutive sorted positions walks them,
-// finishes the runs that lie inside and leaves (sum, count) of the at most two pieces that cross its borders;
-// rz_join_kernel: the thread whose segment holds a crossing run's head adds the pieces of the segments after it.
-constexpr int RZ_SEG = 16;
-struct RzPiece {
-    double v;            // sum, or max / min
-    unsigned cnt;
-    unsigned pad;
-};
-
-template <int AGG>
-__device__ __forceinline__ void rz_piece_take(RzPiece &p, double v) {
-    if (v != v) return;
-    ++p.cnt;
-    if constexpr (AGG == AGG_MEAN) p.v += v;
-    else if constexpr (AGG == AGG_MAX) p.v = v > p.v ? v : p.v;
-    else p.v = v < p.v ? v : p.v;
-}
-template <int AGG>
-__device__ __forceinline__ void rz_piece_join(RzPiece &p, const RzPiece &q) {
-    p.cnt += q.cnt;
-    if constexpr (AGG == AGG_MEAN) p.v += q.v;
-    else if constexpr (AGG == AGG_MAX) p.v = q.v > p.v ? q.v : p.v;
-    else p.v = q.v < p.v ? q.v : p.v;
-}
-template <int AGG>
-__device__ __forceinline__ float rz_piece_result(const RzPiece &p) {
-    return AGG == AGG_MEAN ? (float)(p.v / (double)p.cnt) : (float)p.v;
-}
-
-// first[t * nb + b]: the piece that CONTINUES a run from segment t - 1 (it starts at the segment's first position);
-// last[t * nb + b]: the piece that starts a run inside segment t (or at its first position) and continues into t + 1
-// PACKED: `id` is not the point's index but its (at most four) byte-valued band values, one byte each -- the sort carried them
-// along as its payload, nothing is gathered (image bytes: the reference's own use, project.py:364 on a uint8 photograph)
-template <int AGG, int NB, bool PACKED>
-__device__ __forceinline__ void rz_pieces_bands(const unsigned (&cs)[RZ_SEG], const unsigned (&id)[RZ_SEG], unsigned before, unsigned after,
-                                                int count, const double *__restrict__ values, int nb, int b0, long long hw, long long t,
-                                                float *__restrict__ raster, RzPiece *__restrict__ first, RzPiece *__restrict__ last) {
-    const double ident = AGG == AGG_MEAN ? 0.0 : (AGG == AGG_MAX ? -INFINITY : INFINITY);
-    RzPiece pc[NB];
-#pragma unroll
-    for (int g = 0; g < NB; ++g) pc[g] = {ident, 0u, 0u};
-    bool from_head = before != cs[0];
-#pragma unroll
-    for (int u = 0; u < RZ_SEG; ++u) {
-        if (u >= count) break;
-        if constexpr (PACKED) {
-#pragma unroll
-            for (int g = 0; g < NB; ++g) rz_piece_take<AGG>(pc[g], (double)((id[u] >> (8 * (b0 + g))) & 0xFFu));
-        } else {
-            const double *row = values + (long long)id[u] * nb + b0;
-#pragma unroll
-            for (int g = 0; g < NB; ++g) rz_piece_take<AGG>(pc[g], row[g]);
-        }
-        const unsigned nextc = u + 1 < count ? cs[u + 1 < RZ_SEG ? u + 1 : 0] : after;
-        if (nextc != cs[u]) {                          // the run ends here
-#pragma unroll
-            for (int g = 0; g < NB; ++g) {
-                if (from_head) { if (pc[g].cnt) raster[(long long)(b0 + g) * hw + cs[u]] = rz_piece_result<AGG>(pc[g]); }
-                else first[t * nb + b0 + g] = pc[g];
-                pc[g].v = ident; pc[g].cnt = 0u;
-            }
-            from_head = true;
-        } else if (u + 1 == count) {                   // ... or goes on in the next segment
-#pragma unroll
-            for (int g = 0; g < NB; ++g) {
-                if (from_head) last[t * nb + b0 + g] = pc[g]; else first[t * nb + b0 + g] = pc[g];
-            }
-        }
-    }
-}
-
-template <int AGG, bool PACKED = false>
-__global__ __launch_bounds__(256) void rz_pieces_kernel(const unsigned *__restrict__ cell_s, const unsigned *__restrict__ idx_s,
-                                                        const double *__restrict__ values, long long n, int nb, long long hw,
-                                                        float *__restrict__ raster, RzPiece *__restrict__ first,
-                                                        RzPiece *__restrict__ last) {
-    const long long nseg = (n + RZ_SEG - 1) / RZ_SEG, stride = (long long)gridDim.x * blockDim.x;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < nseg; t += stride) {
-        const long long p0 = t * RZ_SEG, p1 = p0 + RZ_SEG < n ? p0 + RZ_SEG : n;
-        unsigned cs[RZ_SEG], id[RZ_SEG];
-#pragma unroll
-        for (int u = 0; u < RZ_SEG; ++u) {
-            cs[u] = p0 + u < p1 ? cell_s[p0 + u] : 0xFFFFFFFFu;
-            id[u] = p0 + u < p1 ? idx_s[p0 + u] : 0u;
-        }
-        const unsigned before = p0 > 0 ? cell_s[p0 - 1] : 0xFFFFFFFFu, after = p1 < n ? cell_s[p1] : 0xFFFFFFFFu;
-        const int count = (int)(p1 - p0);
-        int b0 = 0;
-        for (; b0 + 4 <= nb; b0 += 4) rz_pieces_bands<AGG, 4, PACKED>(cs, id, before, after, count, values, nb, b0, hw, t, raster, first, last);
-        if (nb - b0 == 3) rz_pieces_bands<AGG, 3, PACKED>(cs, id, before, after, count, values, nb, b0, hw, t, raster, first, last);
-        else if (nb - b0 == 2) rz_pieces_bands<AGG, 2, PACKED>(cs, id, before, after, count, values, nb, b0, hw, t, raster, first, last);
-        else if (nb - b0 == 1) rz_pieces_bands<AGG, 1, PACKED>(cs, id, before, after, count, values, nb, b0, hw, t, raster, first, last);
-    }
-}
-
-template <int AGG>
-__global__ __launch_bounds__(256) void rz_join_kernel(const unsigned *__restrict__ cell_s, long long n, int nb, long long hw,
-                                                      float *__restrict__ raster, const RzPiece *__restrict__ first,
-                                                      const RzPiece *__restrict__ last) {
-    const long long nseg = (n + RZ_SEG - 1) / RZ_SEG, stride = (long long)gridDim.x * blockDim.x;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < nseg; t += stride) {
-        const long long p0 = t * RZ_SEG, p1 = p0 + RZ_SEG;
-        if (p1 >= n) continue;                                   // the last segment: nothing goes on behind it
-        const unsigned c = cell_s[p1 - 1];
-        if (cell_s[p1] != c) continue;                           // no run leaves this segment
-        if (cell_s[p0] == c && p0 > 0 && cell_s[p0 - 1] == c) continue;      // the run's head is in an earlier segment
-        // segments t + 1 ... e: the run fills t + 1 ... e - 1 and ends in e.  Gallop + bisect on "position still in the run".
-        long long lo = p1, step = RZ_SEG;
-        while (lo + step < n && cell_s[lo + step] == c) { lo += step; step <<= 1; }
-        long long hi = lo + step < n ? lo + step : n;
-        while (hi - lo > 1) {
-            const long long mid = lo + ((hi - lo) >> 1);
-            if (cell_s[mid] == c) lo = mid; else hi = mid;
-        }
-        const long long e = lo / RZ_SEG;                       // segment of the run's last position
-        for (int b = 0; b < nb; ++b) {
-            RzPiece acc = last[t * nb + b];
-            long long u = t + 1;
-            for (; u + 4 <= e + 1; u += 4) {
-                const RzPiece q0 = first[u * nb + b], q1 = first[(u + 1) * nb + b], q2 = first[(u + 2) * nb + b], q3 = first[(u + 3) * nb + b];
-                rz_piece_join<AGG>(acc, q0); rz_piece_join<AGG>(acc, q1); rz_piece_join<AGG>(acc, q2); rz_piece_join<AGG>(acc, q3);
-            }
-            for (; u <= e; ++u) rz_piece_join<AGG>(acc, first[u * nb + b]);
-            if (acc.cnt) raster[(long long)b * hw + c] = rz_piece_result<AGG>(acc);
-        }
-    }
-}
-
-// what do the bands hold?  flag bit 0: some value is not an integer of magnitude below 2^31; bit 1: some value is not a byte
-// (an integer in [0, 255]; NaN is not a byte either: a packed value has no way to say "skip me")
-__global__ __launch_bounds__(256) void rz_integer_check_kernel(const double *__restrict__ values, long long count,
-                                                               unsigned *__restrict__ flag) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    unsigned bad = 0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-        const double v = values[i];
-        if (v != v) { bad |= 2u; continue; }
-        if (!(fabs(v) < 2147483648.0 && v == (double)(long long)v)) bad |= 3u;
-        else if (!(v >= 0.0 && v <= 255.0)) bad |= 2u;
-    }
-    for (int m = 32; m >= 1; m >>= 1) bad |= (unsigned)__shfl_xor((int)bad, m, 64);
-    if (bad && (threadIdx.x & 63) == 0 && (*flag & bad) != bad) atomicOr(flag, bad);
-}
-
-// byte-valued bands (nb <= 4), interleaved float64 -> one packed word per point: the sort's payload
-__global__ __launch_bounds__(256) void rz_pack_kernel(const double *__restrict__ values, long long n, int nb, unsigned *__restrict__ packed) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        unsigned w = 0;
-        for (int b = 0; b < nb; ++b) w |= ((unsigned)values[i * nb + b] & 0xFFu) << (8 * b);
-        packed[i] = w;
-    }
-}
-
-// one sweep of the NaN-only 3x3 focal fill
-template <int AGG>
-__global__ __launch_bounds__(256) void rz_focal_kernel(const float *__restrict__ src, float *__restrict__ dst,
-                                                       int nb, int width, int height) {
-    const long long hw = (long long)width * height;
-    const long long total = hw * nb;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const float centre = src[i];
-        if (centre == centre) { dst[i] = centre; continue; }
-        const long long p = i % hw;
-        const int row = (int)(p / width), col = (int)(p - (long long)row * width);
-        const float *band = src + (i - p);
-        double w[9];
-        int k = 0, have = 0;
-#pragma unroll
-        for (int dr = -1; dr <= 1; ++dr)
-#pragma unroll
-            for (int dc = -1; dc <= 1; ++dc, ++k) {
-                const int rr = row + dr, cc = col + dc;
-                float val = __int_as_float(0x7fc00000);
-                if (rr >= 0 && rr < height && cc >= 0 && cc < width) val = band[(long long)rr * width + cc];
-                const bool ok = val == val;
-                have += ok;
-                if constexpr (AGG == AGG_MEAN) w[k] = ok ? (double)val : 0.0;           // nansum: NaN -> 0
-                else if constexpr (AGG == AGG_MAX) w[k] = ok ? (double)val : -INFINITY;
-                else w[k] = ok ? (double)val : INFINITY;
-            }
-        float out = __int_as_float(0x7fc00000);
-        if (have) {
-            if constexpr (AGG == AGG_MEAN) {
-                // numpy's pairwise sum of 9 contiguous doubles: block of 8, then the rest
-                const double s = (((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]))) + w[8];
-                out = (float)(s / (double)have);
-            } else {
-                double m = w[0];
-#pragma unroll
-                for (int j = 1; j < 9; ++j) m = (AGG == AGG_MAX) ? fmax(m, w[j]) : fmin(m, w[j]);
-                out = (float)m;
-            }
-        }
-        dst[i] = out;
-    }
-}
-
-__global__ __launch_bounds__(256) void rz_to_u8_kernel(const float *__restrict__ raster, long long total, int nodata,
-                                                       unsigned char *__restrict__ out) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const float v = raster[i];
-        unsigned char o;
-        if (v != v) o = (unsigned char)nodata;
-        else o = (unsigned char)(v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v));      // clip, then truncate
-        out[i] = o;
-    }
-}
-
-// ------------------------------------------------------------------ fused tail
-// up to RZ_SMAX focal sweeps + uint8 in ONE pass over the raster: a workgroup owns a tile of RZ_TW x RZ_TH cells, loads the
-// float32 raster of the tile and a halo of S cells into LDS (a cell S sweeps later depends on the cells within S of it,
-// nothing else), sweeps there -- each sweep is valid on a region one cell smaller all round -- and writes bytes only.
-// Every value is formed by the expressions of the separate kernels above (which stay as the path for more sweeps), so the
-// bytes are the same; the raster does not cross HBM as float32 once per sweep and once more for the conversion, and a
-// tile whose own and neighbouring tiles hold no point -- most of a georectified photograph's bounding box -- reads nothing.
-constexpr int RZ_TW = 64, RZ_TH = 32, RZ_SMAX = 8;
-enum { AGG_MEDIAN_FOCAL = 3 };
-
-template <int AGG>
-__device__ __forceinline__ float rz_window_value(const float *__restrict__ s, int lw, int at) {
-    const float nan = __int_as_float(0x7fc00000);
-    if constexpr (AGG == AGG_MEDIAN_FOCAL) {
-        // the window's values in order, its NaN behind them as +inf: a 25-exchange network for nine (no loop whose length
-        // differs from lane to lane: the insertion sort of rz_focal_median_kernel took 0.36 ms of the 100 M-vertex frame's tail,
-        // this 0.1x).  Equal values (and +-0) may come out in another order than there: the same numbers, and the tail writes bytes
-        float w[9];
-        int have = 0, k = 0;
-#pragma unroll
-        for (int dr = -1; dr <= 1; ++dr)
-#pragma unroll
-            for (int dc = -1; dc <= 1; ++dc, ++k) {
-                const float val = s[at + dr * lw + dc];
-                const bool ok = val == val;
-                have += ok;
-                w[k] = ok ? val : INFINITY;
-            }
-        if (!have) return nan;
-#define RZ_CE(i, j) { const float lo = w[i] < w[j] ? w[i] : w[j], hi = w[i] < w[j] ? w[j] : w[i]; w[i] = lo; w[j] = hi; }
-        RZ_CE(0, 3) RZ_CE(1, 7) RZ_CE(2, 5) RZ_CE(4, 8)
-        RZ_CE(0, 7) RZ_CE(2, 4) RZ_CE(3, 8) RZ_CE(5, 6)
-        RZ_CE(0, 2) RZ_CE(1, 3) RZ_CE(4, 5) RZ_CE(7, 8)
-        RZ_CE(1, 4) RZ_CE(3, 6) RZ_CE(5, 7)
-        RZ_CE(0, 1) RZ_CE(2, 4) RZ_CE(3, 5) RZ_CE(6, 8)
-        RZ_CE(2, 3) RZ_CE(4, 5) RZ_CE(6, 7)
-        RZ_CE(1, 2) RZ_CE(3, 4) RZ_CE(5, 6)
-#undef RZ_CE
-        const int ka = (have - 1) >> 1, kb = have >> 1;
-        float a = w[0], b = w[0];
-#pragma unroll
-        for (int u = 1; u < 9; ++u) { a = ka == u ? w[u] : a; b = kb == u ? w[u] : b; }
-        return (have & 1) ? a : (float)(((double)a + (double)b) / 2);
-    } else {
-        double w[9];
-        int k = 0, have = 0;
-#pragma unroll
-        for (int dr = -1; dr <= 1; ++dr)
-#pragma unroll
-            for (int dc = -1; dc <= 1; ++dc, ++k) {
-                const float val = s[at + dr * lw + dc];
-                const bool ok = val == val;
-                have += ok;
-                if constexpr (AGG == AGG_MEAN) w[k] = ok ? (double)val : 0.0;
-                else if constexpr (AGG == AGG_MAX) w[k] = ok ? (double)val : -INFINITY;
-                else w[k] = ok ? (double)val : INFINITY;
-            }
-        if (!have) return nan;
-        if constexpr (AGG == AGG_MEAN) {
-            const double sum = (((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]))) + w[8];     // numpy's order, as above
-            return (float)(sum / (double)have);
-        } else {
-            double m = w[0];
-#pragma unroll
-            for (int j = 1; j < 9; ++j) m = (AGG == AGG_MAX) ? fmax(m, w[j]) : fmin(m, w[j]);
-            return (float)m;
-        }
-    }
-}
-
-// the float32 raster the run kernels wrote (NaN = empty cell) -> S sweeps of the aggregate's own 3x3 window -> bytes
-// NaN into the float32 raster of the tiles that hold a point (all bands); the tail never reads the others
-// (the tiles: rz_tile_list_kernel's list; an entry = tile number | the 3 x 3 neighbourhood's "holds a point" bits << 20, bit 4 the
-// tile itself)
-constexpr int RZ_TILE_BITS = 20;
-__global__ __launch_bounds__(256) void rz_fill_tiles_kernel(float *__restrict__ raster, const unsigned *__restrict__ list,
-                                                            const unsigned *__restrict__ list_count, int nb, int width, int height,
-                                                            int tiles_x) {
-    const unsigned count = *list_count;
-    const long long hw = (long long)width * height;
-    const float nan = __int_as_float(0x7fc00000);
-    for (unsigned e = blockIdx.x; e < count; e += gridDim.x) {
-        const unsigned entry = list[e];
-        if (!((entry >> (RZ_TILE_BITS + 4)) & 1u)) continue;
-        const int t = (int)(entry & ((1u << RZ_TILE_BITS) - 1u));
-        const int ty = t / tiles_x, tx = t - ty * tiles_x;
-        for (int k = threadIdx.x; k < RZ_TW * RZ_TH * nb; k += 256) {
-            const int b = k / (RZ_TW * RZ_TH), r = (k / RZ_TW) % RZ_TH, c = k % RZ_TW;
-            const int gr = ty * RZ_TH + r, gc = tx * RZ_TW + c;
-            if (gr < height && gc < width) raster[b * hw + (long long)gr * width + gc] = nan;
-        }
-    }
-}
-
-// the tiles a sweep can reach -- those with a point in their own or one of their eight neighbouring tiles -- as a compact list
-// (any order): the fill and the tail walk it instead of launching a workgroup per tile of a mostly empty raster
-__global__ __launch_bounds__(256) void rz_tile_list_kernel(const unsigned char *__restrict__ tile_used, int tiles_x, int tiles_y,
-                                                           unsigned *__restrict__ list, unsigned *__restrict__ list_count) {
-    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (t >= tiles_x * tiles_y) return;
-    const int ty = t / tiles_x, tx = t - ty * tiles_x;
-    unsigned used9 = 0;
-    for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int yy = ty + dy, xx = tx + dx;
-            if (yy >= 0 && yy < tiles_y && xx >= 0 && xx < tiles_x && tile_used[yy * tiles_x + xx]) used9 |= 1u << (3 * (dy + 1) + dx + 1);
-        }
-    if (used9) list[atomicAdd(list_count, 1u)] = (unsigned)t | (used9 << RZ_TILE_BITS);
-}
-
-// list: the tiles a sweep can reach (rz_tile_list_kernel) -- most of a georectified photograph's bounding box is empty; the
-// other tiles keep the nodata launch_tail filled `out` with (one wide fill instead of byte stores tile by tile), and cells
-// of neighbouring tiles without points are NaN without being read (they were never filled)
-template <int AGG>
-__global__ __launch_bounds__(256) void rz_tail_kernel(const float *__restrict__ raster, int width, int height, int S,
-                                                      int nodata, int tiles_x, int nb, unsigned char *__restrict__ out,
-                                                      const unsigned *__restrict__ list, const unsigned *__restrict__ list_count) {
-    extern __shared__ float rz_tail_lds[];                   // two rasters of (RZ_TH + 2 S) x (RZ_TW + 2 S) floats: 18 KB at S = 1, 31 KB at S = 8
-    __shared__ int s_any;
-    const float nan = __int_as_float(0x7fc00000);
-    const int tid = (int)threadIdx.x;
-    const long long hw = (long long)width * height;
-    const int lw = RZ_TW + 2 * S, lh = RZ_TH + 2 * S;
-    const float inv_lw = 1.0f / (float)lw;                       // idx / lw through (idx + 0.5) * (1 / lw): idx < 3840, exact
-    const unsigned work = list_count[0] * (unsigned)nb;          // (tile, band) pairs, the bands of a tile next to each other
-    for (unsigned item = blockIdx.x; item < work; item += gridDim.x) {
-        __syncthreads();                                             // the previous item's LDS is read no more
-        if (tid == 0) s_any = 0;
-        __syncthreads();
-        const unsigned entry = list[item / (unsigned)nb];
-        const int t = (int)(entry & ((1u << RZ_TILE_BITS) - 1u));
-        const unsigned used9 = entry >> RZ_TILE_BITS;                // which of the 3 x 3 tiles around this one hold points (bit 3 * (dy + 1) + (dx + 1))
-        const int ty = t / tiles_x, tx = t - ty * tiles_x;
-        const long long band_base = (long long)(item % (unsigned)nb) * hw;
-        const int x0 = tx * RZ_TW - S, y0 = ty * RZ_TH - S;        // raster position of LDS cell (0, 0)
-        float *buf_cur = rz_tail_lds, *buf_nxt = rz_tail_lds + lw * lh;
-        bool any = false;
-        for (int idx = tid; idx < lw * lh; idx += 256) {
-            const int r = (int)(((float)idx + 0.5f) * inv_lw), c = idx - r * lw;
-            const int gr = y0 + r, gc = x0 + c;
-            float v = nan;                                           // outside the raster: NaN, in every sweep
-            if (gr >= 0 && gr < height && gc >= 0 && gc < width) {
-                const int dy = r < S ? 0 : (r >= S + RZ_TH ? 2 : 1), dx = c < S ? 0 : (c >= S + RZ_TW ? 2 : 1);
-                if ((used9 >> (3 * dy + dx)) & 1u) v = raster[band_base + (long long)gr * width + gc];
-            }
-            buf_cur[idx] = v;
-            any |= (v == v);
-        }
-        if (any) s_any = 1;
-        __syncthreads();
-        if (s_any) {
-            for (int s = 0; s < S; ++s) {
-                const int rw = lw - 2 * (s + 1), rh = lh - 2 * (s + 1);
-                const float inv_rw = 1.0f / (float)rw;
-                for (int idx = tid; idx < rw * rh; idx += 256) {
-                    int r = (int)(((float)idx + 0.5f) * inv_rw), c = idx - r * rw;
-                    r += s + 1;
-                    c += s + 1;
-                    const int at = r * lw + c;
-                    float o = buf_cur[at];
-                    if (o != o) {
-                        const int gr = y0 + r, gc = x0 + c;
-                        if (gr >= 0 && gr < height && gc >= 0 && gc < width) o = rz_window_value<AGG>(buf_cur, lw, at);
-                    }
-                    buf_nxt[at] = o;
-                }
-                __syncthreads();
-                float *const done = buf_cur;
-                buf_cur = buf_nxt;
-                buf_nxt = done;
-            }
-        }
-        for (int idx = tid; idx < RZ_TW * RZ_TH; idx += 256) {
-            const int r = idx / RZ_TW, c = idx % RZ_TW;
-            const int gr = y0 + S + r, gc = x0 + S + c;
-            if (gr >= height || gc >= width) continue;
-            const float v = buf_cur[(r + S) * lw + c + S];
-            unsigned char o;
-            if (v != v) o = (unsigned char)nodata;
-            else o = (unsigned char)(v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v));      // clip, then truncate
-            out[band_base + (long long)gr * width + gc] = o;
-        }
-    }
-}
-
-// ------------------------------------------------------------------ median
-// groupby median needs the values of every cell in order.  Image bands are bytes or float32 in float64 columns: when every
-// non-NaN value of the band IS a float32 (checked on the device), ONE radix sort of the composite key
-// (cell : order-preserving float32 bits) per band puts every cell's values in order, and the middle key(s) of a run ARE the
-// median's operands.  Any other band takes two stable sorts (by value, then by cell) as before.
-__device__ __forceinline__ unsigned f2ord(float f) {
-    const unsigned u = __float_as_uint(f);
-    return (u >> 31) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float ord2f(unsigned o) { return __uint_as_float((o >> 31) ? (o & 0x7fffffffu) : ~o); }
-
-// what kind of values do the bands hold?  flag[band] bit 0: some value is not a float32; bit 1: some value is not an integer in
-// [0, 65535]; bit 2: not an integer in [0, 255] (image bytes and 16-bit samples: their composite key needs 8 / 16 value bits, three
-// / two radix passes fewer); bit 3: some value is NaN (bytes without one can ride the sort as its payload: rz_median_packed_kernel).
-// All bands in one launch: one wait of the host instead of one per band.
-__global__ __launch_bounds__(256) void rz_median_check_kernel(const double *__restrict__ values, long long count, int nb,
-                                                              unsigned *__restrict__ flag) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-        const double val = values[i];
-        unsigned bad = 0;
-        if (val != val) bad = 8u;
-        else {
-            if ((double)(float)val != val) bad |= 1u;
-            const bool whole = val >= 0.0 && val <= 65535.0 && val == (double)(unsigned)val;
-            if (!whole) bad |= 6u;
-            else if (val > 255.0) bad |= 4u;
-        }
-        if (bad) {
-            unsigned *f = flag + (int)(i % nb);
-            if ((*f & bad) != bad) atomicOr(f, bad);           // a plain look first: the word settles after a few writers
-        }
-    }
-}
-
-// VBITS = 32: key = cell : order-preserving float32 bits; VBITS = 16 / 8: key = cell : the integer itself
-template <int VBITS>
-__global__ __launch_bounds__(256) void rz_median_key_kernel(const unsigned *__restrict__ cell, const double *__restrict__ values,
-                                                            long long n, int nb, int band, unsigned long long *__restrict__ key) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const double val = values[i * nb + band];
-        const unsigned long long lo = VBITS == 32 ? (unsigned long long)f2ord((float)val) : (unsigned long long)(unsigned)val;
-        key[i] = val != val ? ~0ull : (((unsigned long long)cell[i] << VBITS) | lo);      // NaN: behind every cell (cells are below 2^31)
-    }
-}
-
-template <int VBITS>
-__global__ __launch_bounds__(256) void rz_median_runs32_kernel(const unsigned long long *__restrict__ key_s, long long n,
-                                                               float *__restrict__ raster_band) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const unsigned long long k0 = key_s[i];
-        const unsigned c = (unsigned)(k0 >> VBITS);
-        if (k0 == ~0ull || (i > 0 && (unsigned)(key_s[i - 1] >> VBITS) == c)) continue;      // NaN tail, or not the head of a run
-        // the run's end: gallop, then bisect (a load per element would cost a run of thousands a millisecond)
-        long long lo = i, step = 1;                            // key_s[lo] is in the run
-        while (lo + step < n && key_s[lo + step] != ~0ull && (unsigned)(key_s[lo + step] >> VBITS) == c) { lo += step; step <<= 1; }
-        long long hi = lo + step < n ? lo + step : n;         // key_s[hi] is not (or hi == n)
-        while (hi - lo > 1) {
-            const long long mid = lo + ((hi - lo) >> 1);
-            if (key_s[mid] != ~0ull && (unsigned)(key_s[mid] >> VBITS) == c) lo = mid; else hi = mid;
-        }
-        const long long k = hi - i;
-        const unsigned long long ka = key_s[i + (k - 1) / 2], kb = key_s[i + k / 2];
-        const double a = VBITS == 32 ? (double)ord2f((unsigned)ka) : (double)(unsigned)(ka & ((1ull << VBITS) - 1ull));
-        const double b = VBITS == 32 ? (double)ord2f((unsigned)kb) : (double)(unsigned)(kb & ((1ull << VBITS) - 1ull));
-        raster_band[c] = (float)((k & 1) ? a : (a + b) / 2);
-    }
-}
-
-// ---- byte-valued bands (at most four, no NaN): ONE sort by cell with the packed values as its payload (the mean's sort), then
-// the middle value(s) of every run are SELECTED from its words -- the order inside a run does not matter to a median.  A run
-// of up to 16 points (nearly all: the frame's cells hold 1.5 points on average) is sorted in the registers of the thread at
-// its head (a bitonic network over its bytes, padded with 256); a longer one (the 100 M-vertex frame: 138 000 of 1.74 M runs,
-// up to 671 points, holding 46 % of the points) is taken by the whole wave: its bytes are counted into a 256-bin histogram in
-// LDS, four bins to a lane, and a prefix sum over the lanes finds the bin of the middle.  (A list of the long runs for a
-// second kernel, appended to with one atomic per run: 1.1 ms -- the 138 000 atomics on one word.)
-template <int N>
-__device__ __forceinline__ void rz_sort_small(unsigned (&a)[N]) {
-#pragma unroll
-    for (int k = 2; k <= N; k <<= 1)
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1)
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const bool up = (i & k) == 0;
-                    const unsigned lo = a[i] < a[l] ? a[i] : a[l], hi = a[i] < a[l] ? a[l] : a[i];
-                    a[i] = up ? lo : hi;
-                    a[l] = up ? hi : lo;
-                }
-            }
-}
-template <int N>
-__device__ __forceinline__ unsigned rz_pick(const unsigned (&a)[N], int k) {
-    unsigned r = a[0];
-#pragma unroll
-    for (int u = 1; u < N; ++u) r = k == u ? a[u] : r;
-    return r;
-}
-__device__ __forceinline__ float rz_middle(unsigned lo, unsigned hi, long long len) {       // pandas' median of a group: its middle
-    return (float)((len & 1) ? (double)lo : ((double)lo + (double)hi) / 2);                 // value, or the mean of the two
-}
-template <int N>
-__device__ __forceinline__ void rz_median_small(const unsigned *__restrict__ pay_s, long long i, int len, int nb, unsigned cell,
-                                                long long hw, float *__restrict__ raster) {
-    unsigned w[N];
-#pragma unroll
-    for (int u = 0; u < N; ++u) w[u] = u < len ? pay_s[i + u] : 0u;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        if (g >= nb) break;
-        unsigned a[N];
-#pragma unroll
-        for (int u = 0; u < N; ++u) a[u] = u < len ? ((w[u] >> (8 * g)) & 0xFFu) : 256u;
-        rz_sort_small<N>(a);
-        raster[(long long)g * hw + cell] = rz_middle(rz_pick<N>(a, (len - 1) >> 1), rz_pick<N>(a, len >> 1), len);
-    }
-}
-
-// one wave (a workgroup of 64) per 64 consecutive sorted positions: the heads among them take their runs
-__global__ __launch_bounds__(64) void rz_median_packed_kernel(const unsigned *__restrict__ cell_s, const unsigned *__restrict__ pay_s,
-                                                              long long n, int nb, long long hw, float *__restrict__ raster) {
-    __shared__ unsigned hist[4][256];
-    const int lane = (int)threadIdx.x;
-    const long long chunks = (n + 63) >> 6;
-    for (long long ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
-        const long long base = ch << 6, i = base + lane;
-        const unsigned c = i < n ? cell_s[i] : 0xFFFFFFFFu;
-        const bool head = i < n && (i == 0 || cell_s[i - 1] != c);
-        const unsigned long long heads = __ballot(head);
-        long long hi = i + 1;
-        if (head) {
-            const unsigned long long later = lane < 63 ? heads >> (lane + 1) : 0ull;
-            if (later) hi = i + 1 + __builtin_ctzll(later);           // the next head among the 64
-            else {                                                      // the run reaches the end of the 64: gallop, then bisect (rz_runs_kernel)
-                long long lo = base + 63 < n ? base + 63 : n - 1, step = 1;
-                while (lo + step < n && cell_s[lo + step] == c) { lo += step; step <<= 1; }
-                hi = lo + step < n ? lo + step : n;
-                while (hi - lo > 1) {
-                    const long long mid = lo + ((hi - lo) >> 1);
-                    if (cell_s[mid] == c) lo = mid; else hi = mid;
-                }
-            }
-        }
-        const unsigned len = head ? (unsigned)(hi - i) : 0u;
-        if (len == 1) {
-            const unsigned w = pay_s[i];
-            for (int g = 0; g < nb; ++g) raster[(long long)g * hw + c] = (float)((w >> (8 * g)) & 0xFFu);
-        } else if (len == 2) {
-            const unsigned w0 = pay_s[i], w1 = pay_s[i + 1];
-            for (int g = 0; g < nb; ++g) raster[(long long)g * hw + c] = rz_middle((w0 >> (8 * g)) & 0xFFu, (w1 >> (8 * g)) & 0xFFu, 2);
-        } else if (len > 2 && len <= 4) rz_median_small<4>(pay_s, i, (int)len, nb, c, hw, raster);
-        else if (len > 4 && len <= 8) rz_median_small<8>(pay_s, i, (int)len, nb, c, hw, raster);
-        else if (len > 8 && len <= 16) rz_median_small<16>(pay_s, i, (int)len, nb, c, hw, raster);
-        // the longer runs, one after the other, by the whole wave
-        unsigned long long longs = __ballot(len > 16u);
-        while (longs) {
-            const int src = __builtin_ctzll(longs);
-            longs &= longs - 1;
-            const long long ri = base + src;
-            const unsigned rlen = __shfl(len, src), rcell = __shfl(c, src);
-            for (int q = lane; q < nb * 256; q += 64) (&hist[0][0])[q] = 0u;
-            __syncthreads();
-            for (unsigned j = (unsigned)lane; j < rlen; j += 64u) {
-                const unsigned w = pay_s[ri + j];
-                for (int g = 0; g < nb; ++g) atomicAdd(&hist[g][(w >> (8 * g)) & 0xFFu], 1u);
-            }
-            __syncthreads();
-            for (int g = 0; g < nb; ++g) {
-                const uint4 cnt = *(const uint4 *)&hist[g][4 * lane];      // this lane's four bins
-                const unsigned sum = cnt.x + cnt.y + cnt.z + cnt.w;
-                unsigned upto = sum;                                        // inclusive prefix over the lanes
-                for (int d = 1; d < 64; d <<= 1) {
-                    const unsigned o = __shfl_up(upto, d);
-                    if (lane >= d) upto += o;
-                }
-                const unsigned before = upto - sum;
-                unsigned mid[2];
-                for (int q = 0; q < 2; ++q) {
-                    const unsigned k = q == 0 ? (rlen - 1u) >> 1 : rlen >> 1;      // the k-th smallest (from 0)
-                    unsigned v = 4u * (unsigned)lane, r = k - before;
-                    if (r >= cnt.x) { r -= cnt.x; ++v; if (r >= cnt.y) { r -= cnt.y; ++v; if (r >= cnt.z) ++v; } }
-                    mid[q] = __shfl(v, __builtin_ctzll(__ballot(before <= k && k < upto)));
-                }
-                if (lane == 0) raster[(long long)g * hw + rcell] = rz_middle(mid[0], mid[1], (long long)rlen);
-            }
-            __syncthreads();                                                // the histograms are read no more
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void rz_median_keys_kernel(const unsigned *__restrict__ cell_in, const double *__restrict__ values,
-                                                             long long n, int nb, int band, unsigned long long *__restrict__ vkey,
-                                                             unsigned *__restrict__ idx, unsigned *__restrict__ cell) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const double val = values[i * nb + band];
-        vkey[i] = d2ord(val);
-        idx[i] = (unsigned)i;
-        cell[i] = (val != val) ? 0xFFFFFFFFu : cell_in[i];      // NaN: sorts behind every pixel
-    }
-}
-
-__global__ __launch_bounds__(256) void rz_gather_cell_kernel(const unsigned *__restrict__ idx_sorted,
-                                                             const unsigned *__restrict__ cell, long long n,
-                                                             unsigned *__restrict__ cell_sorted) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        cell_sorted[i] = cell[idx_sorted[i]];
-}
-
-// runs of equal pixel in the (pixel, value)-sorted order -> median into the float32 raster
-__global__ __launch_bounds__(256) void rz_median_runs_kernel(const unsigned *__restrict__ cell_sorted,
-                                                             const unsigned *__restrict__ idx_sorted,
-                                                             const double *__restrict__ values, long long n, int nb,
-                                                             int band, float *__restrict__ raster_band) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const unsigned c = cell_sorted[i];
-        if (c == 0xFFFFFFFFu || (i > 0 && cell_sorted[i - 1] == c)) continue;      // not the head of a run
-        long long lo = i, step = 1;                            // gallop, then bisect, as above
-        while (lo + step < n && cell_sorted[lo + step] == c) { lo += step; step <<= 1; }
-        long long hi = lo + step < n ? lo + step : n;
-        while (hi - lo > 1) {
-            const long long mid = lo + ((hi - lo) >> 1);
-            if (cell_sorted[mid] == c) lo = mid; else hi = mid;
-        }
-        const long long k = hi - i;
-        const double a = values[(long long)idx_sorted[i + (k - 1) / 2] * nb + band];
-        const double b = values[(long long)idx_sorted[i + k / 2] * nb + band];
-        raster_band[c] = (float)((k & 1) ? a : (a + b) / 2);
-    }
-}
-
-__global__ __launch_bounds__(256) void rz_focal_median_kernel(const float *__restrict__ src, float *__restrict__ dst,
-                                                              int nb, int width, int height) {
-    const long long hw = (long long)width * height;
-    const long long total = hw * nb;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const float centre = src[i];
-        if (centre == centre) { dst[i] = centre; continue; }
-        const long long p = i % hw;
-        const int row = (int)(p / width), col = (int)(p - (long long)row * width);
-        const float *band = src + (i - p);
-        float w[9];
-        int have = 0;
-        for (int dr = -1; dr <= 1; ++dr)
-            for (int dc = -1; dc <= 1; ++dc) {
-                const int rr = row + dr, cc = col + dc;
-                if (rr < 0 || rr >= height || cc < 0 || cc >= width) continue;
-                const float val = band[(long long)rr * width + cc];
-                if (val != val) continue;
-                int k = have++;                                   // insertion sort of at most 9 values
-                while (k > 0 && w[k - 1] > val) { w[k] = w[k - 1]; --k; }
-                w[k] = val;
-            }
-        float out = __int_as_float(0x7fc00000);
-        if (have) out = (have & 1) ? w[have / 2] : (float)(((double)w[have / 2 - 1] + (double)w[have / 2]) / 2);
-        dst[i] = out;
-    }
-}
+// The kernels, in dependency order (one translation unit):
+#include "rasterize_runs.h"
+#include "rasterize_tail.h"
+#include "rasterize_median.h"
 
 }  // namespace alp
 
