@@ -104,6 +104,7 @@ _SIGNATURES = {
     "alp_device_info": [ctypes.c_char_p, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_i64)],
     "alp_device_pci_bus_id": [ctypes.c_char_p, _c_int],
     "alp_host_hash64": [_c_void_p, _c_i64, _c_int, ctypes.POINTER(ctypes.c_uint64)],
+    "alp_host_minmax": [_c_dp, _c_i64, _c_int, _c_dp],
     "alp_synchronize": [],
     "alp_event_record": [_c_int],
     "alp_event_elapsed_ms": [_c_int, _c_int, _c_fp],
@@ -237,6 +238,17 @@ def host_hash64(a, threads=0):
     d = ctypes.c_uint64()
     check(load().alp_host_hash64(a.ctypes.data_as(_c_void_p), a.nbytes, int(threads), ctypes.byref(d)))
     return int(d.value)
+
+
+def host_minmax(a, threads=0):
+    """(a.min(), a.max()) of a C-contiguous float64 array in one threaded pass (alp_host_minmax; NaN, NaN if any value is
+    NaN, like numpy; no device needed).  An empty array raises numpy's own error."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.size == 0:
+        return a.min(), a.max()
+    out = (ctypes.c_double * 2)()
+    check(load().alp_host_minmax(a.ctypes.data_as(_c_dp), a.size, int(threads), out))
+    return np.float64(out[0]), np.float64(out[1])
 
 
 def params_vector(params):
@@ -687,7 +699,7 @@ def rasterize_points_f32(x, y, values, resolution=1.0, interpolate=True, max_dis
     values = np.ascontiguousarray(values, dtype=np.float64)
     if values.ndim != 2 or values.shape[0] != len(x) or len(y) != len(x):
         raise ValueError("x, y (n,) and values (n, bands) expected")
-    x_min, x_max, y_min, y_max = x.min(), x.max(), y.min(), y.max()
+    (x_min, x_max), (y_min, y_max) = host_minmax(x), host_minmax(y)
     width = int(np.ceil((x_max - x_min) / resolution))
     height = int(np.ceil((y_max - y_min) / resolution))
     if width <= 0 or height <= 0:

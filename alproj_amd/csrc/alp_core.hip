@@ -306,6 +306,56 @@ int alp_host_hash64(const void *buf, int64_t bytes, int threads, uint64_t *diges
     return ALP_OK;
 }
 
+int alp_host_minmax(const double *values, int64_t n, int threads, double out[2]) {
+    ALP_REQUIRE(values && out && n >= 1, "bad argument");
+    int T = threads > 0 ? threads : (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (T > 64) T = 64;
+    const int64_t per = (int64_t)1 << 20;                        // a thread is worth starting for a million values
+    if ((int64_t)T > (n + per - 1) / per) T = (int)((n + per - 1) / per);
+    std::vector<double> lo((size_t)T, INFINITY), hi((size_t)T, -INFINITY);
+    std::vector<char> nan((size_t)T, 0);
+    auto run = [&](int t) {
+        const int64_t a = n * t / T, b = n * (t + 1) / T;
+        // eight independent chains (the compare-and-select is a dependency; the compiler turns the inner loop into vector min / max)
+        double l[8], h[8];
+        for (int k = 0; k < 8; ++k) { l[k] = INFINITY; h[k] = -INFINITY; }
+        int bad = 0;
+        int64_t i = a;
+        for (; i + 8 <= b; i += 8)
+            for (int k = 0; k < 8; ++k) {
+                const double v = values[i + k];
+                bad |= v != v;
+                l[k] = v < l[k] ? v : l[k];
+                h[k] = v > h[k] ? v : h[k];
+            }
+        for (; i < b; ++i) {
+            const double v = values[i];
+            bad |= v != v;
+            l[0] = v < l[0] ? v : l[0];
+            h[0] = v > h[0] ? v : h[0];
+        }
+        double l0 = l[0], h0 = h[0];
+        for (int k = 1; k < 8; ++k) { l0 = l[k] < l0 ? l[k] : l0; h0 = h[k] > h0 ? h[k] : h0; }
+        lo[(size_t)t] = l0;
+        hi[(size_t)t] = h0;
+        nan[(size_t)t] = (char)bad;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(run, t);
+    run(0);
+    for (auto &x : th) x.join();
+    double l = lo[0], h = hi[0];
+    bool bad = nan[0];
+    for (int t = 1; t < T; ++t) {
+        l = lo[(size_t)t] < l ? lo[(size_t)t] : l;
+        h = hi[(size_t)t] > h ? hi[(size_t)t] : h;
+        bad |= nan[(size_t)t] != 0;
+    }
+    out[0] = bad ? NAN : l;
+    out[1] = bad ? NAN : h;
+    return ALP_OK;
+}
+
 int alp_device_pci_bus_id(char *id, int len) {
     if (int rc = require_init()) return rc;
     ALP_REQUIRE(id && len >= 16, "id is NULL or shorter than 16 bytes");

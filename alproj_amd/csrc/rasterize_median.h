@@ -18,8 +18,9 @@ __device__ __forceinline__ float ord2f(unsigned o) { return __uint_as_float((o >
 // [0, 65535]; bit 2: not an integer in [0, 255] (image bytes and 16-bit samples: their composite key needs 8 / 16 value bits, three
 // / two radix passes fewer); bit 3: some value is NaN (bytes without one can ride the sort as its payload: rz_median_packed_kernel).
 // All bands in one launch: one wait of the host instead of one per band.
+// planar_n: 0 for interleaved rows (element i belongs to band i % nb), n for a table's columns as they lie (band i / n)
 __global__ __launch_bounds__(256) void rz_median_check_kernel(const double *__restrict__ values, long long count, int nb,
-                                                              unsigned *__restrict__ flag) {
+                                                              long long planar_n, unsigned *__restrict__ flag) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
         const double val = values[i];
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(256) void rz_median_check_kernel(const double *__re
             else if (val > 255.0) bad |= 4u;
         }
         if (bad) {
-            unsigned *f = flag + (int)(i % nb);
+            unsigned *f = flag + (planar_n ? (int)(i / planar_n) : (int)(i % nb));
             if ((*f & bad) != bad) atomicOr(f, bad);           // a plain look first: the word settles after a few writers
         }
     }

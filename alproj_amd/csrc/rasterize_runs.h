@@ -253,12 +253,14 @@ __global__ __launch_bounds__(256) void rz_integer_check_kernel(const double *__r
     if (bad && (threadIdx.x & 63) == 0 && (*flag & bad) != bad) atomicOr(flag, bad);
 }
 
-// byte-valued bands (nb <= 4), interleaved float64 -> one packed word per point: the sort's payload
-__global__ __launch_bounds__(256) void rz_pack_kernel(const double *__restrict__ values, long long n, int nb, unsigned *__restrict__ packed) {
+// byte-valued bands (nb <= 4) in float64 -> one packed word per point: the sort's payload.  values[i * es + b * bs]:
+// interleaved rows (es = nb, bs = 1) or a table's columns as they lie (es = 1, bs = n)
+__global__ __launch_bounds__(256) void rz_pack_kernel(const double *__restrict__ values, long long n, int nb, long long es, long long bs,
+                                                      unsigned *__restrict__ packed) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         unsigned w = 0;
-        for (int b = 0; b < nb; ++b) w |= ((unsigned)values[i * nb + b] & 0xFFu) << (8 * b);
+        for (int b = 0; b < nb; ++b) w |= ((unsigned)values[i * es + b * bs] & 0xFFu) << (8 * b);
         packed[i] = w;
     }
 }

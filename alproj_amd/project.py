@@ -454,7 +454,7 @@ def rasterize(df, resolution=1.0, bands=["R", "G", "B"], interpolate=True, max_d
             raise ValueError(f"Band '{band}' not found in DataFrame columns: {list(df.columns)}")
     x = np.ascontiguousarray(df["x"].to_numpy(dtype=np.float64))
     y = np.ascontiguousarray(df["y"].to_numpy(dtype=np.float64))
-    x_min, x_max, y_min, y_max = x.min(), x.max(), y.min(), y.max()
+    (x_min, x_max), (y_min, y_max) = _lib.host_minmax(x), _lib.host_minmax(y)      # one threaded pass each (numpy: four, 14-30 ms)
     width = int(np.ceil((x_max - x_min) / resolution))
     height = int(np.ceil((y_max - y_min) / resolution))
     if width <= 0 or height <= 0:

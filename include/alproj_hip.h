@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ALP_ABI_VERSION 4
+#define ALP_ABI_VERSION 5
 
 /* x,y,z,fov,pan,tilt,roll,a1,a2,k1..k6,p1,p2,s1..s4,w,h,cx,cy */
 #define ALP_NPARAM 25
@@ -83,6 +83,11 @@ int alp_device_pci_bus_id(char *id, int len);
  * kept on the device still equals the caller's arrays (the reference uploads on every call,
  * src/alproj/project.py:213-215, so an in-place edit between two calls must be seen). */
 int alp_host_hash64(const void *buf, int64_t bytes, int threads, uint64_t *digest);
+/* (ABI 5) out[0] = min, out[1] = max of n float64 values (n >= 1) on host threads (0: up to 8), NaN for both if any value
+ * is NaN -- numpy's `a.min()`, `a.max()` in one pass: `x.min(), x.max(), y.min(), y.max()` of to_geotiff (project.py:420-423)
+ * took 14-30 ms of numpy on one core for the 11.7 M rows of the 100 M-vertex frame's table, a multiple of the device's work.
+ * No device needed. */
+int alp_host_minmax(const double *values, int64_t n, int threads, double out[2]);
 /* Block until everything queued on the library stream is done. */
 int alp_synchronize(void);
 

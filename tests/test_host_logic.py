@@ -249,3 +249,24 @@ def test_result_memory_is_recycled_only_when_nobody_holds_it():
     finally:
         L.set_result_pool(0)
         L.set_result_pool(old_cap)
+
+
+def test_host_minmax_is_numpys_min_and_max():
+    """alp_host_minmax (to_geotiff's x.min(), x.max(), y.min(), y.max(), project.py:420-423, in one threaded pass per column):
+    numpy's values for any length and thread count, NaN for both when any value is NaN, -0.0 / +0.0 as equal as numpy has them"""
+    from alproj_amd import _lib as L
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 3, 1000, (1 << 20) + 1, 5_000_001):
+        a = rng.normal(0, 1e3, n)
+        for threads in (0, 1, 3, 16):
+            lo, hi = L.host_minmax(a, threads)
+            assert lo == a.min() and hi == a.max()
+        a[n // 2] = np.nan
+        lo, hi = L.host_minmax(a)
+        assert np.isnan(lo) and np.isnan(hi) and np.isnan(a.min())
+    lo, hi = L.host_minmax(np.array([np.inf, -np.inf, 3.0]))
+    assert lo == -np.inf and hi == np.inf
+    lo, hi = L.host_minmax(np.arange(10, dtype=np.int64)[::2])          # any dtype / stride: converted like np.asarray
+    assert (lo, hi) == (0.0, 8.0)
+    with pytest.raises(ValueError):
+        L.host_minmax(np.empty(0))
