@@ -270,3 +270,20 @@ def test_host_minmax_is_numpys_min_and_max():
     assert (lo, hi) == (0.0, 8.0)
     with pytest.raises(ValueError):
         L.host_minmax(np.empty(0))
+
+
+def test_prefault_leaves_the_buffer_usable():
+    """alp_host_prefault is advice to the kernel (huge pages + populate, four threads): whatever the kernel makes of it -- this
+    container's refuses nothing, a sandbox may -- the buffer is ordinary memory afterwards; odd addresses and sizes are fine"""
+    from alproj_amd import _lib as L
+    lib = L.load()
+    for nbytes, skew in ((0, 0), (1, 0), (4095, 1), (8192, 0), (3 << 20, 17), ((64 << 20) + 12345, 3)):
+        raw = np.empty(nbytes + 64, dtype=np.uint8)
+        view = raw[skew:skew + nbytes]
+        assert lib.alp_host_prefault(view.ctypes.data_as(L._c_void_p), nbytes, 0) == 0
+        assert lib.alp_host_prefault(view.ctypes.data_as(L._c_void_p), nbytes, 7) == 0
+        view[:] = 5
+        assert int(view.sum()) == 5 * nbytes
+    big = L.result_empty((40 << 20,), np.uint8)          # a pool miss: populated before it is handed out
+    big[:] = 1
+    assert int(big[:: 1 << 20].sum()) == 40
