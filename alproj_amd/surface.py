@@ -58,17 +58,22 @@ def colored_surface_mesh(aerial2, dsm2, transform, nodata_mask, source_dtype, co
     aerial2 = np.asarray(aerial2)[:3]
     dsm2 = np.asarray(dsm2)
     nodata_mask = np.asarray(nodata_mask, dtype=bool)
+    any_nodata = bool(nodata_mask.any())
+    all_nodata = any_nodata and bool(nodata_mask.all())
     if dsm_max_height is None:
-        dsm_max_height = dsm2[~nodata_mask].max() if (~nodata_mask).any() else 0
+        # dsm2[~nodata_mask].max() without the compacted copy of the DSM (50 ms for 6000 x 6000 cells)
+        if not any_nodata:
+            dsm_max_height = dsm2.max()
+        else:
+            dsm_max_height = 0 if all_nodata else np.max(dsm2, where=~nodata_mask, initial=-np.inf)
     if dsm2.min() < 0:
         warnings.warn("DSM still has negative elevation values. Consider using a larger fill_dsm_dist. "
                       "Negative values will be filled with 0.")
-    if nodata_mask.all():
+    if all_nodata:
         warnings.warn("All triangles were filtered out (all vertices are nodata).")
     div = color_divisor(aerial2, source_dtype, color_max)
     t = [float(transform[k]) for k in range(6)]
-    return _lib.Mesh.from_rasters(dsm2, t, float(dsm_max_height), aerial2, div,
-                                  nodata_mask if nodata_mask.any() else None)
+    return _lib.Mesh.from_rasters(dsm2, t, float(dsm_max_height), aerial2, div, nodata_mask if any_nodata else None)
 
 
 def get_colored_surface(aerial, dsm, shooting_point, distance=2000, res=1.0, resampling=None, fill_dsm_dist=300,
