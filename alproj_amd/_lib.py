@@ -32,7 +32,10 @@ DIST_KEYS = PARAM_KEYS[7:21]
 # size is written into it: a series of photographs through one camera model pays for its pages once.  The arrays behave
 # like np.empty's except for ``flags.owndata``.  set_result_pool(0) turns it off.
 _POOL_MIN = 8 << 20
-_pool_cap = 4 << 30
+try:
+    _pool_cap = min(4 << 30, os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") // 16)     # at most a sixteenth of the host's memory
+except (ValueError, OSError, AttributeError):
+    _pool_cap = 1 << 30
 _pool = {}
 _pool_bytes = 0
 _pool_lock = threading.Lock()
@@ -40,7 +43,7 @@ POOL_STATS = {"hits": 0, "misses": 0}
 
 
 def set_result_pool(cap_bytes):
-    """Keep at most ``cap_bytes`` of dropped result memory for reuse (default 4 GiB; 0: none, and what is kept is released)."""
+    """Keep at most ``cap_bytes`` of dropped result memory for reuse (default 4 GiB or a sixteenth of the host's memory, whichever is less; 0: none, and what is kept is released)."""
     global _pool_cap, _pool_bytes
     with _pool_lock:
         _pool_cap = int(cap_bytes)
