@@ -2,8 +2,9 @@
 """Development: randomised differential test of to_geotiff's compute (alp_rasterize_columns through
 alproj_amd.project.rasterize, and the device-fed ReverseProjection.rasterize) against the pandas / scipy restatement of the
 reference (oracle.ref_numpy.rasterize_points): clustered points (long runs of one raster cell inside a wave, runs across
-wave and workgroup boundaries), NaN values, 1-4 bands, all four aggregates, 0-9 focal sweeps, several resolutions.
-Byte-exact.   python3 tools/fuzz_rasterize.py [seconds] [seed]"""
+wave and workgroup boundaries), NaN values, 1-4 bands, all four aggregates, 0-9 focal sweeps, several resolutions; a third of
+the cases once more with the points as the surface pixels of a resident frame and the bands from a uint8 / uint16 / float32 /
+float64 image.  Byte-exact.   python3 tools/fuzz_rasterize.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -22,7 +23,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 99)
 L.init(0)
 warnings.simplefilter("ignore")
 t_end = time.time() + budget
-n_cases = n_f32 = 0
+n_cases = n_f32 = n_dev = 0
 names = ["R", "G", "B", "N"]
 while time.time() < t_end:
     n = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 1000, 5000, 40_000]))
@@ -82,6 +83,53 @@ while time.time() < t_end:
                   f"got {gf[tuple(bad[0])]!r} want {wf[tuple(bad[0])]!r}", flush=True)
             sys.exit(1)
         n_f32 += 1
+    if rng.random() < 0.35:         # the same points as the surface pixels of a resident frame: ReverseProjection.rasterize
+        off = np.array([732000.0, 1655.0, 4048000.0])
+        w_img = int(rng.integers(max(1, -(-n // 30000)), 60))         # (a frame is at most 32768 pixels tall)
+        h_img = -(-n // w_img) + int(rng.integers(0, 3))
+        slots = np.sort(rng.choice(w_img * h_img, n, replace=False))
+        raw = np.zeros((h_img * w_img, 3), dtype=np.float32)
+        raw[slots, 0] = np.maximum(xy[:, 0] + 10.0, 0.5).astype(np.float32)      # channel 0 > 0: the pixel sees the surface
+        raw[slots, 2] = (xy[:, 1] + 10.0).astype(np.float32)
+        raw[slots, 1] = 5.0
+        dtype = [np.uint8, np.uint8, np.uint16, np.float32, np.float64][int(rng.integers(0, 5))]
+        arr = np.zeros((h_img * w_img, nb), dtype=dtype)
+        if dtype == np.uint8:
+            arr[slots] = rng.integers(0, 256, (n, nb))
+        elif dtype == np.uint16:
+            arr[slots] = rng.integers(0, 65536, (n, nb))
+        else:
+            arr[slots] = rng.uniform(-20, 300, (n, nb))
+            if rng.random() < 0.4:
+                arr[slots[rng.integers(0, n, max(1, n // 20))], rng.integers(0, nb)] = np.nan
+        xd = raw[slots, 0].astype(np.float64) + off[0]
+        yd = raw[slots, 2].astype(np.float64) + off[2]
+        vd = arr[slots].astype(np.float64)
+        chn = names[:nb]
+        order = [chn.index(b) for b in bands]
+        try:
+            want_d, wb_d = orc.rasterize_points(xd, yd, vd[:, order], res, interp, max_dist, agg, nodata)
+        except ValueError:
+            want_d = None
+        vert = np.array([[0, 0, 0], [1, 0, 0], [0, 0, 1], [1, 0, 1]], dtype=np.float32)
+        with L.Mesh(vert, None, None, grid=(2, 2)) as m:
+            m.load_image(raw.reshape(h_img, w_img, 3))
+            rp = prj.ReverseProjection(m, off, w_img, h_img, False, None)
+            try:
+                got_d, gb_d = rp.rasterize(arr.reshape(h_img, w_img, nb), chn, resolution=res, bands=bands, interpolate=interp,
+                                           max_dist=max_dist, agg_func=agg, nodata=nodata)
+            except ValueError:
+                assert want_d is None, "the device-fed path refused what the oracle accepts"
+                got_d = None
+        if got_d is not None:
+            assert want_d is not None, "the device-fed path accepted what the oracle refuses"
+            if gb_d != wb_d or not np.array_equal(got_d, want_d):
+                bad = np.argwhere(got_d != want_d)
+                print(f"DEVICE-FED MISMATCH: n {n} nb {nb} dtype {np.dtype(dtype).name} res {res} agg {agg} interp {interp} max_dist {max_dist}: "
+                      f"{len(bad)} bytes differ, first {bad[:3].tolist()}", flush=True)
+                sys.exit(1)
+        n_dev += 1
     n_cases += 1
+print(f"fuzz_rasterize: {n_dev} of the cases also as the surface pixels of a resident frame (ReverseProjection.rasterize; uint8 / uint16 / float32 / float64 images): byte-identical")
 print(f"fuzz_rasterize: {n_cases} random cases, every raster byte-identical to the pandas / scipy restatement of the reference; "
       f"{n_f32} of them also compared as float32 rasters before the byte conversion: every bit equal")
