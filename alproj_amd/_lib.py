@@ -38,7 +38,7 @@ except (ValueError, OSError, AttributeError):
     _pool_cap = 1 << 30
 _pool = {}
 _pool_bytes = 0
-_pool_lock = threading.Lock()
+_pool_lock = threading.RLock()       # re-entrant: a garbage collection inside the locked region may run another result's finalizer
 POOL_STATS = {"hits": 0, "misses": 0}
 
 
