@@ -231,8 +231,8 @@ static int run_rasterize(int agg, const double *dx, const double *dy, const doub
         size_t t = tmp;
         e = rocprim::radix_sort_pairs<RzPairSort>(sort_tmp, t, cell, cell_s, idx, idx_s, count, 0u, cell_bits, st);
         if (e == hipSuccess) {
-            const unsigned chunks = (unsigned)std::min<long long>((n + 63) / 64, (long long)cu * 256);
-            hipLaunchKernelGGL(rz_median_packed_kernel, dim3(chunks), dim3(64), 0, st, cell_s, idx_s, n, nb, hw, ra);
+            const unsigned turns = (unsigned)std::min<long long>((n + RZ_MED_TURN - 1) / RZ_MED_TURN, (long long)cu * 256);
+            hipLaunchKernelGGL(rz_median_packed_kernel<RZ_MED_GROUPS>, dim3(turns), dim3(64), 0, st, cell_s, idx_s, n, nb, hw, ra);
             e = hipGetLastError();
         }
     } else if (e == hipSuccess) {

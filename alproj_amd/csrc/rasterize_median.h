@@ -77,8 +77,7 @@ __global__ __launch_bounds__(256) void rz_median_runs32_kernel(const unsigned lo
 
 // ---- byte-valued bands (at most four, no NaN): ONE sort by cell with the packed values as its payload (the mean's sort), then
 // the middle value(s) of every run are SELECTED from its words -- the order inside a run does not matter to a median.  A run
-// of up to 16 points (nearly all: the frame's cells hold 1.5 points on average) is sorted in the registers of the thread at
-// its head (a bitonic network over its bytes, padded with 256); a longer one (the 100 M-vertex frame: 138 000 of 1.74 M runs,
+// of up to 16 points (92 % of the frame's runs; its cells hold 6.7 points on average) is sorted in the registers of one lane (a bitonic network over its bytes, padded with 256); a longer one (the 100 M-vertex frame: 138 000 of 1.74 M runs,
 // up to 671 points, holding 46 % of the points) is taken by the whole wave: its bytes are counted into a 256-bin histogram in
 // LDS, four bins to a lane, and a prefix sum over the lanes finds the bin of the middle.  (A list of the long runs for a
 // second kernel, appended to with one atomic per run: 1.1 ms -- the 138 000 atomics on one word.)
@@ -126,49 +125,106 @@ __device__ __forceinline__ void rz_median_small(const unsigned *__restrict__ pay
     }
 }
 
-// one wave (a workgroup of 64) per 64 consecutive sorted positions: the heads among them take their runs
+// One wave (a workgroup of 64) per turn of RZ_MED_GROUPS x 64 consecutive sorted positions.  First it finds the heads of the
+// runs that start there and files them by length -- 1-2, 3-4, 5-8, 9-16, longer -- in LDS; then each file is worked through
+// with all 64 lanes on runs of one kind.  (A head per lane as the positions lie -- every seventh position of the frame is a
+// head, and a wave ran the networks of all four sizes for its nine heads -- took 0.27 ms for the frame's 11.7 M points: the
+// issue rate of the sorting networks.  Filed, and the turn's cells loaded in one go: 0.185 ms at 8 groups of 64 positions per
+// turn; 2 groups 0.237, 4 groups 0.195, 16 groups 0.226 -- fewer, longer turns leave the chip short of waves.)
+constexpr int RZ_MED_GROUPS = 8, RZ_MED_TURN = RZ_MED_GROUPS * 64;
+template <int GROUPS>
 __global__ __launch_bounds__(64) void rz_median_packed_kernel(const unsigned *__restrict__ cell_s, const unsigned *__restrict__ pay_s,
                                                               long long n, int nb, long long hw, float *__restrict__ raster) {
+    constexpr int TURN = GROUPS * 64;
     __shared__ unsigned hist[4][256];
+    // an entry: the head's offset in the turn (10 bits) | the run's length << 10 (at most 16); a file cannot hold more heads
+    // than the turn has positions / the shortest run of its kind
+    __shared__ unsigned short file0[TURN], file1[TURN / 3 + 4], file2[TURN / 5 + 4], file3[TURN / 9 + 4];
+    __shared__ unsigned long_off[TURN / 17 + 4], long_len[TURN / 17 + 4];
     const int lane = (int)threadIdx.x;
-    const long long chunks = (n + 63) >> 6;
-    for (long long ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
-        const long long base = ch << 6, i = base + lane;
-        const unsigned c = i < n ? cell_s[i] : 0xFFFFFFFFu;
-        const bool head = i < n && (i == 0 || cell_s[i - 1] != c);
-        const unsigned long long heads = __ballot(head);
-        long long hi = i + 1;
-        if (head) {
-            const unsigned long long later = lane < 63 ? heads >> (lane + 1) : 0ull;
-            if (later) hi = i + 1 + __builtin_ctzll(later);           // the next head among the 64
-            else {                                                      // the run reaches the end of the 64: gallop, then bisect (rz_runs_kernel)
-                long long lo = base + 63 < n ? base + 63 : n - 1, step = 1;
-                while (lo + step < n && cell_s[lo + step] == c) { lo += step; step <<= 1; }
-                hi = lo + step < n ? lo + step : n;
-                while (hi - lo > 1) {
-                    const long long mid = lo + ((hi - lo) >> 1);
-                    if (cell_s[mid] == c) lo = mid; else hi = mid;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const long long turns = (n + TURN - 1) / TURN;
+    for (long long turn = blockIdx.x; turn < turns; turn += gridDim.x) {
+        const long long base = turn * TURN;
+        int cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cntl = 0;          // wave-uniform
+        unsigned cc[GROUPS];                                     // the turn's cells: all loads in flight together
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            const long long i = base + g * 64 + lane;
+            cc[g] = i < n ? cell_s[i] : 0xFFFFFFFFu;
+        }
+        unsigned carry = base > 0 ? cell_s[base - 1] : 0xFFFFFFFFu;    // the cell before the group's first position
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            const long long gbase = base + g * 64, i = gbase + lane;
+            const unsigned c = cc[g];
+            unsigned prev = __shfl_up(c, 1);
+            if (lane == 0) prev = carry;
+            carry = __shfl(c, 63);
+            const bool head = i < n && (i == 0 || prev != c);
+            const unsigned long long heads = __ballot(head);
+            long long hi = i + 1;
+            if (head) {
+                const unsigned long long later = lane < 63 ? heads >> (lane + 1) : 0ull;
+                if (later) hi = i + 1 + __builtin_ctzll(later);           // the next head among the 64
+                else {                                                      // the run reaches the end of the 64: gallop, then bisect (rz_runs_kernel)
+                    long long lo = gbase + 63 < n ? gbase + 63 : n - 1, step = 1;
+                    while (lo + step < n && cell_s[lo + step] == c) { lo += step; step <<= 1; }
+                    hi = lo + step < n ? lo + step : n;
+                    while (hi - lo > 1) {
+                        const long long mid = lo + ((hi - lo) >> 1);
+                        if (cell_s[mid] == c) lo = mid; else hi = mid;
+                    }
                 }
             }
+            const unsigned len = head ? (unsigned)(hi - i) : 0u;
+            const unsigned off = (unsigned)(g * 64 + lane);
+            const unsigned short entry = (unsigned short)(off | (len << 10));      // (meaningful for len <= 16 only)
+            const unsigned long long m0 = __ballot(len >= 1u && len <= 2u), m1 = __ballot(len >= 3u && len <= 4u),
+                                     m2 = __ballot(len >= 5u && len <= 8u), m3 = __ballot(len >= 9u && len <= 16u), ml = __ballot(len > 16u);
+            if (len >= 1u && len <= 2u) file0[cnt0 + __popcll(m0 & below)] = entry;
+            else if (len >= 3u && len <= 4u) file1[cnt1 + __popcll(m1 & below)] = entry;
+            else if (len >= 5u && len <= 8u) file2[cnt2 + __popcll(m2 & below)] = entry;
+            else if (len >= 9u && len <= 16u) file3[cnt3 + __popcll(m3 & below)] = entry;
+            else if (len > 16u) {
+                const int at = cntl + __popcll(ml & below);
+                long_off[at] = off;
+                long_len[at] = len;
+            }
+            cnt0 += __popcll(m0); cnt1 += __popcll(m1); cnt2 += __popcll(m2); cnt3 += __popcll(m3); cntl += __popcll(ml);
         }
-        const unsigned len = head ? (unsigned)(hi - i) : 0u;
-        if (len == 1) {
-            const unsigned w = pay_s[i];
-            for (int g = 0; g < nb; ++g) raster[(long long)g * hw + c] = (float)((w >> (8 * g)) & 0xFFu);
-        } else if (len == 2) {
-            const unsigned w0 = pay_s[i], w1 = pay_s[i + 1];
-            for (int g = 0; g < nb; ++g) raster[(long long)g * hw + c] = rz_middle((w0 >> (8 * g)) & 0xFFu, (w1 >> (8 * g)) & 0xFFu, 2);
-        } else if (len > 2 && len <= 4) rz_median_small<4>(pay_s, i, (int)len, nb, c, hw, raster);
-        else if (len > 4 && len <= 8) rz_median_small<8>(pay_s, i, (int)len, nb, c, hw, raster);
-        else if (len > 8 && len <= 16) rz_median_small<16>(pay_s, i, (int)len, nb, c, hw, raster);
+        __syncthreads();
+        for (int h = lane; h < cnt0; h += 64) {
+            const unsigned e = file0[h], len = e >> 10;
+            const long long i = base + (e & 1023u);
+            const unsigned c = cell_s[i], w0 = pay_s[i];
+            if (len == 1u) {
+                for (int g = 0; g < nb; ++g) raster[(long long)g * hw + c] = (float)((w0 >> (8 * g)) & 0xFFu);
+            } else {
+                const unsigned w1 = pay_s[i + 1];
+                for (int g = 0; g < nb; ++g) raster[(long long)g * hw + c] = rz_middle((w0 >> (8 * g)) & 0xFFu, (w1 >> (8 * g)) & 0xFFu, 2);
+            }
+        }
+        for (int h = lane; h < cnt1; h += 64) {
+            const unsigned e = file1[h];
+            const long long i = base + (e & 1023u);
+            rz_median_small<4>(pay_s, i, (int)(e >> 10), nb, cell_s[i], hw, raster);
+        }
+        for (int h = lane; h < cnt2; h += 64) {
+            const unsigned e = file2[h];
+            const long long i = base + (e & 1023u);
+            rz_median_small<8>(pay_s, i, (int)(e >> 10), nb, cell_s[i], hw, raster);
+        }
+        for (int h = lane; h < cnt3; h += 64) {
+            const unsigned e = file3[h];
+            const long long i = base + (e & 1023u);
+            rz_median_small<16>(pay_s, i, (int)(e >> 10), nb, cell_s[i], hw, raster);
+        }
         // the longer runs, one after the other, by the whole wave
-        unsigned long long longs = __ballot(len > 16u);
-        while (longs) {
-            const int src = __builtin_ctzll(longs);
-            longs &= longs - 1;
-            const long long ri = base + src;
-            const unsigned rlen = __shfl(len, src), rcell = __shfl(c, src);
-            for (int q = lane; q < nb * 256; q += 64) (&hist[0][0])[q] = 0u;
+        for (int q = 0; q < cntl; ++q) {
+            const long long ri = base + long_off[q];
+            const unsigned rlen = long_len[q], rcell = cell_s[ri];
+            for (int k = lane; k < nb * 256; k += 64) (&hist[0][0])[k] = 0u;
             __syncthreads();
             for (unsigned j = (unsigned)lane; j < rlen; j += 64u) {
                 const unsigned w = pay_s[ri + j];
@@ -185,16 +241,17 @@ __global__ __launch_bounds__(64) void rz_median_packed_kernel(const unsigned *__
                 }
                 const unsigned before = upto - sum;
                 unsigned mid[2];
-                for (int q = 0; q < 2; ++q) {
-                    const unsigned k = q == 0 ? (rlen - 1u) >> 1 : rlen >> 1;      // the k-th smallest (from 0)
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const unsigned k = k2 == 0 ? (rlen - 1u) >> 1 : rlen >> 1;      // the k-th smallest (from 0)
                     unsigned v = 4u * (unsigned)lane, r = k - before;
                     if (r >= cnt.x) { r -= cnt.x; ++v; if (r >= cnt.y) { r -= cnt.y; ++v; if (r >= cnt.z) ++v; } }
-                    mid[q] = __shfl(v, __builtin_ctzll(__ballot(before <= k && k < upto)));
+                    mid[k2] = __shfl(v, __builtin_ctzll(__ballot(before <= k && k < upto)));
                 }
                 if (lane == 0) raster[(long long)g * hw + rcell] = rz_middle(mid[0], mid[1], (long long)rlen);
             }
             __syncthreads();                                                // the histograms are read no more
         }
+        __syncthreads();                                                    // the files are read no more
     }
 }
 
