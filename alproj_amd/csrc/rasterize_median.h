@@ -98,13 +98,6 @@ __device__ __forceinline__ void rz_sort_small(unsigned (&a)[N]) {
                 }
             }
 }
-template <int N>
-__device__ __forceinline__ unsigned rz_pick(const unsigned (&a)[N], int k) {
-    unsigned r = a[0];
-#pragma unroll
-    for (int u = 1; u < N; ++u) r = k == u ? a[u] : r;
-    return r;
-}
 __device__ __forceinline__ float rz_middle(unsigned lo, unsigned hi, long long len) {       // pandas' median of a group: its middle
     return (float)((len & 1) ? (double)lo : ((double)lo + (double)hi) / 2);                 // value, or the mean of the two
 }
@@ -114,14 +107,20 @@ __device__ __forceinline__ void rz_median_small(const unsigned *__restrict__ pay
     unsigned w[N];
 #pragma unroll
     for (int u = 0; u < N; ++u) w[u] = u < len ? pay_s[i + u] : 0u;
+    // The N - len places the run does not fill are padded HALF below every byte (0), half above (257; the bytes themselves
+    // count from 1): floor((N - len) / 2) pads sort in front of the run's values, so its middle lands on places N / 2 - 1 and
+    // N / 2 of the network's output whatever len is -- an odd run's median is place N / 2 - 1, an even run's the mean of the
+    // two.  (Padding behind only, and picking places (len - 1) / 2 and len / 2: the compiler kept the sorted array in scratch
+    // memory to index it, 80 bytes per lane.)
+    const int low = (N - len) >> 1;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         if (g >= nb) break;
         unsigned a[N];
 #pragma unroll
-        for (int u = 0; u < N; ++u) a[u] = u < len ? ((w[u] >> (8 * g)) & 0xFFu) : 256u;
+        for (int u = 0; u < N; ++u) a[u] = u < len ? ((w[u] >> (8 * g)) & 0xFFu) + 1u : (u - len < low ? 0u : 257u);
         rz_sort_small<N>(a);
-        raster[(long long)g * hw + cell] = rz_middle(rz_pick<N>(a, (len - 1) >> 1), rz_pick<N>(a, len >> 1), len);
+        raster[(long long)g * hw + cell] = rz_middle(a[N / 2 - 1] - 1u, a[N / 2] - 1u, len);
     }
 }
 
@@ -241,6 +240,7 @@ __global__ __launch_bounds__(64) void rz_median_packed_kernel(const unsigned *__
                 }
                 const unsigned before = upto - sum;
                 unsigned mid[2];
+#pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) {
                     const unsigned k = k2 == 0 ? (rlen - 1u) >> 1 : rlen >> 1;      // the k-th smallest (from 0)
                     unsigned v = 4u * (unsigned)lane, r = k - before;
