@@ -37,3 +37,21 @@ def test_oracle_matches_reference_on_a_million_float_points():
         raster, bounds = orc.rasterize_points(df["x"].to_numpy(), df["y"].to_numpy(), df[["R", "G", "B"]].to_numpy(), **FLOAT_CASES["float_mean"])
     np.testing.assert_array_equal(raster, g["float_mean_raster"])
     np.testing.assert_array_equal(np.array(bounds[:4]), g["float_mean_bounds"])
+
+
+def test_oracle_matches_reference_on_a_million_byte_points():
+    """g18 (gen_golden_geotiff_bytes.py): the reference's to_geotiff on a million clustered byte-valued points -- its own use, a
+    photograph's uint8 bands; the oracle's minimum of two bands with three sweeps and nodata 0 byte for byte (the whole fixture is held against
+    the device path, tests/test_gpu_rasterize.py)"""
+    from tests.rasterize_cases import BYTE_CASES, byte_points
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g18_geotiff_bytes.npz"), allow_pickle=False)
+    df = byte_points()
+    assert len(df) == int(g["n_points"])
+    kw = dict(BYTE_CASES["byte_min_gb"])
+    bands = kw.pop("bands")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        raster, bounds = orc.rasterize_points(df["x"].to_numpy(), df["y"].to_numpy(), df[bands].to_numpy(), kw["resolution"], True,
+                                              kw["max_dist"], kw["agg_func"], kw["nodata"])
+    np.testing.assert_array_equal(raster, g["byte_min_gb_raster"])
+    np.testing.assert_array_equal(np.array(bounds[:4]), g["byte_min_gb_bounds"])
