@@ -421,7 +421,8 @@ int alp_rasterize_points_f32(const double *x, const double *y, const double *val
                              int agg, int sweeps, float *out);
 /* The same with the band values as nb separate columns (columns[b][i]: each n contiguous doubles -- how a DataFrame keeps
  * them, so that to_geotiff(df) hands its columns over without the transposed copy df[bands].to_numpy() makes, ~100 ms for
- * 16 M rows x 3 bands); the interleaving happens on the device. */
+ * 16 M rows x 3 bands); byte-valued columns (a photograph's bands, at most four) are packed into the sort's payload as they lie,
+ * any others interleaved on the device. */
 int alp_rasterize_columns(const double *x, const double *y, const double *const *columns, int64_t n, int64_t nb,
                           double x_min, double y_max, double resolution, int64_t width, int64_t height,
                           int agg, int sweeps, int nodata, uint8_t *out);
