@@ -211,7 +211,7 @@ static int run_rasterize(int agg, const double *dx, const double *dy, const doub
         e = rocprim::radix_sort_pairs<RzPairSort>(sort_tmp, t, cell, cell_s, idx, idx_s, count, 0u, cell_bits, st);      // stable: a run keeps the rows' order
         if (e == hipSuccess) {
             RzPiece *first = (RzPiece *)key, *last = first + (size_t)nseg * nb;
-            const unsigned gs = grid(nseg);
+            const unsigned gs = (unsigned)((nseg + 255) / 256);          // a thread per segment (at most 2^31 / 16 / 256 workgroups); the dispatcher evens them out
 #define ALP_RZ_PIECES(A)                                                                                                                  \
     do {                                                                                                                                  \
         if (packed) hipLaunchKernelGGL((rz_pieces_kernel<A, true>), dim3(gs), dim3(256), 0, st, cell_s, idx_s, dv, n, nb, hw, ra, first, last); \
