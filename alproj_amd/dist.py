@@ -11,8 +11,10 @@ same losses on every rank -> same trajectory).
 The 128-byte RCCL unique id has to travel from rank 0 to the others once; this module takes
 it over whatever control plane the launcher provides:
 
-* ``init_from_torch()``  -- a ``torch.distributed`` process group (torchrun); plumbing only,
-* ``init_from_file(path)`` -- a file on a shared filesystem (no torch needed),
+* ``init_comm(rank, world, bcast_bytes)`` -- any callable that hands rank 0's bytes to every rank
+  (``alproj_amd.launch.Control.bcast_bytes`` is what ``bench.py`` passes; ``examples/rendezvous_over_process_group.py``
+  shows the same over a process group a foreign launcher already made),
+* ``init_from_file(path)`` -- a file on a shared filesystem,
 
 The reduction contract itself (``combine_partials``) is plain numpy so that it can be tested
 on CPU with the gloo backend (tests/test_dist_gloo.py).
@@ -71,23 +73,6 @@ def init_comm(rank, world_size, bcast_bytes, device=None):
     uid = _lib.comm_unique_id() if rank == 0 else b"\0" * _lib.UNIQUE_ID_BYTES
     uid = bcast_bytes(uid)
     _lib.comm_init(uid, rank, world_size)
-
-
-def init_from_torch(device=None):
-    """Use an already initialised torch.distributed process group as the control plane."""
-    import torch
-    import torch.distributed as dist
-    rank, world = dist.get_rank(), dist.get_world_size()
-
-    def bcast(b):
-        t = torch.tensor(list(b), dtype=torch.uint8)
-        if dist.get_backend() == "nccl":
-            t = t.cuda()
-        dist.broadcast(t, src=0)
-        return bytes(t.cpu().tolist())
-
-    init_comm(rank, world, bcast, device)
-    return rank, world
 
 
 def init_from_file(path, rank, world_size, device=None, timeout_s=120.0):

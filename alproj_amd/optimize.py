@@ -16,7 +16,10 @@ here                          reference                                device en
 ============================  =======================================  ======================
 
 Extra keyword arguments (all optional, defaults keep the reference behaviour):
-``precision`` ("f32" | "f64") selects the element type of the device-resident point set,
+``precision`` (None | "f32" | "f64") selects the element type of the device-resident point set
+-- None, the default, is the reference's own float64 arithmetic (optimize.py:329-357) for every
+point set of up to ``F64_MAX_POINTS`` = 4 M points (any GCP-scale use of the reference: float64
+costs nothing there) and float32 (20 B/vertex, ~1e-3 px) for DSM-sized sets above it;
 ``seed`` makes the CMA-ES trajectory reproducible.  There is no CPU fallback: without the
 HIP library / a GPU every function that touches points raises ``AlprojHipError``.
 """
@@ -83,6 +86,20 @@ def _uv_array(img_points):
 # ------------------------------------------------------------------------------------------
 # projection and losses
 # ------------------------------------------------------------------------------------------
+F64_MAX_POINTS = 4_000_000
+
+
+def default_precision(n_points, precision=None):
+    """The element type of a device-resident point set when the caller names none: the reference's float64
+    (optimize.py:139-154, 329-357) up to F64_MAX_POINTS points, float32 above (DSM-sized sets, where the float64
+    population kernel costs 3 x the float32 one and the set 2 x the HBM)."""
+    if precision is not None:
+        if precision not in ("f32", "f64"):
+            raise ValueError("precision must be None, 'f32' or 'f64'")
+        return precision
+    return "f64" if int(n_points) <= F64_MAX_POINTS else "f32"
+
+
 def project(obj_points, params, precision="f64"):
     """3D -> 2D perspective projection of ``obj_points`` (DataFrame with x, y, z) with the
     camera ``params``; returns a DataFrame with columns u, v (reference optimize.py:122-155).
@@ -168,8 +185,9 @@ class BaseOptimizer:
         self.target_params_init = np.array([self.params_init[t] for t in target_params])
 
     # -- device-resident copy of the GCPs, shared by both optimisers -------------------------
-    def _device_points(self, precision):
-        pts = _lib.Points(_xyz_array(self.obj_points), _camera_origin(self.params_init), precision)
+    def _device_points(self, precision=None):
+        xyz = _xyz_array(self.obj_points)
+        pts = _lib.Points(xyz, _camera_origin(self.params_init), default_precision(len(xyz), precision))
         pts.set_observed(_uv_array(self.img_points))
         return pts
 
@@ -199,7 +217,7 @@ class CMAOptimizer(BaseOptimizer):
     several GPUs, one RCCL all-reduce of the per-candidate sums).
     """
 
-    def _loss_function(self, bounds, f_scale=None, precision="f32"):
+    def _loss_function(self, bounds, f_scale=None, precision=None):
         """Population loss closure: X (P, D) in [0,1] -> (losses (P,), argmin).  Vectorised
         counterpart of the reference's per-candidate ``_proj_error`` (optimize.py:347-356)."""
         lower, upper = bounds[:, 0], bounds[:, 1]
@@ -216,28 +234,32 @@ class CMAOptimizer(BaseOptimizer):
         return _proj_error
 
     def optimize(self, sigma=0.2, bound_widths=None, generation=1000, population_size=10,
-                 n_max_resampling=100, f_scale=None, precision="f32", seed=None, progress=True):
+                 n_max_resampling=100, f_scale=None, precision=None, seed=None, progress=True):
         """Run CMA-ES; returns ``(params, error)`` like the reference: the best candidate of
-        the LAST generation (optimize.py:427, quirk Q9) and its mean reprojection distance."""
+        the LAST generation (optimize.py:427, quirk Q9) and its mean reprojection distance.
+        ``precision=None``: float64 like the reference up to F64_MAX_POINTS points (per rank), float32 above."""
         bounds = bounds_to_array(self.params_init, self.target_params, bound_widths)
         lower, upper = bounds[:, 0], bounds[:, 1]
         normalized_init = (self.target_params_init - lower) / (upper - lower)
         d = len(self.target_params)
         normalized_bounds = np.column_stack([np.zeros(d), np.ones(d)])
 
+        # Several ranks (one process per GPU, vertices sharded): every population evaluation
+        # all-reduces the per-candidate sums, so every rank MUST evaluate the same candidates.
+        # The reference seeds nothing (optimize.py:410-416); here rank 0's seed (its own entropy
+        # when seed is None) and, every generation, rank 0's candidate matrix are broadcast.
+        # Rank 0's element type travels with the seed: the float64 confirmation of near-tied float32
+        # losses is a collective of its own, so shards on either side of F64_MAX_POINTS must not differ.
+        precision = default_precision(len(self.obj_points), precision)
+        _, world = _lib.comm_info()
+        if world > 1:
+            s = np.array([np.random.SeedSequence().entropy % (1 << 63) if seed is None else int(seed),
+                          precision == "f64"], dtype=np.uint64)
+            _lib.comm_bcast(s, root=0)
+            seed, precision = int(s[0]), ("f64" if s[1] else "f32")
         loss_function = self._loss_function(bounds, f_scale, precision)
         pts = loss_function.points
         try:
-            # Several ranks (one process per GPU, vertices sharded): every population evaluation
-            # all-reduces the per-candidate sums, so every rank MUST evaluate the same candidates.
-            # The reference seeds nothing (optimize.py:410-416); here rank 0's seed (its own entropy
-            # when seed is None) and, every generation, rank 0's candidate matrix are broadcast.
-            _, world = _lib.comm_info()
-            if world > 1:
-                s = np.array([np.random.SeedSequence().entropy % (1 << 63) if seed is None else int(seed)],
-                             dtype=np.uint64)
-                _lib.comm_bcast(s, root=0)
-                seed = int(s[0])
             optimizer = CMA(mean=normalized_init.astype("float64"), sigma=float(sigma),
                             bounds=normalized_bounds, population_size=population_size,
                             n_max_resampling=n_max_resampling, seed=seed,
@@ -272,7 +294,7 @@ class CMAOptimizer(BaseOptimizer):
             pts.close()
         return params, float(err[0])
 
-    F64_FINAL_MAX_POINTS = 4_000_000
+    F64_FINAL_MAX_POINTS = F64_MAX_POINTS
 
 
 class LsqOptimizer(BaseOptimizer):

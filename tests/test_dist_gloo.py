@@ -185,7 +185,7 @@ def test_optimisers_multi_rank_branches_stay_in_lockstep(tmp_path, world):
             assert float(r[tag + "_err"]) == float(res[0][tag + "_err"])
     assert res[0]["cma_X"].shape == (20, 12, 9)
     # the order of collectives every rank went through: seed, then (candidates, evaluation) x 20, then the final error
-    expect = ["('bcast', 'uint64', (1,))"] + ["('bcast', 'float64', (12, 9))", "('eval', 12)"] * 20 + ["('eval', 1)"]
+    expect = ["('bcast', 'uint64', (2,))"] + ["('bcast', 'float64', (12, 9))", "('eval', 12)"] * 20 + ["('eval', 1)"]
     for r in res:
         assert list(r["cma_log"]) == expect
         log = list(r["lsq_log"])

@@ -461,6 +461,40 @@ def test_cma_optimizer_recovers_pose(L):
     assert err == pytest.approx(ref, rel=1e-5)
 
 
+def test_cma_optimizer_default_is_float64_at_gcp_scale(L):
+    """optimize(precision=None) on a g5-sized point set: the loss closure the optimiser itself builds holds a float64
+    point set and reproduces the reference's float64 losses (g5) to 1e-9; a set above F64_MAX_POINTS is float32."""
+    from alproj_amd import optimize as opt
+    g = load("g5_population.npz")
+    init = orc.vector_to_params(g["params_init"])
+    o = opt.CMAOptimizer(pd.DataFrame(g["xyz"], columns=["x", "y", "z"]), pd.DataFrame(g["uv_obs"], columns=["u", "v"]), init)
+    for tag in ("d9", "d12", "d21"):
+        o.set_target([str(t) for t in g[f"{tag}_targets"]])
+        for key, fs in (("hub", 10.0), ("md", None)):
+            f = o._loss_function(g[f"{tag}_bounds"], f_scale=fs)             # precision left to the default
+            try:
+                assert f.points.precision == L.ALP_F64
+                losses, amin = f(g[f"{tag}_X"])
+                np.testing.assert_allclose(losses, g[f"{tag}_{key}"], rtol=1e-9)
+                assert amin == int(np.argmin(g[f"{tag}_{key}"]))
+            finally:
+                f.points.close()
+    # the optimiser run itself, default precision: the reported error is the float64 mean distance of the returned pose
+    o.set_target(["pan", "tilt"])
+    params, err = o.optimize(generation=5, population_size=8, seed=2, progress=False)
+    ref = orc.mean_distance(g["uv_obs"], orc.project_points(g["xyz"], params))
+    assert err == pytest.approx(ref, rel=1e-9)
+    # DSM-sized: float32 (the threshold lowered instead of allocating 4 M points)
+    saved = opt.F64_MAX_POINTS
+    opt.F64_MAX_POINTS = 100
+    try:
+        f = o._loss_function(g["d9_bounds"][:2], f_scale=10.0)
+        assert f.points.precision == L.ALP_F32
+        f.points.close()
+    finally:
+        opt.F64_MAX_POINTS = saved
+
+
 def test_lsq_optimizer(L):
     from alproj_amd import optimize as opt
     from alproj_amd import synthetic as syn

@@ -78,6 +78,52 @@ def test_set_target_and_candidate_matrix():
     assert set(res) == set(init) and res["w"] == init["w"]
 
 
+def test_default_precision_is_the_references_float64_at_gcp_scale(monkeypatch):
+    """CMAOptimizer.optimize(precision=None): a float64 point set up to F64_MAX_POINTS points (the reference's arithmetic,
+    optimize.py:329-357), float32 above; an explicit choice is kept.  The device is a recorder here: no GPU."""
+    from alproj_amd import _lib
+    assert opt.default_precision(1127) == "f64" and opt.default_precision(opt.F64_MAX_POINTS) == "f64"
+    assert opt.default_precision(opt.F64_MAX_POINTS + 1) == "f32" and opt.default_precision(100_000_000) == "f32"
+    assert opt.default_precision(100_000_000, "f64") == "f64" and opt.default_precision(10, "f32") == "f32"
+    with pytest.raises(ValueError):
+        opt.default_precision(10, "f16")
+    made = []
+
+    class Recorder:
+        def __init__(self, xyz, origin, precision="f32"):
+            made.append((len(xyz), precision))
+            self.precision, self.n = (_lib.ALP_F64 if precision == "f64" else _lib.ALP_F32), len(xyz)
+
+        def set_observed(self, uv):
+            pass
+
+        def eval_population(self, cand, kind, f_scale, want_argmin=True):
+            return np.arange(len(cand), dtype=np.float64), 0
+
+        def close(self):
+            pass
+
+        __enter__ = lambda self: self
+        __exit__ = lambda self, *a: None
+
+    monkeypatch.setattr(_lib, "Points", Recorder)
+    monkeypatch.setattr(_lib, "comm_info", lambda: (0, 1))
+    g = load("g5_population.npz")
+    init = orc.vector_to_params(g["params_init"])
+    o = opt.CMAOptimizer(pd.DataFrame(g["xyz"], columns=["x", "y", "z"]), pd.DataFrame(g["uv_obs"], columns=["u", "v"]), init)
+    o.set_target(["pan", "tilt"])
+    o.optimize(generation=2, population_size=4, progress=False, seed=1)
+    assert made == [(len(g["xyz"]), "f64")]
+    del made[:]
+    o.optimize(generation=2, population_size=4, progress=False, seed=1, precision="f32")
+    assert made == [(len(g["xyz"]), "f32"), (len(g["xyz"]), "f64")]       # explicit float32; the final error from a float64 copy
+    del made[:]
+    monkeypatch.setattr(opt, "F64_MAX_POINTS", 100)                        # a "DSM-sized" set without allocating one
+    monkeypatch.setattr(opt.CMAOptimizer, "F64_FINAL_MAX_POINTS", 100)
+    o.optimize(generation=2, population_size=4, progress=False, seed=1)
+    assert made == [(len(g["xyz"]), "f32")]
+
+
 def test_lsq_argument_errors_need_no_gpu():
     o = opt.LsqOptimizer(pd.DataFrame(np.zeros((3, 3)), columns=["x", "y", "z"]),
                          pd.DataFrame(np.zeros((3, 2)), columns=["u", "v"]), {k: 1.0 for k in orc.PARAM_KEYS})
