@@ -30,34 +30,84 @@ DIST_KEYS = PARAM_KEYS[7:21]
 # kernel hands them out one fault at a time -- against 56 GB/s into pages that exist (tools/d2h_rate.hip).  So the memory of
 # a result the caller has dropped (the array AND every view of it) is kept, up to a cap, and the next result of the same
 # size is written into it: a series of photographs through one camera model pays for its pages once.  The arrays behave
-# like np.empty's except for ``flags.owndata``.  set_result_pool(0) turns it off.
+# like np.empty's except for ``flags.owndata`` -- and, like np.empty's, they hold whatever bytes were there before (a previous
+# result's): the library overwrites the whole array.  Kept buffers are resident memory (pre-faulted): clear_result_pool()
+# gives them back, set_result_pool(0) turns the pool off.
 _POOL_MIN = 8 << 20
 try:
     _pool_cap = min(4 << 30, os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") // 16)     # at most a sixteenth of the host's memory
 except (ValueError, OSError, AttributeError):
     _pool_cap = 1 << 30
-_pool = {}
+_POOL_PER_SIZE = 2                  # a result and the one before it; more of one size is a leak, not a cache
+_pool = {}                           # nbytes -> [backing, ...] (newest last)
+_pool_age = []                       # (nbytes, id(backing)) in the order they came back: eviction takes the oldest first
 _pool_bytes = 0
 _pool_lock = threading.RLock()       # re-entrant: a garbage collection inside the locked region may run another result's finalizer
-POOL_STATS = {"hits": 0, "misses": 0}
+POOL_STATS = {"hits": 0, "misses": 0, "evicted": 0}
+
+
+def _pool_drop_oldest(spare_size=None):
+    """forget the buffer that has waited longest (of another size than ``spare_size`` if there is one); False when none is left"""
+    global _pool_bytes
+    pick = next((i for i, (nb, _) in enumerate(_pool_age) if nb != spare_size), 0 if _pool_age else None)
+    if pick is None:
+        return False
+    nb, ident = _pool_age.pop(pick)
+    bufs = _pool.get(nb, [])
+    for j, b in enumerate(bufs):
+        if id(b) == ident:
+            del bufs[j]
+            break
+    if not bufs:
+        _pool.pop(nb, None)
+    _pool_bytes -= nb
+    POOL_STATS["evicted"] += 1
+    return True
+
+
+def clear_result_pool():
+    """Give back every kept buffer now (they are pre-faulted, so each counts in full against the process's resident set:
+    up to the cap -- 4 GiB by default -- for as long as it is kept).  Results still held by the caller are not touched."""
+    global _pool_bytes
+    with _pool_lock:
+        _pool.clear()
+        del _pool_age[:]
+        _pool_bytes = 0
 
 
 def set_result_pool(cap_bytes):
-    """Keep at most ``cap_bytes`` of dropped result memory for reuse (default 4 GiB or a sixteenth of the host's memory, whichever is less; 0: none, and what is kept is released)."""
-    global _pool_cap, _pool_bytes
+    """Keep at most ``cap_bytes`` of dropped result memory for reuse (default 4 GiB or a sixteenth of the host's memory,
+    whichever is less; 0: none).  What is kept beyond a new, smaller cap is released, oldest first.  Kept memory is
+    resident memory: see clear_result_pool()."""
+    global _pool_cap
     with _pool_lock:
         _pool_cap = int(cap_bytes)
-        if _pool_bytes > _pool_cap:
-            _pool.clear()
-            _pool_bytes = 0
+        while _pool_bytes > _pool_cap and _pool_drop_oldest():
+            pass
 
 
 def _pool_release(backing):
+    """A result's memory comes back.  It is the newest entry; to make room under the cap the oldest buffers go first --
+    those of OTHER sizes before its own (a workload that changed its raster size must not keep the old size's buffers
+    resident for ever and recycle nothing) -- and no size keeps more than _POOL_PER_SIZE."""
     global _pool_bytes
+    nb = backing.nbytes
     with _pool_lock:
-        if _pool_bytes + backing.nbytes <= _pool_cap:
-            _pool.setdefault(backing.nbytes, []).append(backing)
-            _pool_bytes += backing.nbytes
+        if nb > _pool_cap:
+            return
+        same = _pool.get(nb, [])
+        while len(same) >= _POOL_PER_SIZE:
+            ident = id(same.pop(0))
+            _pool_age[:] = [e for e in _pool_age if e != (nb, ident)]
+            _pool_bytes -= nb
+            POOL_STATS["evicted"] += 1
+        while _pool_bytes + nb > _pool_cap and _pool_drop_oldest(spare_size=nb):
+            pass
+        while _pool_bytes + nb > _pool_cap and _pool_drop_oldest():
+            pass
+        _pool.setdefault(nb, []).append(backing)
+        _pool_age.append((nb, id(backing)))
+        _pool_bytes += nb
 
 
 def _prefault(a):
@@ -84,6 +134,9 @@ def result_empty(shape, dtype):
         free = _pool.get(nbytes)
         backing = free.pop() if free else None
         if backing is not None:
+            _pool_age[:] = [e for e in _pool_age if e != (nbytes, id(backing))]
+            if not free:
+                _pool.pop(nbytes, None)
             _pool_bytes -= nbytes
             POOL_STATS["hits"] += 1
         else:

@@ -6,13 +6,14 @@
 #include <sys/mman.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
 namespace alp {
 
 // ------------------------------------------------------------------ errors
-static thread_local char g_err[512] = "";
+static thread_local char g_err[2048] = "";
 
 void set_error(const char *fmt, ...) {
     va_list ap;
@@ -83,8 +84,9 @@ void ktime_end() {
     do {                                                                                  \
         ncclResult_t r__ = (expr);                                                        \
         if (r__ != ncclSuccess)                                                           \
-            return ::alp::fail(ALP_ERCCL, "%s failed: %s (%s:%d)", #expr,                 \
-                               ncclGetErrorString(r__), __FILE__, __LINE__);              \
+            return ::alp::fail(ALP_ERCCL, "%s failed: %s | RCCL says: %s (%s:%d)", #expr, \
+                               ncclGetErrorString(r__), ncclGetLastError(nullptr),        \
+                               __FILE__, __LINE__);                                       \
     } while (0)
 
 int comm_allreduce_sum_f64(double *dev_buf, int64_t count) {
@@ -462,7 +464,23 @@ int alp_comm_init(const char id[ALP_UNIQUE_ID_BYTES], int rank, int world_size) 
     memcpy(&uid, id, sizeof(uid));
     ncclComm_t comm;
     ALP_HIP(hipSetDevice(c.device));
-    ALP_NCCL(ncclCommInitRank(&comm, world_size, uid, rank));
+    const ncclResult_t r = ncclCommInitRank(&comm, world_size, uid, rank);
+    if (r != ncclSuccess) {
+        // The first contact of N ranks happens on a machine nobody may be watching: say everything RCCL knows and everything
+        // about this rank that decides whether its peers can reach it (device, bus, the variables RCCL / ROCr read).
+        char bus[32] = "?";
+        hipDeviceGetPCIBusId(bus, (int)sizeof(bus), c.device);
+        auto env = [](const char *k) { const char *v = getenv(k); return v ? v : "(unset)"; };
+        const char *last = ncclGetLastError(nullptr);
+        return fail(ALP_ERCCL,
+                    "ncclCommInitRank failed: %s | RCCL says: %s | rank %d of %d on HIP device %d (pci %s) | "
+                    "NCCL_DEBUG=%s HSA_ENABLE_IPC_MODE_LEGACY=%s HIP_VISIBLE_DEVICES=%s ROCR_VISIBLE_DEVICES=%s NCCL_SOCKET_IFNAME=%s | "
+                    "hints: NCCL_DEBUG=INFO prints RCCL's own log; every rank needs a DIFFERENT device and the SAME 128-byte id; "
+                    "hosts whose driver only supports dmabuf IPC need HSA_ENABLE_IPC_MODE_LEGACY=0 (hipIpcGetMemHandle: invalid argument otherwise)",
+                    ncclGetErrorString(r), (last && *last) ? last : "(no further text)", rank, world_size, c.device, bus,
+                    env("NCCL_DEBUG"), env("HSA_ENABLE_IPC_MODE_LEGACY"), env("HIP_VISIBLE_DEVICES"), env("ROCR_VISIBLE_DEVICES"),
+                    env("NCCL_SOCKET_IFNAME"));
+    }
     c.comm = (void *)comm;
     c.rank = rank;
     c.world = world_size;

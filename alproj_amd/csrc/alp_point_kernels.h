@@ -21,6 +21,8 @@ template <> struct Num<float> {
     static __device__ __forceinline__ float rcp(float a) { return __builtin_amdgcn_rcpf(a); }
     static __device__ __forceinline__ float sqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
     static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+    static __device__ __forceinline__ float rcp_pop(float a) { return rcp(a); }
+    static __device__ __forceinline__ float sqrt_pop(float a) { return sqrt(a); }
     // streaming (non-temporal) 16-byte accesses: data touched once per pass
     typedef float native4 __attribute__((ext_vector_type(4)));
     static __device__ __forceinline__ float4 nt_load(const float4 *p) {
@@ -61,6 +63,28 @@ template <> struct Num<double> {
         return __builtin_amdgcn_class(a, 0x260) ? a : g;       // 0x260: -0, +0, +inf
     }
     static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+    // The population kernel's forms (K2 is bound by float64 instruction issue, K1 / K3 by HBM and PCIe: those keep the forms
+    // above and their bit patterns).  rcp_pop: the special operands (0, inf, NaN) are put right by ONE v_div_fixup_f64 instead
+    // of a compare and two selects; POP_F64_NEWTON = 1 drops the second Newton step (relative error 2^-52 + rounding instead of
+    // ~2^-53: measured against the fixtures in profiles/r05_popeval_f64_isa_census.txt).  sqrt_pop: the refinement of h is
+    // dropped -- the correction term (a - g^2) h is itself of relative size 2^-52, so h's 2^-26 error moves the result by 2^-78.
+#ifndef POP_F64_NEWTON
+#define POP_F64_NEWTON 2
+#endif
+    static __device__ __forceinline__ double rcp_pop(double a) {
+        const double y0 = __builtin_amdgcn_rcp(a);
+        double y = __builtin_fma(y0, __builtin_fma(-a, y0, 1.0), y0);
+        if (POP_F64_NEWTON >= 2) y = __builtin_fma(y, __builtin_fma(-a, y, 1.0), y);
+        return __builtin_amdgcn_div_fixup(y, a, 1.0);
+    }
+    static __device__ __forceinline__ double sqrt_pop(double a) {
+        const double y = __builtin_amdgcn_rsq(a);
+        double g = a * y;
+        const double h = 0.5 * y;
+        g = __builtin_fma(g, __builtin_fma(-h, g, 0.5), g);
+        g = __builtin_fma(__builtin_fma(-g, g, a), h, g);
+        return __builtin_amdgcn_class(a, 0x260) ? a : g;       // 0x260: -0, +0, +inf
+    }
     typedef double native2 __attribute__((ext_vector_type(2)));
     static __device__ __forceinline__ double2 nt_load(const double2 *p) {
         const native2 t = __builtin_nontemporal_load(reinterpret_cast<const native2 *>(p));
@@ -200,9 +224,22 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     v += dpp_f<0x143, 0xc>(v);   // row_bcast31 into rows 2 and 3 -> lane 63: total
     return v;
 }
+// float64: the same butterfly with the two halves of the value moved by a DPP mov each (gfx950 has no 64-bit DPP add);
+// until round 4 six __shfl_xor steps = twelve ds_bpermute_b32 through the LDS crossbar per candidate and group
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double wave_sum_to_lane63(double v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    v += dpp_d<0xB1, 0xf>(v);
+    v += dpp_d<0x4E, 0xf>(v);
+    v += dpp_d<0x141, 0xf>(v);
+    v += dpp_d<0x140, 0xf>(v);
+    v += dpp_d<0x142, 0xa>(v);
+    v += dpp_d<0x143, 0xc>(v);
     return v;
 }
 
@@ -247,10 +284,31 @@ template <typename T> struct PopCfg;
 #define POP_TC 128
 #endif
 template <> struct PopCfg<float> : PopCfgT<float, POP_V, POP_TC, POP_MINW> {};
+// float64, 100 M x 2048 Huber after round 5's instruction trims (tools/sweep_popeval_f64.sh, ms): V=3 564 | V=4 546 | V=5 541
+// (156 VGPRs, still 3 waves per SIMD) | V=4 with TC=64 564; stripes per CU at V=5: 3: 548 | 4: 541 | 6: 534 | 12: 531 | 24: 527 | 48: 525
 #ifndef POP_VD
-#define POP_VD 3
+#define POP_VD 5
 #endif
-template <> struct PopCfg<double> : PopCfgT<double, POP_VD, 128, 1> {};
+#ifndef POP_TCD
+#define POP_TCD 128
+#endif
+#ifndef POP_MINWD
+#define POP_MINWD 1
+#endif
+template <> struct PopCfg<double> : PopCfgT<double, POP_VD, POP_TCD, POP_MINWD> {};
+// float64 forms of the evaluation (round 5; each measured on its own, profiles/r05_popeval_f64_isa_census.txt)
+#ifndef POP_F64_SHARED_RCP
+#define POP_F64_SHARED_RCP 1
+#endif
+#ifndef POP_F64_HORNER
+#define POP_F64_HORNER 1
+#endif
+#ifndef POP_F64_HUBER_MIN
+#define POP_F64_HUBER_MIN 1
+#endif
+#ifndef POP_F64_Q2
+#define POP_F64_Q2 1
+#endif
 
 // Sum of the losses of V points against one pose record r (wave-uniform).  uoc/voc are the
 // observed pixels minus the image centre (c0, c1 are the same for every candidate of a call:
@@ -281,7 +339,7 @@ __device__ __forceinline__ void norm_coords(const T *r, const T (&qx)[V], const 
         o.y1[j] = N::fma(r[4], qx[j], N::fma(r[5], qy[j], N::fma(r[6], qz[j], r[7])));
     }
 #pragma unroll
-    for (int j = 0; j < V; ++j) zc[j] = N::rcp(zc[j]);
+    for (int j = 0; j < V; ++j) zc[j] = N::rcp_pop(zc[j]);
 #pragma unroll
     for (int j = 0; j < V; ++j) {
         o.x1[j] *= zc[j];
@@ -289,8 +347,8 @@ __device__ __forceinline__ void norm_coords(const T *r, const T (&qx)[V], const 
         o.xx[j] = o.x1[j] * o.x1[j];
         o.yy[j] = o.y1[j] * o.y1[j];
         o.r2[j] = o.xx[j] + o.yy[j];
-        if constexpr (sizeof(T) == 8) {            // Q2: the reference squares sqrt(x^2+y^2)
-            const T rr = N::sqrt(o.r2[j]);
+        if constexpr (sizeof(T) == 8 && POP_F64_Q2) {            // Q2: the reference squares sqrt(x^2+y^2)
+            const T rr = N::sqrt_pop(o.r2[j]);
             o.r2[j] = rr * rr;
         }
     }
@@ -325,15 +383,16 @@ __device__ __forceinline__ T group_loss_sum(const T *r, const T (&qx)[V], const 
     }
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-        if constexpr (sizeof(T) == 4) {
-            // one quarter-rate reciprocal for both denominators: 1/dx = dy / (dx dy), 1/dy = dx / (dx dy)
-            const T inv = N::rcp(dx[j] * dy[j]);
+        if constexpr (sizeof(T) == 4 || POP_F64_SHARED_RCP) {
+            // one reciprocal for both denominators: 1/dx = dy / (dx dy), 1/dy = dx / (dx dy)  (float32: a quarter-rate
+            // v_rcp_f32 saved; float64: 3 multiplies instead of a second v_rcp_f64 + Newton steps + fix-up)
+            const T inv = N::rcp_pop(dx[j] * dy[j]);
             const T idx = dy[j] * inv;
             dy[j] = dx[j] * inv;
             dx[j] = idx;
         } else {
-            dx[j] = N::rcp(dx[j]);
-            dy[j] = N::rcp(dy[j]);
+            dx[j] = N::rcp_pop(dx[j]);
+            dy[j] = N::rcp_pop(dy[j]);
         }
     }
 #pragma unroll
@@ -341,7 +400,7 @@ __device__ __forceinline__ T group_loss_sum(const T *r, const T (&qx)[V], const 
         // x1_d = x1 num/den + 2 p1 x y + 2 p2 r2 x^2 + r2 (s1 + s2 r2)   (optimize.py:112-116, Q1)
         const T t1 = r[20] * (x1[j] * y1[j]);             // 2 p1 x y       (shared by x and y)
         T a, b;
-        if constexpr (sizeof(T) == 4) {
+        if constexpr (sizeof(T) == 4 || POP_F64_HORNER) {
             // r2 (2 p2 x^2 + s1 + s2 r2) + t1: one multiply fewer per coordinate pair
             a = N::fma(r2[j], N::fma(r[21], xx[j], N::fma(r[23], r2[j], r[22])), t1);
             b = N::fma(r2[j], N::fma(r[21], yy[j], N::fma(r[25], r2[j], r[24])), t1);
@@ -360,17 +419,18 @@ __device__ __forceinline__ T group_loss_sum(const T *r, const T (&qx)[V], const 
         d2[j] = N::fma(dv, dv, du * du);
     }
 #pragma unroll
-    for (int j = 0; j < V; ++j) dist[j] = N::sqrt(d2[j]);
+    for (int j = 0; j < V; ++j) dist[j] = N::sqrt_pop(d2[j]);
     T acc = 0;
 #pragma unroll
     for (int j = 0; j < V; ++j) {
         if constexpr (LOSS == ALP_LOSS_MEAN_DIST) {
             acc += (MASKED && !ok[j]) ? (T)0 : dist[j];                                  // optimize.py:176
-        } else if constexpr (sizeof(T) == 4) {
+        } else if constexpr (sizeof(T) == 4 || POP_F64_HUBER_MIN) {
             // Huber (optimize.py:207-211) without a branch: with c = min(r, f),
             // 0.5 c (2r - c) = 0.5 r^2 for r <= f and f (r - 0.5 f) beyond; a NaN r gives c = f and
             // a NaN term, an infinite r an infinite term, like np.where
-            const T c = __builtin_fminf(dist[j], f_scale);
+            // (float64: min, two fma instead of two multiplies, an fma, a compare, two selects and an add)
+            const T c = sizeof(T) == 4 ? (T)__builtin_fminf((float)dist[j], (float)f_scale) : (T)__builtin_fmin((double)dist[j], (double)f_scale);
             const T t = N::fma((T)2, dist[j], -c);
             if (MASKED && !ok[j]) continue;
             acc = N::fma(c, t, acc);                      // twice the loss: halved once below (exact: a power of two)
@@ -381,7 +441,7 @@ __device__ __forceinline__ T group_loss_sum(const T *r, const T (&qx)[V], const 
             acc += (MASKED && !ok[j]) ? (T)0 : ((dist[j] <= f_scale) ? quad : lin);
         }
     }
-    if constexpr (LOSS != ALP_LOSS_MEAN_DIST && sizeof(T) == 4) acc *= (T)0.5;      // one multiply per V evaluations instead of one each
+    if constexpr (LOSS != ALP_LOSS_MEAN_DIST && (sizeof(T) == 4 || POP_F64_HUBER_MIN)) acc *= (T)0.5;      // one multiply per V evaluations instead of one each
     return acc;
 }
 

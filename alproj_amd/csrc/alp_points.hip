@@ -18,6 +18,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "alp_point_kernels.h"
@@ -188,8 +190,8 @@ int enqueue_popeval(alp_points *p, const double *cand, int64_t P, int loss_kind,
     // workgroups per CU: a stripe is re-read once per tile of 128 candidates and a short one stays
     // in cache between those passes.  Measured, 100 M x 2048 float32: 4 workgroups per CU 244 ms,
     // 8: 229, 16: 224, 32: 221, 64: 219, 128: 219; 10 M x 256: 8 per CU (stripes of 19 rows) 3.31
-    // ms, 16: 3.46, 32: 3.73.  float64 keeps 4 per CU.
-    int nblk = ctx().cu_count * 4;
+    // ms, 16: 3.46, 32: 3.73.  float64 (three workgroups resident per CU): 24 per CU (round 5: 527 ms against 541 with 4).
+    int nblk = ctx().cu_count * (sizeof(T) == 8 ? 24 : 4);
     int ytiles = 1;
     const int64_t rows = (p->n + 255) / 256;
     if (sizeof(T) == 4) {
@@ -219,10 +221,11 @@ int enqueue_popeval(alp_points *p, const double *cand, int64_t P, int loss_kind,
                 ytiles = tiles;
             }
         }
-        if (const char *e = getenv("ALP_POP_GRID")) {           // tuning hook: "stripes,ytiles" (any value gives the same losses)
-            int a = 0, b = 0;
-            if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && b >= 1 && b <= tiles) { nblk = a; ytiles = b; }
-        }
+    }
+    if (const char *e = getenv("ALP_POP_GRID")) {           // tuning hook: "stripes,ytiles" (float32: any value gives the same losses)
+        const int tiles = (int)((P + PopCfg<T>::TC - 1) / PopCfg<T>::TC);
+        int a = 0, b = 0;
+        if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && b >= 1 && b <= tiles) { nblk = a; ytiles = b; }
     }
     if (rows < nblk) nblk = (int)(rows > 0 ? rows : 1);
     if (int rc = ensure_pop_scratch(p, P, nblk)) return rc;
@@ -334,6 +337,98 @@ int residuals_impl(alp_points *p, const double *cand, int64_t B, double *out) {
 
 }  // namespace
 
+// ---- fetch with a change of element type (float32 set -> float64 arrays, the reference's type; or the reverse)
+// The planes are converted ON THE HOST while they arrive: a chunk crosses PCIe in its stored type (a float32 set moves 4 bytes
+// per value, not 8) into one of two pinned staging buffers, and host threads widen / narrow the previous chunk into the
+// caller's array meanwhile -- the copy engine and the host cores overlap, nothing of the size of the result is allocated.
+// The reverse (a float64 set fetched as float32) is cast on the device into the scratch area first, so that again the narrow
+// type crosses PCIe.  ALP_FETCH_CONVERT=host|device forces either way (tests, tools/probe_fetch.py).
+namespace {
+constexpr int64_t FETCH_CHUNK = (int64_t)8 << 20;         // values per chunk: 32 MB of float32, 64 MB of float64
+void *g_fetch_stage[2] = {nullptr, nullptr};               // pinned, FETCH_CHUNK * 8 bytes each; lives until the process ends
+hipEvent_t g_fetch_ev[2] = {nullptr, nullptr};
+
+template <typename S, typename D>
+void convert_slice(const S *__restrict__ src, D *__restrict__ dst, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) __builtin_nontemporal_store((D)src[i], dst + i);     // the result is not read back here
+}
+
+template <typename S, typename D>
+void convert_threads(const S *src, D *dst, int64_t n, int T) {
+    if (T <= 1 || n < (1 << 16)) return convert_slice(src, dst, n);
+    std::vector<std::thread> th;
+    const int64_t per = ((n + T - 1) / T + 15) & ~(int64_t)15;
+    for (int t = 1; t < T; ++t) {
+        const int64_t a = std::min(n, per * t), b = std::min(n, per * (t + 1));
+        if (b > a) th.emplace_back([=] { convert_slice(src + a, dst + a, b - a); });
+    }
+    convert_slice(src, dst, std::min(n, per));
+    for (auto &x : th) x.join();
+}
+
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void cast_plane_kernel(const S *__restrict__ src, D *__restrict__ dst, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (D)src[i];
+}
+
+int fetch_threads() {
+    if (const char *e = getenv("ALP_HOST_THREADS")) return std::max(1, std::min(64, atoi(e)));
+    return (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+}
+
+template <typename S, typename D>
+int fetch_converted_t(alp_points *p, D *u_out, D *v_out) {
+    hipStream_t st = ctx().stream;
+    const S *planes[2] = {(const S *)p->u, (const S *)p->v};
+    D *outs[2] = {u_out, v_out};
+    // the NARROWER type crosses PCIe: widening happens on the host (measured, 100 M points: 17 ms against 30 ms through the device
+    // cast and 14 ms for the plain float32 fetch), narrowing on the device (15 ms against 33 ms; the plain float64 fetch: 28 ms)
+    const char *mode = getenv("ALP_FETCH_CONVERT");
+    const bool on_device = mode ? !strcmp(mode, "device") : sizeof(D) < sizeof(S);
+    if (on_device) {
+        D *tmp = nullptr;
+        if (int rc = scratch_reserve((size_t)FETCH_CHUNK * sizeof(D), (void **)&tmp)) return rc;
+        for (int pl = 0; pl < 2; ++pl)
+            for (int64_t off = 0; off < p->n; off += FETCH_CHUNK) {
+                const int64_t cnt = std::min(FETCH_CHUNK, p->n - off);
+                hipLaunchKernelGGL((cast_plane_kernel<S, D>), dim3(stream_grid(cnt)), dim3(256), 0, st, planes[pl] + off, tmp, (long long)cnt);
+                ALP_HIP(hipMemcpyAsync(outs[pl] + off, tmp, (size_t)cnt * sizeof(D), hipMemcpyDeviceToHost, st));   // in stream order: the next cast waits
+            }
+        ALP_HIP(hipStreamSynchronize(st));
+        return ALP_OK;
+    }
+    for (auto &b : g_fetch_stage)
+        if (!b) ALP_HIP(hipHostMalloc(&b, (size_t)FETCH_CHUNK * 8, hipHostMallocDefault));
+    const int T = fetch_threads();
+    for (auto &e : g_fetch_ev)
+        if (!e) ALP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipEvent_t *ev = g_fetch_ev;
+    struct Job { int pl; int64_t off, cnt; };
+    std::vector<Job> jobs;
+    for (int pl = 0; pl < 2; ++pl)
+        for (int64_t off = 0; off < p->n; off += FETCH_CHUNK) jobs.push_back({pl, off, std::min(FETCH_CHUNK, p->n - off)});
+    for (size_t k = 0; k <= jobs.size(); ++k) {
+        if (k < jobs.size()) {       // chunk k is on its way into stage[k & 1] (chunk k - 2, its last user, was converted in round k - 1)
+            const Job &j = jobs[k];
+            ALP_HIP(hipMemcpyAsync(g_fetch_stage[k & 1], planes[j.pl] + j.off, (size_t)j.cnt * sizeof(S), hipMemcpyDeviceToHost, st));
+            ALP_HIP(hipEventRecord(ev[k & 1], st));
+        }
+        if (k > 0) {                 // ... while the host cores convert chunk k - 1
+            const Job &j = jobs[k - 1];
+            ALP_HIP(hipEventSynchronize(ev[(k - 1) & 1]));
+            convert_threads((const S *)g_fetch_stage[(k - 1) & 1], outs[j.pl] + j.off, j.cnt, T);
+        }
+    }
+    return ALP_OK;
+}
+
+int fetch_converted(alp_points *p, void *u_out, void *v_out, int out_dtype) {
+    return out_dtype == ALP_F64 ? fetch_converted_t<float, double>(p, (double *)u_out, (double *)v_out)
+                                : fetch_converted_t<double, float>(p, (float *)u_out, (float *)v_out);
+}
+}  // namespace
+
 extern "C" {
 
 int alp_points_create(const void *xyz, int in_dtype, int64_t n, const double origin[3], int precision,
@@ -427,25 +522,7 @@ int alp_projected_fetch(alp_points_t *p, void *u_out, void *v_out, int out_dtype
         ALP_HIP(hipStreamSynchronize(ctx().stream));
         return ALP_OK;
     }
-    std::vector<char> tmp((size_t)p->n * es * 2);
-    ALP_HIP(hipMemcpyAsync(tmp.data(), p->u, (size_t)p->n * es, hipMemcpyDeviceToHost, ctx().stream));
-    ALP_HIP(hipMemcpyAsync(tmp.data() + (size_t)p->n * es, p->v, (size_t)p->n * es, hipMemcpyDeviceToHost,
-                           ctx().stream));
-    ALP_HIP(hipStreamSynchronize(ctx().stream));
-    if (out_dtype == ALP_F64) {
-        const float *s = (const float *)tmp.data();
-        for (int64_t i = 0; i < p->n; ++i) {
-            ((double *)u_out)[i] = s[i];
-            ((double *)v_out)[i] = s[p->n + i];
-        }
-    } else {
-        const double *s = (const double *)tmp.data();
-        for (int64_t i = 0; i < p->n; ++i) {
-            ((float *)u_out)[i] = (float)s[i];
-            ((float *)v_out)[i] = (float)s[p->n + i];
-        }
-    }
-    return ALP_OK;
+    return fetch_converted(p, u_out, v_out, out_dtype);
 }
 
 int alp_projected_fetch_strided(alp_points_t *p, int64_t first, int64_t stride, int64_t count,

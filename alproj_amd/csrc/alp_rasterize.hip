@@ -137,7 +137,7 @@ static int rz_look_at(int agg, const double *values, long long n, int nb, bool p
         ALP_HIP(hipStreamSynchronize(st));
     } else if (rz_pieces_fit(agg, n, nb) && (agg == AGG_MEAN || nb <= 4)) {
         ALP_HIP(hipMemsetAsync(flags_dev, 0, sizeof(unsigned), st));
-        hipLaunchKernelGGL(rz_integer_check_kernel, dim3(grid), dim3(256), 0, st, values, count, flags_dev);
+        hipLaunchKernelGGL(rz_integer_check_kernel, dim3(grid), dim3(256), 0, st, values, count, rz_integer_limit(n), flags_dev);
         ALP_HIP(hipMemcpyAsync(&look->kind, flags_dev, sizeof(unsigned), hipMemcpyDeviceToHost, st));
         ALP_HIP(hipStreamSynchronize(st));
     }

@@ -135,7 +135,7 @@ template <int GROUPS>
 __global__ __launch_bounds__(64) void rz_median_packed_kernel(const unsigned *__restrict__ cell_s, const unsigned *__restrict__ pay_s,
                                                               long long n, int nb, long long hw, float *__restrict__ raster) {
     constexpr int TURN = GROUPS * 64;
-    __shared__ unsigned hist[4][256];
+    __shared__ __attribute__((aligned(16))) unsigned hist[4][256];       // read back as uint4 (ds_read_b128) by the long-run median
     // an entry: the head's offset in the turn (10 bits) | the run's length << 10 (at most 16); a file cannot hold more heads
     // than the turn has positions / the shortest run of its kind
     __shared__ unsigned short file0[TURN], file1[TURN / 3 + 4], file2[TURN / 5 + 4], file3[TURN / 9 + 4];

@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256) void rz_runs_kernel(const unsigned *__restrict
 
 // ---- order-free aggregates in parallel pieces
 // max / min never depend on the order, and neither does the mean of INTEGER-valued bands (image bytes in float64 columns:
-// Kahan's compensation stays exactly 0 and every partial sum below 2^53 is exact).  Then a run need not be walked by one
+// Kahan's compensation stays exactly 0 and every partial sum below 2^53 is exact: rz_integer_check_kernel bounds the values by
+// min(2^31, 2^53 / n), n = the longest run there can be).  Then a run need not be walked by one
 // thread -- next to the camera thousands of camera pixels share a cell, and the longest run alone set the kernel's time
 // (1.1 ms of 2.2 for the 100 M-vertex frame).  rz_pieces_kernel: a thread per RZ_SEG consecutive sorted positions walks them,
 // finishes the runs that lie inside and leaves (sum, count) of the at most two pieces that cross its borders;
@@ -237,16 +238,22 @@ __global__ __launch_bounds__(256) void rz_join_kernel(const unsigned *__restrict
     }
 }
 
-// what do the bands hold?  flag bit 0: some value is not an integer of magnitude below 2^31; bit 1: some value is not a byte
-// (an integer in [0, 255]; NaN is not a byte either: a packed value has no way to say "skip me")
-__global__ __launch_bounds__(256) void rz_integer_check_kernel(const double *__restrict__ values, long long count,
+// what do the bands hold?  flag bit 0: some value is not an integer of magnitude below `limit`; bit 1: some value is not a byte
+// (an integer in [0, 255]; NaN is not a byte either: a packed value has no way to say "skip me").  `limit` is what makes the
+// order-free mean exact: a run is at most n points long, so with |v| < limit = min(2^31, 2^53 / n) every partial sum of
+// every run stays below 2^53 (rz_integer_limit)
+__host__ __device__ inline double rz_integer_limit(long long n) {
+    const double by_run = 9007199254740992.0 / (double)(n < 1 ? 1 : n);
+    return by_run < 2147483648.0 ? by_run : 2147483648.0;
+}
+__global__ __launch_bounds__(256) void rz_integer_check_kernel(const double *__restrict__ values, long long count, double limit,
                                                                unsigned *__restrict__ flag) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     unsigned bad = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
         const double v = values[i];
         if (v != v) { bad |= 2u; continue; }
-        if (!(fabs(v) < 2147483648.0 && v == (double)(long long)v)) bad |= 3u;
+        if (!(fabs(v) < limit && v == (double)(long long)v)) bad |= 3u;
         else if (!(v >= 0.0 && v <= 255.0)) bad |= 2u;
     }
     for (int m = 32; m >= 1; m >>= 1) bad |= (unsigned)__shfl_xor((int)bad, m, 64);

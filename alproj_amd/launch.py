@@ -4,23 +4,30 @@ The data path of a multi-GPU job has exactly one collective -- the RCCL all-redu
 sums inside libalproj_hip.so (the loop it shards is reference optimize.py:418-424).
 Everything else a job needs between its ranks is control traffic: the 128-byte RCCL unique id from rank 0
 to the others, barriers around timed regions, a max over the ranks' wall times, a few gathered records.
-This module carries that over a localhost socket (``multiprocessing.connection``: stdlib, authenticated),
+This module carries that over a localhost socket (``multiprocessing.connection``: stdlib; HMAC challenge on a
+16-byte random key; messages are JSON bytes -- nothing received is ever unpickled),
 so that neither the product nor ``bench.py`` needs ``torch.distributed``:
 
 * ``spawn(argv, n)``   -- the PARENT: starts ``n`` fresh children of ``argv`` with ``RANK`` / ``LOCAL_RANK`` /
   ``WORLD_SIZE`` set, serves the hub, ends the others when one child fails, enforces one wall-clock limit.
   The parent never touches the GPU and never ``exec``s: children are ``subprocess.Popen``-ed before any HIP call.
 * ``Control.from_env()`` -- a RANK: connects to the parent's hub (``ALPROJ_HUB``), or, when another launcher
-  (``torch.distributed.run``) set ``WORLD_SIZE``, to a hub that rank 0 hosts and announces through a file
-  keyed by ``MASTER_ADDR`` / ``MASTER_PORT`` / the launcher's run id.
+  (``torch.distributed.run``) set ``WORLD_SIZE``, to a hub that rank 0 hosts and announces -- address AND a random
+  key -- through a 0600 file in a directory only this user can enter (``$XDG_RUNTIME_DIR`` or a 0700 directory under
+  the temporary directory, owner and mode checked), named after ``MASTER_ADDR`` / ``MASTER_PORT`` / the run id.
+* ``gpu_nodes()`` / ``preflight(n)`` -- how many GPUs the node has, from sysfs (no HIP call), so that ``spawn`` is not
+  asked for more ranks than there are devices.
 
 A collective is one message per rank to the hub and one reply per rank: barrier, max, bcast (rank 0's
 payload), gather (every rank's payload, in rank order).  A rank that dies closes its socket; the hub then
 answers every other rank with an error, so nobody waits for a barrier that cannot complete.
 """
+import glob
 import hashlib
+import json
 import os
 import signal
+import stat
 import subprocess
 import sys
 import tempfile
@@ -28,7 +35,7 @@ import threading
 import time
 from multiprocessing.connection import Client, Listener
 
-__all__ = ["Hub", "Control", "spawn", "LaunchError"]
+__all__ = ["Hub", "Control", "spawn", "LaunchError", "gpu_nodes", "preflight"]
 
 HUB_ENV, KEY_ENV = "ALPROJ_HUB", "ALPROJ_HUB_KEY"
 COLLECTIVE_TIMEOUT_S = 3600.0
@@ -36,6 +43,49 @@ COLLECTIVE_TIMEOUT_S = 3600.0
 
 class LaunchError(RuntimeError):
     pass
+
+
+# ---------------------------------------------------------------------------------------------- wire format
+# One message = one JSON document sent with send_bytes(): [op, payload] to the hub, [status, payload] back.  Payloads are
+# None, numbers, strings, bytes (the RCCL id; carried as {"__bytes__": hex}), and lists / dicts of those.  Connection.send()
+# would pickle -- and recv() unpickle whatever a peer that knows the key sends; this format cannot carry code.
+def _enc(o):
+    if isinstance(o, (bytes, bytearray)):
+        return {"__bytes__": bytes(o).hex()}
+    if isinstance(o, dict):
+        return {str(k): _enc(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_enc(v) for v in o]
+    if o is None or isinstance(o, (bool, int, float, str)):
+        return o
+    if hasattr(o, "item") and getattr(o, "shape", None) == ():      # a numpy scalar
+        return o.item()
+    raise TypeError(f"control-plane payloads are JSON values and bytes, not {type(o).__name__}")
+
+
+def _dec(o):
+    if isinstance(o, dict):
+        if set(o) == {"__bytes__"}:
+            return bytes.fromhex(o["__bytes__"])
+        return {k: _dec(v) for k, v in o.items()}
+    if isinstance(o, list):
+        return [_dec(v) for v in o]
+    return o
+
+
+def _send(conn, op, payload=None):
+    conn.send_bytes(json.dumps([op, _enc(payload)]).encode())
+
+
+def _recv(conn):
+    """-> (op, payload); a malformed message is a LaunchError, never an object"""
+    try:
+        op, payload = json.loads(conn.recv_bytes(1 << 26).decode())
+    except (ValueError, UnicodeDecodeError) as e:
+        raise LaunchError(f"malformed control message ({e})") from e
+    if not isinstance(op, str):
+        raise LaunchError("malformed control message (no op)")
+    return op, _dec(payload)
 
 
 class Hub:
@@ -76,19 +126,19 @@ class Hub:
                 pass
             for _ in range(self.world):
                 c = self.listener.accept()
-                op, rank = c.recv()
-                if op != "hello" or not (0 <= rank < self.world) or conns[rank] is not None:
+                op, rank = _recv(c)
+                if op != "hello" or not isinstance(rank, int) or not (0 <= rank < self.world) or conns[rank] is not None:
                     raise LaunchError(f"unexpected greeting {op!r} from rank {rank!r}")
                 conns[rank] = c
             for c in conns:
-                c.send(("ok", self.world))
+                _send(c, "ok", self.world)
             alive = self.world
             while alive:
                 msgs = []
                 for r, c in enumerate(conns):
                     if not c.poll(COLLECTIVE_TIMEOUT_S):
                         raise LaunchError(f"rank {r} did not reach collective {self.collectives} within {COLLECTIVE_TIMEOUT_S:.0f} s")
-                    msgs.append(c.recv())              # EOFError when the rank has gone away
+                    msgs.append(_recv(c))              # EOFError when the rank has gone away
                 ops = {m[0] for m in msgs}
                 if len(ops) != 1:
                     raise LaunchError(f"ranks disagree on collective {self.collectives}: {sorted(ops)}")
@@ -97,7 +147,7 @@ class Hub:
                 if op == "barrier":
                     out = [None] * self.world
                 elif op == "max":
-                    out = [max(payloads)] * self.world
+                    out = [max(float(x) for x in payloads)] * self.world
                 elif op == "bcast":
                     out = [payloads[0]] * self.world
                 elif op == "gather":
@@ -108,14 +158,14 @@ class Hub:
                 else:
                     raise LaunchError(f"unknown collective {op!r}")
                 for c, o in zip(conns, out):
-                    c.send(("ok", o))
+                    _send(c, "ok", o)
                 self.collectives += 1
-        except (EOFError, OSError, LaunchError) as e:
+        except (EOFError, OSError, LaunchError, TypeError, ValueError) as e:
             self.error = f"{type(e).__name__}: {e}" if str(e) else f"{type(e).__name__}: a rank closed its connection"
             for c in conns:
                 if c is not None:
                     try:
-                        c.send(("error", self.error))
+                        _send(c, "error", self.error)
                     except (OSError, ValueError):
                         pass
         finally:
@@ -128,11 +178,63 @@ class Hub:
             self.close()
 
 
+def _private_dir():
+    """A directory only this user can enter: $XDG_RUNTIME_DIR when it is one, else <tmp>/alproj_<uid> made 0700.  An
+    existing directory is accepted only if it is a real directory (not a symlink), owned by this user, with no access
+    for anybody else -- in a sticky /tmp somebody else may have made a directory of that name first."""
+    uid = os.getuid()
+    cands = [os.environ.get("XDG_RUNTIME_DIR"), os.path.join(tempfile.gettempdir(), f"alproj_{uid}")]
+    problems = []
+    for d in cands:
+        if not d:
+            continue
+        try:
+            os.mkdir(d, 0o700)
+        except FileExistsError:
+            pass
+        except OSError as e:
+            problems.append(f"{d}: {e}")
+            continue
+        try:
+            st = os.lstat(d)
+        except OSError as e:
+            problems.append(f"{d}: {e}")
+            continue
+        if stat.S_ISDIR(st.st_mode) and st.st_uid == uid and not (st.st_mode & 0o077):
+            return d
+        problems.append(f"{d}: not a private directory of uid {uid} (mode {stat.S_IMODE(st.st_mode):o}, owner {st.st_uid})")
+    raise LaunchError("no private directory for the hub announcement: " + "; ".join(problems))
+
+
 def _rendezvous_file():
-    """Where rank 0 announces its hub when a foreign launcher started the ranks: one name per job on this node."""
+    """Where rank 0 announces its hub when a foreign launcher started the ranks: one name per job on this node, inside
+    the private directory.  The name is public knowledge (MASTER_ADDR / MASTER_PORT / run id); the KEY is not derived
+    from it -- rank 0 draws it and it travels inside the file."""
     tag = "|".join(os.environ.get(k, "") for k in ("MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "GROUP_RANK"))
-    h = hashlib.sha256(tag.encode()).hexdigest()[:20]
-    return os.path.join(tempfile.gettempdir(), f"alproj_hub_{os.getuid()}_{h}"), hashlib.sha256(("key|" + tag).encode()).digest()[:16]
+    return os.path.join(_private_dir(), "hub_" + hashlib.sha256(tag.encode()).hexdigest()[:20])
+
+
+def _announce(path, address, key):
+    """rank 0: publish address and key.  A stale file of an earlier job is removed first (it lives in a directory nobody
+    else can write to); the new one is created exclusively, never through a symlink, readable by this user only."""
+    try:
+        os.unlink(path)
+    except FileNotFoundError:
+        pass
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+    with os.fdopen(fd, "w") as f:
+        json.dump({"host": address[0], "port": address[1], "key": key.hex()}, f)
+
+
+def _read_announcement(path):
+    """a rank: ((host, port), key) from rank 0's file -- only if the file is a regular file of this user with mode 0600"""
+    fd = os.open(path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))        # FileNotFoundError until rank 0 has written it
+    with os.fdopen(fd) as f:
+        st = os.fstat(f.fileno())
+        if not stat.S_ISREG(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise LaunchError(f"{path}: not a private file of uid {os.getuid()}")
+        d = json.load(f)
+    return (str(d["host"]), int(d["port"])), bytes.fromhex(d["key"])
 
 
 class Control:
@@ -155,34 +257,26 @@ class Control:
             address, key = (host, int(port)), bytes.fromhex(os.environ[KEY_ENV])
             conn = cls._connect(lambda: (address, key), rank, connect_timeout_s)
         else:                                           # started by torch.distributed.run or the like
-            path, key = _rendezvous_file()
+            path = _rendezvous_file()
             if rank == 0:
-                hub = Hub(world, authkey=key).start()
-                tmp = f"{path}.tmp.{os.getpid()}"
-                with open(tmp, "w") as f:
-                    f.write(f"{hub.address[0]}:{hub.address[1]}")
-                os.replace(tmp, path)
+                hub = Hub(world).start()                # a fresh 16-byte random key
+                _announce(path, hub.address, hub.authkey)
                 announce = path
-
-            def where():
-                with open(path) as f:                   # FileNotFoundError until rank 0 has written it
-                    host, port = f.read().strip().rsplit(":", 1)
-                return (host, int(port)), key
-            conn = cls._connect(where, rank, connect_timeout_s)
+            conn = cls._connect(lambda: _read_announcement(path), rank, connect_timeout_s)
         return cls(rank, world, local_rank, conn, hub, announce)
 
     @staticmethod
     def _connect(where, rank, timeout_s):
-        """A stale announcement (an earlier job with the same MASTER_PORT) points at a closed port or at somebody who
-        fails the key handshake: both are retried until rank 0's new announcement is there."""
+        """A stale announcement (an earlier job with the same MASTER_PORT) points at a closed port or carries a key the
+        listener there does not share: both are retried until rank 0's new announcement is there."""
         t0 = time.time()
         last = None
         while time.time() - t0 < timeout_s:
             try:
                 address, key = where()
                 conn = Client(address, authkey=key)
-                conn.send(("hello", rank))
-                status, _ = conn.recv()
+                _send(conn, "hello", rank)
+                status, _ = _recv(conn)
                 if status == "ok":
                     return conn
                 last = LaunchError("hub refused the greeting")
@@ -195,8 +289,8 @@ class Control:
         if self.world <= 1:
             return {"barrier": None, "max": payload, "bcast": payload, "gather": [payload], "bye": None}[op]
         try:
-            self._conn.send((op, payload))
-            status, out = self._conn.recv()
+            _send(self._conn, op, payload)
+            status, out = _recv(self._conn)
         except (EOFError, OSError) as e:
             raise LaunchError(f"rank {self.rank}: the hub went away during {op} ({type(e).__name__})") from e
         if status != "ok":
@@ -275,6 +369,58 @@ def _stop(procs, grace_s=5.0):
             pass
 
 
+KFD_NODES = "/sys/class/kfd/kfd/topology/nodes"
+KFD_ENV = "ALPROJ_KFD_TOPOLOGY"          # another root for the same tree (tests)
+
+
+def gpu_nodes(root=None):
+    """GPUs of this node as the kernel driver lists them -- KFD topology nodes with ``simd_count > 0`` (CPUs are nodes
+    with none) -- read from sysfs: no HIP call, so the launcher stays a process that never initialised the GPU.
+    Returns (count, what was read); count is None when the tree is absent (no amdgpu driver, or not Linux)."""
+    root = root or os.environ.get(KFD_ENV) or KFD_NODES
+    files = sorted(glob.glob(os.path.join(root, "*", "properties")))
+    if not files:
+        return None, root
+    n = 0
+    for f in files:
+        try:
+            for line in open(f):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+        except (OSError, ValueError):
+            continue
+    return n, root
+
+
+def _visible_limit(env):
+    """devices left by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES (None: no restriction)"""
+    lim = None
+    for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = env.get(k)
+        if v is not None:
+            c = len([x for x in v.split(",") if x.strip() != ""])
+            lim = c if lim is None else min(lim, c)
+    return lim
+
+
+def preflight(n, env=None, log=sys.stderr, root=None):
+    """True when ``n`` ranks can each have a GPU of their own.  Says in ONE line what is wrong otherwise."""
+    env = os.environ if env is None else env
+    have, where = gpu_nodes(root)
+    if have is None:
+        print(f"launch: no GPU on this node: {where} has no topology nodes (is the amdgpu driver loaded?); --gpus {n} needs {n}",
+              file=log, flush=True)
+        return False
+    lim = _visible_limit(env)
+    usable = have if lim is None else min(have, lim)
+    if usable < n:
+        why = f"{have} GPU node(s) under {where}" + (f", {lim} left by *_VISIBLE_DEVICES" if lim is not None and lim < have else "")
+        print(f"launch: --gpus {n} but this node offers {usable}: {why}; nothing was started", file=log, flush=True)
+        return False
+    return True
+
+
 def spawn(argv, n, timeout_s=3600.0, env=None, log=sys.stderr):
     """Run ``n`` ranks of ``argv`` and return the job's exit code: 0 when every rank returned 0; the first failing
     rank's code (the others are ended) otherwise; 124 when ``timeout_s`` of wall clock ran out.
@@ -286,8 +432,15 @@ def spawn(argv, n, timeout_s=3600.0, env=None, log=sys.stderr):
         raise ValueError("need at least one rank")
     hub = Hub(n)
     base = dict(os.environ if env is None else env)
-    base.update({"WORLD_SIZE": str(n), HUB_ENV: f"{hub.address[0]}:{hub.address[1]}", KEY_ENV: hub.authkey.hex(),
-                 "HSA_ENABLE_IPC_MODE_LEGACY": base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})    # dmabuf IPC: RCCL needs it on this driver
+    base.update({"WORLD_SIZE": str(n), HUB_ENV: f"{hub.address[0]}:{hub.address[1]}", KEY_ENV: hub.authkey.hex()})
+    # HSA_ENABLE_IPC_MODE_LEGACY is the operator's to set: a value in the environment is passed on untouched.  Only when it
+    # is absent do the ranks get 0 -- and a line saying so: the operating note of the pool this was built on states that its
+    # host driver supports dmabuf IPC only and that RCCL fails with "hipIpcGetMemHandle: invalid argument" without it
+    # (the note exports the variable itself on every box; no multi-GPU run of this code exists yet to confirm either way --
+    # alp_comm_init's failure message prints the value in force).
+    if n > 1 and "HSA_ENABLE_IPC_MODE_LEGACY" not in base:
+        base["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        print("launch: HSA_ENABLE_IPC_MODE_LEGACY is unset; the ranks get 0 (dmabuf IPC; set it yourself to override)", file=log, flush=True)
     procs = []
     try:
         for r in range(n):       # children first, hub thread afterwards: no fork out of a threaded parent

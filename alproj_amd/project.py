@@ -30,10 +30,12 @@ mesh on the device between calls:
 
 * pass a ``Mesh`` (or use ``reverse_proj_device``): the explicit device handle, nothing is compared;
 * ``set_mesh_cache(True)``: the last mesh stays resident and a call with the same array OBJECTS re-renders
-  it -- after the cache has made sure their CONTENT is unchanged: arrays that are read-only all the way
-  down (``a.setflags(write=False)``, no writeable base) are taken by identity; writeable arrays by a
-  64-bit digest of every byte (``alp_host_hash64``, all host cores), taken at upload time and again at
-  lookup.  An in-place edit of a single vertex between two calls is therefore always seen.  The digest
+  it -- after the cache has made sure their CONTENT is unchanged: writeable arrays by a 64-bit digest of
+  every byte (``alp_host_hash64``, all host cores), taken at upload time and again at lookup: an in-place
+  edit of a single vertex between two calls is always seen.  Arrays that are read-only all the way down
+  (``a.setflags(write=False)``, no writeable base) are the caller's PROMISE not to edit the memory; they
+  are taken by identity plus a sampled digest (every byte up to 32 MB, 16 MB of evenly spaced blocks above),
+  which catches the usual way of breaking the promise (flag off, array rewritten, flag on again).  The digest
   costs about what reading the arrays from host memory costs (``bench.py``: ``dropin_call.verify``): it pays
   for writeable arrays only where PCIe is slower than the host's memory, for read-only arrays always.
 
@@ -77,12 +79,31 @@ def _immutable(a):
     return True
 
 
+_SAMPLE_FULL_BELOW = 32 << 20       # read-only arrays up to this size are digested in full (a few ms)
+_SAMPLE_BLOCKS, _SAMPLE_BLOCK = 256, 64 << 10
+
+
+def _sample_digest(a):
+    """Digest of a read-only array: every byte up to 32 MB, above that 256 evenly spaced 64 KB blocks (head and tail
+    included) -- 16 MB, ~3 ms.  ``writeable=False`` is the caller's promise not to edit the memory; this is the check that
+    catches the common way of breaking it (flags toggled, array rewritten, flags toggled back), not a proof: an edit of a
+    few rows between two sampled blocks of a large array goes unseen.  Writeable arrays get the full digest."""
+    c = np.ascontiguousarray(a)
+    if c.nbytes <= _SAMPLE_FULL_BELOW:
+        return _lib.host_hash64(c)
+    b = c.reshape(-1).view(np.uint8)
+    starts = np.linspace(0, b.size - _SAMPLE_BLOCK, _SAMPLE_BLOCKS).astype(np.int64)
+    return _lib.host_hash64(np.concatenate([b[s:s + _SAMPLE_BLOCK] for s in starts]))
+
+
 def _key(a):
-    """(weak reference, layout, content digest or None for an immutable array)"""
+    """(weak reference, layout, content digest, "full" | "sample": sampled for an immutable array)"""
     if a is None:
         return None
     layout = (a.shape, a.dtype.str, a.strides, a.__array_interface__["data"][0])
-    return (weakref.ref(a), layout, None if _immutable(a) else _lib.host_hash64(np.ascontiguousarray(a)))
+    if _immutable(a):
+        return (weakref.ref(a), layout, _sample_digest(a), "sample")
+    return (weakref.ref(a), layout, _lib.host_hash64(np.ascontiguousarray(a)), "full")
 
 
 def _same(key, a):
@@ -90,8 +111,8 @@ def _same(key, a):
         return key is None and a is None
     if key[0]() is not a or key[1] != (a.shape, a.dtype.str, a.strides, a.__array_interface__["data"][0]):
         return False
-    if key[2] is None:                # it was immutable when it was uploaded: it still has to be
-        return _immutable(a)
+    if key[3] == "sample":            # it was immutable when it was uploaded: it still has to be, and look the same
+        return _immutable(a) and key[2] == _sample_digest(a)
     return key[2] == _lib.host_hash64(np.ascontiguousarray(a))
 
 

@@ -65,7 +65,9 @@ def colored_surface_mesh(aerial2, dsm2, transform, nodata_mask, source_dtype, co
         if not any_nodata:
             dsm_max_height = dsm2.max()
         else:
-            dsm_max_height = 0 if all_nodata else np.max(dsm2, where=~nodata_mask, initial=-np.inf)
+            # `initial` must be a value of the DSM's own type: an int16 DSM cannot hold -inf
+            lowest = np.iinfo(dsm2.dtype).min if np.issubdtype(dsm2.dtype, np.integer) else -np.inf
+            dsm_max_height = 0 if all_nodata else np.max(dsm2, where=~nodata_mask, initial=lowest)
     if dsm2.min() < 0:
         warnings.warn("DSM still has negative elevation values. Consider using a larger fill_dsm_dist. "
                       "Negative values will be filled with 0.")

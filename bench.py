@@ -90,9 +90,14 @@ def parse():
     ap.add_argument("--no-dropin", action="store_true", help="skip the reference-typed sim_image + reverse_proj call pair (9.6 GB of host arrays)")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the SURVEY 8(f) rows f1-f4 and the full-size pipeline")
     ap.add_argument("--launch-timeout", type=float, default=3000.0, help="wall-clock limit of a self-launched multi-rank job (s)")
-    ap.add_argument("--debug-share-device", action="store_true",
-                    help="DEVELOPMENT: all ranks use device 0 and no RCCL communicator is made (RCCL refuses two ranks on one GPU): "
-                         "walks the multi-rank control flow of this script on a 1-GPU box; the line it prints is marked and means nothing")
+    ap.add_argument("--debug-share-device", nargs="?", const="nocomm", default=None, choices=["nocomm", "rccl"],
+                    help="DEVELOPMENT: all ranks use device 0.  'nocomm' (default): no RCCL communicator is made (RCCL refuses two ranks "
+                         "on one GPU): walks the multi-rank control flow of this script on a 1-GPU box; the line it prints is marked and "
+                         "means nothing.  'rccl': ncclCommInitRank IS called and fails -- shows what a failed RCCL set-up prints and "
+                         "that every rank ends")
+    ap.add_argument("--debug-fail-comm-init-rank", type=int, default=-1,
+                    help="DEVELOPMENT: this rank gives up right before alp_comm_init (its peers are then inside ncclCommInitRank "
+                         "waiting for it): the launcher must end them")
     ap.add_argument("--launch-selftest", action="store_true", help="run the launch / control plane with a stub worker (no GPU, no library)")
     ap.add_argument("--selftest-fail-rank", type=int, default=-1, help="selftest: this rank exits with code 7 after the first barrier")
     ap.add_argument("--selftest-hang-rank", type=int, default=-1, help="selftest: this rank never reaches the second barrier")
@@ -503,7 +508,11 @@ def main():
     args = parse()
     from alproj_amd import launch
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # the LAUNCHER: builds the library once (hipcc only), then starts the ranks; it never initialises the GPU
+        # the LAUNCHER: checks that the node has N GPUs (sysfs, no HIP), builds the library once (hipcc only), then starts the
+        # ranks; it never initialises the GPU.  The stub worker needs no GPU: its pre-flight runs only against a named tree.
+        if not args.debug_share_device and (not args.launch_selftest or os.environ.get(launch.KFD_ENV)):
+            if not launch.preflight(args.gpus):
+                sys.exit(2)
         if not args.launch_selftest:
             try:
                 from alproj_amd import _build
@@ -541,14 +550,25 @@ def main():
     from alproj_amd.optimize import bounds_to_array      # the product's own host logic
     from oracle import ref_numpy as orc       # checker (parity spot check) and cpu_baseline only
 
-    if args.debug_share_device:
+    if args.debug_share_device == "nocomm":
         L.init(0)
         ctl.bcast_bytes(b"\0" * 128)             # the id's trip is still made
     else:
-        adist.init_comm(ctl.rank, ctl.world, ctl.bcast_bytes, ctl.local_rank)
+        def id_trip(b):
+            b = ctl.bcast_bytes(b)
+            if ctl.rank == args.debug_fail_comm_init_rank:
+                print(f"bench.py: rank {ctl.rank} gives up before alp_comm_init (--debug-fail-comm-init-rank)", file=sys.stderr, flush=True)
+                os._exit(9)
+            return b
+        try:
+            adist.init_comm(ctl.rank, ctl.world, id_trip, 0 if args.debug_share_device else ctl.local_rank)
+        except L.AlprojHipError as e:
+            # one block per rank, RCCL's own text included (alp_comm_init); the launcher ends the other ranks
+            print(f"bench.py: rank {ctl.rank}/{ctl.world} (LOCAL_RANK {ctl.local_rank}) could not set up: {e}", file=sys.stderr, flush=True)
+            sys.exit(5)
     info = L.device_info()
     comm_rank, comm_world = L.comm_info()
-    if args.debug_share_device:
+    if args.debug_share_device == "nocomm":
         comm_rank, comm_world = ctl.rank, ctl.world
     # the communicator the LIBRARY reports must be the job: a rank that fell back to a world of its own would add
     # nothing to the all-reduce and the line would still look plausible

@@ -1,0 +1,76 @@
+"""The line bench.py prints, as the driver stores it: `roofline` must carry the whole metric within the 24 keys the
+driver keeps (task 1).  No GPU: the split is exercised on the committed N = 1 line and on a canned one."""
+import json
+import os
+
+import pytest
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+MUST_CARRY = ["bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "bytes_per_vertex",
+              "strict_1e-5_relative_pass", "cma_iters_per_s", "cma_kernel_ms", "cma_valu_frac", "cma_all_reduce_ms",
+              "f64_gpoints_per_s", "f64_hbm_frac", "f64_strict_1e-5_pass", "c3_iters_per_s", "c3_kernel_ms", "c3_valu_frac",
+              "raster_ms_per_frame", "raster_hbm_frac", "raster_binding_roof_frac", "raster_int32_indices_ms_per_frame"]
+
+
+def canned():
+    """what the legs of a default N = 1 run put into the flat dict before the split (names as in bench.main)"""
+    flat = {k: 1.0 for k in MUST_CARRY}
+    flat.update({"bound": "hbm", "unit": "GB/s", "kernel": "project_kernel",
+                 "traffic_source": "profiles/...", "kernel_ms_median_of_single_launches": 0.3, "single_launches": 24,
+                 "vertices_per_launch": 100_000_000, "cma_generations_timed": 50, "cma_population": 2048, "cma_dims": 21,
+                 "cma_valu_frac_at_survey_100_flop": 0.6, "cma_all_reduce_share": 0.0, "f64_kernel_ms": 0.6, "f64_max_err_rel": 1e-16,
+                 "f64_cma_iters_per_s": 1.5, "c2_gpoints_per_s_kernel_median": 250.0, "c2_hbm_frac_at_median": 0.6,
+                 "c3_evals_per_s": 8e11, "c3_generations_timed": 100, "c3_mean_distance_iters_per_s": 340.0,
+                 "raster_frames_timed": 10, "raster_same_view_again_ms": 0.14, "raster_binding_roof": "l2_atomics",
+                 "raster_binding_roof_source": "profiles/...", "raster_int32_indices_hbm_frac": 0.28})
+    return flat
+
+
+def test_roofline_fits_the_drivers_cap_and_carries_all_five_configs():
+    assert list(bench.ROOFLINE_KEYS) == MUST_CARRY and len(bench.ROOFLINE_KEYS) <= bench.ROOFLINE_CAP == 24
+    flat = canned()
+    roof, detail = bench.driver_roofline(flat)
+    assert list(roof) == MUST_CARRY                       # order too: the driver keeps the FIRST 24
+    assert len(roof) <= 24 and all(roof[k] is not None for k in MUST_CARRY)
+    assert not set(roof) & set(detail) and set(roof) | set(detail) == set(flat)
+    # a leg that did not run (N > 1: no float64 / 10 M / render legs) leaves None, never a missing or shifted key
+    part = {k: v for k, v in flat.items() if not k.startswith(("f64_", "c3_", "raster_"))}
+    roof2, _ = bench.driver_roofline(part)
+    assert list(roof2) == MUST_CARRY and roof2["c3_iters_per_s"] is None and roof2["frac"] == 1.0
+    json.dumps(roof)
+
+
+def test_committed_line_of_this_round_obeys_the_cap():
+    """the round's own committed N = 1 line (profiles/r05_bench_default_run.json, once it exists) was split by the same rule"""
+    f = os.path.join(ROOT, "profiles", "r05_bench_default_run.json")
+    if not os.path.exists(f):
+        pytest.skip("no round-5 line committed yet")
+    line = json.load(open(f))
+    assert list(line["roofline"]) == MUST_CARRY
+    missing = [k for k in MUST_CARRY if line["roofline"][k] is None]
+    assert not missing, missing
+    assert 0 < line["roofline"]["raster_binding_roof_frac"] <= 1.05 and line["roofline"]["raster_ms_per_frame"] > 0
+
+
+def test_binding_roof_summary_is_consistent():
+    br, src = bench.committed_summary("raster_binding_roof")
+    assert br is not None and src.startswith("profiles/")
+    assert br["floor_ms"] == max(br["atomic_floor_ms"], br["valu_floor_ms"])
+    assert br["atomic_floor_ms"] == pytest.approx(br["atomic_line_requests_per_frame"] / br["atomic_rate_per_s"] * 1e3)
+    assert br["valu_floor_ms"] == pytest.approx(br["valu_active_quad_cycles_per_frame"] * 4 / (br["simds"] * br["clock_hz"]) * 1e3)
+    assert br["binding"] in ("l2_atomics", "valu")
+
+
+def test_expectation_for_n_gpus_is_kernel_time_over_n(tmp_path, monkeypatch):
+    one = {"n_gpus": 1, "config": {"vertices": 100_000_000}, "roofline": {"kernel_ms": 0.32, "cma_kernel_ms": 214.0},
+           "cma": {"ms_per_iter": 216.0}}
+    (tmp_path / "r05_bench_default_run.json").write_text(json.dumps(one))
+    monkeypatch.setattr(bench, "PROFILES", str(tmp_path))
+    e = bench.expectation_from_one_gpu(8, 0.05)
+    assert e["projection_kernel_ms"] == pytest.approx(0.04) and e["projection_gpoints_per_s"] == pytest.approx(2500.0)
+    assert e["cma_kernel_ms"] == pytest.approx(26.75) and e["cma_ms_per_iter"] == pytest.approx(26.75 + 0.05 + 2.0)
+    monkeypatch.setattr(bench, "PROFILES", str(tmp_path / "nothing"))
+    assert bench.expectation_from_one_gpu(8, 0.05) is None

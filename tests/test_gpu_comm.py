@@ -78,7 +78,7 @@ def test_optimisers_take_rank0s_seed_and_candidates_on_the_device(monkeypatch):
     def fake_bcast(array, root=0):
         assert root == 0 and array.flags["C_CONTIGUOUS"]
         if array.dtype == np.uint64:
-            array[...] = 424242
+            array[...] = (424242, 1)                                    # "rank 0's" seed and element type (1 = float64)
         else:
             array[...] = rank0.uniform(0.3, 0.7, array.shape)           # "rank 0's" candidates / solution
             sent.append(array.copy())
@@ -107,19 +107,22 @@ def test_optimisers_take_rank0s_seed_and_candidates_on_the_device(monkeypatch):
     real_eval = L.Points.eval_population
 
     def spy_eval(self, cand, kind, f_scale=10.0, want_argmin=True):
-        events.append(("eval", np.array(cand, copy=True), want_argmin))
+        events.append(("eval", np.array(cand, copy=True), want_argmin, self.precision))
         return real_eval(self, cand, kind, f_scale, want_argmin)
 
     monkeypatch.setattr(L.Points, "eval_population", spy_eval)
     o = aopt.CMAOptimizer(obj, img, init)
     o.set_target(["fov", "pan", "tilt", "roll"])
     gens, pop = 6, 10
-    params, err = o.optimize(generation=gens, sigma=0.3, population_size=pop, f_scale=10.0, seed=None, progress=False, precision="f64")
+    params, err = o.optimize(generation=gens, sigma=0.3, population_size=pop, f_scale=10.0, seed=None, progress=False, precision="f32")
     kinds = [e[0] for e in events]
     assert kinds == ["bcast", "cma"] + ["bcast", "eval", "tell"] * gens + ["eval"]
     # the argmin (with its float64 confirmation on float32 sets) is asked for in the LAST generation only (optimize.py:427)
     assert [e[2] for e in events if e[0] == "eval"] == [False] * (gens - 1) + [True, True]
-    assert events[0][1:] == ("uint64", (1,)) and events[1][1] == 424242           # the sampler is built from rank 0's seed
+    assert events[0][1:] == ("uint64", (2,)) and events[1][1] == 424242           # the sampler is built from rank 0's seed
+    # ... and the point set has rank 0's element type, not the one this rank asked for: the float64 confirmation of a
+    # float32 set is a collective of its own, so the ranks must not differ
+    assert all(e[3] == L.ALP_F64 for e in events if e[0] == "eval")
     bounds = aopt.bounds_to_array(init, o.target_params)
     cols = [L.PARAM_KEYS.index(t) for t in o.target_params]
     for g in range(gens):

@@ -199,15 +199,26 @@ def test_opt_in_mesh_cache_verifies_content(L, scene):
         np.testing.assert_array_equal(sim_i, aproj.sim_image(vert, col, ind, p, off))
         np.testing.assert_array_equal(sim_c, aproj.sim_image(vert, col, scene["ind64"], p, off))
         assert (sim_c != sim_a).any()
-        # ---- read-only arrays are taken by identity (no digest), and stop being cacheable when made writeable again
+        # ---- read-only arrays are taken by identity + a sampled digest, and stop being cacheable when made writeable again
         aproj.set_mesh_cache(True)
         for a in (vert, col, ind):
             a.setflags(write=False)
         aproj.sim_image(vert, col, ind, p, off)
-        assert aproj._cache["vert"][2] is None and aproj._cache["ind"][2] is None
+        assert aproj._cache["vert"][3] == "sample" and aproj._cache["ind"][3] == "sample"
         held = aproj._cache["mesh"]
         aproj.reverse_proj(sim, vert, ind, p, off)
         assert aproj._cache["mesh"] is held and aproj.LAST_CACHE["hit"]
+        # the flag toggled, the array edited, the flag toggled back: not the stale mesh
+        vert.setflags(write=True)
+        vert[len(vert) // 3, 1] += 25.0
+        vert.setflags(write=False)
+        df_t = aproj.reverse_proj(sim, vert, ind, p, off)
+        assert aproj._cache["mesh"] is not held and not aproj.LAST_CACHE["hit"]
+        aproj.set_mesh_cache(False)
+        assert df_t.equals(aproj.reverse_proj(sim, vert, ind, p, off))
+        aproj.set_mesh_cache(True)
+        aproj.reverse_proj(sim, vert, ind, p, off)
+        held = aproj._cache["mesh"]
         vert.setflags(write=True)
         vert[5, 1] += 1.0
         aproj.reverse_proj(sim, vert, ind, p, off)

@@ -243,9 +243,36 @@ def test_resident_mesh_cache_keys():
     frozen = rng.random((1000, 3))
     frozen.setflags(write=False)
     kf = aproj._key(frozen)
-    assert kf[2] is None and aproj._same(kf, frozen) and aproj._immutable(frozen)
+    assert kf[3] == "sample" and aproj._same(kf, frozen) and aproj._immutable(frozen)
     frozen.setflags(write=True)
     assert not aproj._same(kf, frozen)
+    # flags toggled, array rewritten, flags toggled back -- same object, read-only again, other content
+    frozen.setflags(write=False)
+    assert aproj._same(kf, frozen)
+    frozen.setflags(write=True)
+    frozen[500, 1] += 1.0
+    frozen.setflags(write=False)
+    assert not aproj._same(kf, frozen)
+    # ... and on an array above the full-digest size: a rewrite is seen through the sampled blocks
+    old_full = aproj._SAMPLE_FULL_BELOW
+    aproj._SAMPLE_FULL_BELOW = 1 << 20
+    try:
+        large = rng.random((3_000_000, 3))                           # 72 MB
+        large.setflags(write=False)
+        kl = aproj._key(large)
+        assert kl[3] == "sample" and aproj._same(kl, large)
+        large.setflags(write=True)
+        large *= 1.0000001
+        large.setflags(write=False)
+        assert not aproj._same(kl, large)
+        kl = aproj._key(large)
+        large.setflags(write=True)
+        large[-1, 2] = -1.0                                          # the tail block is always sampled
+        large.setflags(write=False)
+        assert not aproj._same(kl, large)
+    finally:
+        aproj._SAMPLE_FULL_BELOW = old_full
+    frozen.setflags(write=True)
     ro_view = frozen[:]
     ro_view.setflags(write=False)
     assert not aproj._immutable(ro_view)                           # its base can still be written
@@ -285,13 +312,51 @@ def test_result_memory_is_recycled_only_when_nobody_holds_it():
         assert f.dtype == np.float64 and f.flags.aligned
         del b, c, f
         gc.collect()
-        assert L._pool_bytes == 3 * 12_000_000
+        assert L._pool_bytes == 2 * 12_000_000           # three came back: no size keeps more than two
         small = L.result_empty((1000, 3), np.float64)
         assert small.flags.owndata
         big = L.result_empty((65 << 20,), np.uint8)    # beyond the cap: never kept
         assert big.flags.owndata
         L.set_result_pool(0)
         assert L._pool_bytes == 0 and L.result_empty((3, 2000, 2000), np.uint8).flags.owndata
+    finally:
+        L.set_result_pool(0)
+        L.set_result_pool(old_cap)
+
+
+def test_result_pool_evicts_other_sizes_first_and_can_be_cleared():
+    """a workload that changes its raster size must not pin the old size's buffers (and recycle nothing):
+    over the cap the OLDEST buffers of OTHER sizes go first; clear_result_pool() gives everything back."""
+    import gc
+    from alproj_amd import _lib as L
+    old_cap = L._pool_cap
+    try:
+        L.set_result_pool(0)
+        L.set_result_pool(40 << 20)
+        ev0 = L.POOL_STATS["evicted"]
+        a1, a2 = L.result_empty((16 << 20,), np.uint8), L.result_empty((16 << 20,), np.uint8)       # the "earlier resolution"
+        del a1, a2
+        gc.collect()
+        assert L._pool_bytes == 32 << 20 and sorted(L._pool) == [16 << 20]
+        b = L.result_empty((20 << 20,), np.uint8)                                                     # the new raster size
+        where = b.ctypes.data
+        del b
+        gc.collect()
+        # 32 + 20 > 40: one 16 MB buffer (the older one) went, the 20 MB one is kept and is recycled
+        assert L._pool_bytes == (16 << 20) + (20 << 20) and L.POOL_STATS["evicted"] == ev0 + 1
+        b2 = L.result_empty((20 << 20,), np.uint8)
+        assert b2.ctypes.data == where
+        c = L.result_empty((20 << 20,), np.uint8)
+        del b2, c
+        gc.collect()
+        # two of 20 MB = 40 MB: the last 16 MB buffer went as well, nothing of the old size stays resident
+        assert sorted(L._pool) == [20 << 20] and L._pool_bytes == 40 << 20 and len(L._pool_age) == 2
+        L.set_result_pool(25 << 20)                        # a smaller cap releases the oldest
+        assert L._pool_bytes == 20 << 20
+        L.clear_result_pool()
+        assert L._pool_bytes == 0 and not L._pool and not L._pool_age
+        d = L.result_empty((20 << 20,), np.uint8)
+        assert d.ctypes.data is not None and L._pool_cap == 25 << 20      # the pool is still on
     finally:
         L.set_result_pool(0)
         L.set_result_pool(old_cap)

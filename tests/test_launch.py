@@ -21,7 +21,8 @@ BENCH = os.path.join(ROOT, "bench.py")
 
 def _run(args, timeout=120, env=None):
     e = dict(os.environ)
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", launch.HUB_ENV, launch.KEY_ENV):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", launch.HUB_ENV, launch.KEY_ENV, launch.KFD_ENV,
+              "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         e.pop(k, None)
     e.update(env or {})
     return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
@@ -96,6 +97,7 @@ def test_ranks_of_a_foreign_launcher_meet_at_rank_0(tmp_path):
         port = str(s.getsockname()[1])
     base = dict(os.environ, WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, TMPDIR=str(tmp_path))
     base.pop(launch.HUB_ENV, None)
+    base.pop("XDG_RUNTIME_DIR", None)                          # the announcement goes to <TMPDIR>/alproj_<uid>/
     procs = [subprocess.Popen([sys.executable, BENCH, "--gpus", "3", "--launch-selftest"], cwd=ROOT,
                               env=dict(base, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
              for r in (2, 0, 1)]                               # rank 0 is not the first to start
@@ -104,7 +106,115 @@ def test_ranks_of_a_foreign_launcher_meet_at_rank_0(tmp_path):
     out = json.loads(outs[1][0])
     assert out["n_gpus"] == 3 and all(x["hub"] == "rank0" for x in out["ranks"]) and len({x["uid_sha256"] for x in out["ranks"]}) == 1
     assert not outs[0][0].strip() and not outs[2][0].strip()
-    assert not [f for f in os.listdir(tmp_path) if f.startswith("alproj_hub_")]
+    private = tmp_path / f"alproj_{os.getuid()}"
+    assert private.is_dir() and (private.stat().st_mode & 0o777) == 0o700 and not os.listdir(private)     # the file is gone afterwards
+
+
+def test_hub_announcement_is_private_and_its_key_is_not_derivable(tmp_path, monkeypatch):
+    """ADVICE round 4: the key of rank 0's hub is random and travels in a 0600 file inside a 0700 directory of this user;
+    a directory or file somebody else could have prepared is refused."""
+    import stat
+    monkeypatch.delenv("XDG_RUNTIME_DIR", raising=False)
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    import tempfile
+    monkeypatch.setattr(tempfile, "tempdir", None)             # re-read TMPDIR
+    for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29500")):
+        monkeypatch.setenv(k, v)
+    path = launch._rendezvous_file()
+    d = os.path.dirname(path)
+    assert d == str(tmp_path / f"alproj_{os.getuid()}") and stat.S_IMODE(os.lstat(d).st_mode) == 0o700
+    keys = set()
+    for _ in range(2):                                          # two jobs with the same public tag: two different keys
+        hub = launch.Hub(1)
+        launch._announce(path, hub.address, hub.authkey)
+        assert stat.S_IMODE(os.lstat(path).st_mode) == 0o600
+        addr, key = launch._read_announcement(path)
+        assert addr == hub.address and key == hub.authkey and len(key) == 16
+        keys.add(key)
+        hub.close()
+    assert len(keys) == 2
+    # a world-readable file, a symlink, a loose directory: all refused
+    os.chmod(path, 0o644)
+    with pytest.raises(launch.LaunchError):
+        launch._read_announcement(path)
+    os.unlink(path)
+    real = tmp_path / "elsewhere"
+    real.write_text('{"host": "127.0.0.1", "port": 1, "key": "00"}')
+    os.chmod(real, 0o600)
+    os.symlink(real, path)
+    with pytest.raises(OSError):
+        launch._read_announcement(path)
+    os.unlink(path)
+    os.chmod(d, 0o755)
+    with pytest.raises(launch.LaunchError):
+        launch._rendezvous_file()
+    os.chmod(d, 0o700)
+
+
+def test_nothing_received_is_unpickled():
+    """a peer that knows the key and speaks pickle (Connection.send) gets an error; the hub does not build its object"""
+    from multiprocessing.connection import Client
+    hub = launch.Hub(1).start()
+
+    class Bomb:
+        def __reduce__(self):
+            return (os.system, ("touch /tmp/alproj_pickle_bomb_%d" % os.getpid(),))
+
+    c = Client(hub.address, authkey=hub.authkey)
+    c.send(Bomb())
+    hub.join(10)
+    assert hub.error and "malformed" in hub.error
+    assert not os.path.exists("/tmp/alproj_pickle_bomb_%d" % os.getpid())
+    with pytest.raises(TypeError):
+        launch._enc(object())
+    assert launch._dec(json.loads(json.dumps(launch._enc({"id": b"\x00\xff", "t": (1, 2.5, None)})))) == {"id": b"\x00\xff", "t": [1, 2.5, None]}
+
+
+def _fake_kfd(root, gpus, cpus=2):
+    for i in range(cpus + gpus):
+        d = root / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {64 if i < cpus else 0}\nsimd_count {0 if i < cpus else 1024}\nmem_banks_count 1\n")
+    return str(root)
+
+
+def test_preflight_counts_gpus_from_sysfs_without_hip(tmp_path):
+    """VERDICT round 4, task 3(a): fewer GPUs than --gpus -> one clear line, exit 2, nothing spawned"""
+    eight = _fake_kfd(tmp_path / "eight", 8)
+    four = _fake_kfd(tmp_path / "four", 4)
+    assert launch.gpu_nodes(eight) == (8, eight) and launch.gpu_nodes(four)[0] == 4
+    assert launch.gpu_nodes(str(tmp_path / "absent"))[0] is None
+    r = _run(["--gpus", "8", "--launch-selftest"], env={launch.KFD_ENV: eight})
+    assert r.returncode == 0 and json.loads(r.stdout)["n_gpus"] == 8 and len(_pids(r.stderr)) == 8
+    r = _run(["--gpus", "8", "--launch-selftest"], env={launch.KFD_ENV: four})
+    assert r.returncode == 2 and not r.stdout.strip() and not _pids(r.stderr)
+    assert "--gpus 8 but this node offers 4" in r.stderr and "nothing was started" in r.stderr
+    r = _run(["--gpus", "4", "--launch-selftest"], env={launch.KFD_ENV: eight, "HIP_VISIBLE_DEVICES": "0,1"})
+    assert r.returncode == 2 and "offers 2" in r.stderr and "VISIBLE_DEVICES" in r.stderr
+    r = _run(["--gpus", "2", "--launch-selftest"], env={launch.KFD_ENV: str(tmp_path / "absent")})
+    assert r.returncode == 2 and "no GPU on this node" in r.stderr
+    # the real benchmark (not the stub) in this GPU-less container: refused by the pre-flight before anything is built or started
+    r = _run(["--gpus", "2"], env={launch.KFD_ENV: str(tmp_path / "absent")})
+    assert r.returncode == 2 and "no GPU on this node" in r.stderr
+
+
+def test_spawn_passes_the_operators_ipc_setting_on_and_says_when_it_sets_one(tmp_path):
+    show = tmp_path / "show.py"
+    show.write_text("import os, sys\nsys.path.insert(0, %r)\nfrom alproj_amd import launch\nc = launch.Control.from_env()\n"
+                    "v = c.gather(os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'))\nc.close()\n"
+                    "open(%r, 'w').write(repr(v)) if c.rank == 0 else None\n" % (ROOT, str(tmp_path / "seen")))
+    env = dict(os.environ)
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
+    log = open(tmp_path / "log", "w+")
+    assert launch.spawn([sys.executable, str(show)], 2, timeout_s=60, env=env, log=log) == 0
+    assert (tmp_path / "seen").read_text() == "['0', '0']"
+    log.seek(0)
+    assert "HSA_ENABLE_IPC_MODE_LEGACY is unset" in log.read()
+    log = open(tmp_path / "log2", "w+")
+    assert launch.spawn([sys.executable, str(show)], 2, timeout_s=60, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="1"), log=log) == 0
+    assert (tmp_path / "seen").read_text() == "['1', '1']"
+    log.seek(0)
+    assert "HSA_ENABLE_IPC_MODE_LEGACY" not in log.read()
 
 
 def test_hub_collectives_in_process():
@@ -126,7 +236,7 @@ def test_hub_collectives_in_process():
     hub.join(5)
     assert hub.error is None and hub.collectives == 6
     for got in res:
-        assert got == (3.0, b"\0\0\0\0", [{"r": i} for i in range(n)], ("x", 0))
+        assert got == (3.0, b"\0\0\0\0", [{"r": i} for i in range(n)], ["x", 0])     # JSON on the wire: a tuple arrives as a list
 
 
 def test_a_vanished_rank_releases_the_others():

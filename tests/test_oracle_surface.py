@@ -62,3 +62,27 @@ def test_normalize_aerial_rules(data, dtype, kw, exp):
         div = color_divisor(arr, dtype, kw.get("color_max"))
     got = np.clip(arr / div if div > 0 else arr, 0, 1)
     np.testing.assert_allclose(got, exp, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", [np.int16, np.uint16, np.int32, np.float32, np.float64])
+def test_default_max_height_of_an_integer_dsm_with_partial_nodata(dtype, monkeypatch):
+    """colored_surface_mesh(dsm_max_height=None) on an INTEGER DSM with a partial nodata mask raised
+    OverflowError (np.max(..., initial=-inf)); the clamp must be dsm2[~nodata_mask].max() as in surface.py:169."""
+    from alproj_amd import _lib, surface
+    seen = {}
+
+    def recorder(dsm, transform, zmax, aerial, div, nodata):
+        seen.update(zmax=zmax, nodata=nodata)
+        return "mesh", "offsets"
+
+    monkeypatch.setattr(_lib.Mesh, "from_rasters", staticmethod(recorder))
+    rng = np.random.default_rng(3)
+    dsm = rng.integers(100, 3000, (12, 9)).astype(dtype)
+    mask = np.zeros((12, 9), dtype=bool)
+    mask[2:5, 3:7] = True
+    dsm[3, 4] = 30000 if dtype != np.int16 else 32000          # the largest value sits under the mask: it must not win
+    aerial = np.zeros((3, 12, 9), np.uint8)
+    assert surface.colored_surface_mesh(aerial, dsm, (1.0, 0, 0, 0, -1.0, 12.0), mask, np.uint8) == ("mesh", "offsets")
+    assert seen["zmax"] == float(dsm[~mask].max()) and seen["nodata"] is mask
+    surface.colored_surface_mesh(aerial, dsm, (1.0, 0, 0, 0, -1.0, 12.0), np.zeros_like(mask), np.uint8)
+    assert seen["zmax"] == float(dsm.max()) and seen["nodata"] is None
