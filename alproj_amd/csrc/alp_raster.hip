@@ -67,7 +67,8 @@
 // the full-frame path and the exact path without its culling.
 #if defined(ALP_WG_TIMING) || defined(ALP_RASTER_STATS) || defined(VIS_PLAIN_STORE) || defined(VIS_NEVER) || defined(PARK_NOATOMIC) || \
     defined(PARKED_SKIP_CELLS) || defined(PARKED_SKIP_COOP) || defined(PARKED_SKIP_COOP4) || defined(GRID_STOP_AFTER) ||               \
-    defined(GRID_NO_XCD_SWIZZLE) || defined(PT_SKIP_CELLS) || defined(PT_SKIP_SMALL) || defined(PT_SKIP_LARGE) || defined(PARKED_TILES_LAB)
+    defined(GRID_NO_XCD_SWIZZLE) || defined(PT_SKIP_CELLS) || defined(PT_SKIP_SMALL) || defined(PT_SKIP_LARGE) || defined(PARKED_TILES_LAB) || \
+    defined(INDEX_LDS_LAB)
 #define ALP_DEV_SWITCHES 1
 #ifndef ALP_DEV
 #error "development switch given without -DALP_DEV: this would build a library that renders wrong images"
@@ -112,6 +113,9 @@ const char *raster_dev_flags() {
 #endif
 #ifdef PARKED_TILES_LAB
            "PARKED_TILES_LAB,"
+#endif
+#ifdef INDEX_LDS_LAB
+           "INDEX_LDS_LAB,"
 #endif
 #if defined(PT_SKIP_CELLS) || defined(PT_SKIP_SMALL) || defined(PT_SKIP_LARGE)
            "PT_SKIP_*(wrong image),"
@@ -618,9 +622,31 @@ int render_impl(alp_mesh *m, const View &v, const RemapCoef &rc, double min_dist
 #define RASTER_BLOCKS_PER_CU 64        // 16: 2.12 ms, 64: 2.01 (explicit int32 indices, 100 M vertices)
 #endif
             const int grid = (int)(want < (long long)cu * RASTER_BLOCKS_PER_CU ? want : (long long)cu * RASTER_BLOCKS_PER_CU);
-            hipLaunchKernelGGL((raster_kernel<IMPLICIT>), dim3(grid), dim3(256), 0, st, m->vert, m->ind, m->valid,
-                               (long long)m->n_tri, (long long)m->grid_w, v, m->vis, m->gqueue, fcount + 1,
-                               m->gcap);
+            bool through_lds = false;
+#ifdef INDEX_LDS_LAB        // round 5: a block's vertices transformed once through an LDS hash set -- bit-exact, slower, not kept (raster_index.h)
+            if constexpr (!IMPLICIT) {
+                if (m->ind_sharing < 0.0f) {       // once per mesh: how many distinct vertices do 256 consecutive triangles name?
+                    unsigned long long *sums = nullptr, host[2] = {0, 0};
+                    if (int e = scratch_reserve(sizeof(host), (void **)&sums)) return e;
+                    ALP_HIP(hipMemsetAsync(sums, 0, sizeof(host), st));
+                    const long long blocks = want, step = blocks > 4096 ? blocks / 4096 : 1;
+                    hipLaunchKernelGGL(index_sharing_kernel, dim3((unsigned)std::min<long long>((blocks + step - 1) / step, 4096)), dim3(256), 0, st,
+                                       m->ind, (long long)m->n_tri, step, sums);
+                    ALP_HIP(hipMemcpyAsync(host, sums, sizeof(host), hipMemcpyDeviceToHost, st));
+                    ALP_HIP(hipStreamSynchronize(st));
+                    m->ind_sharing = host[1] ? (float)((double)host[0] / (double)host[1]) : 1.0f;
+                }
+                const char *force = getenv("ALP_INDEX_LDS");     // "0" / "1": either kernel whatever the array
+                through_lds = force ? atoi(force) != 0 : m->ind_sharing <= INDEX_SHARING_MAX;
+                if (through_lds)
+                    hipLaunchKernelGGL(raster_index_lds_kernel, dim3(grid), dim3(256), 0, st, m->vert, m->ind, m->valid, (long long)m->n_tri, v,
+                                       m->vis, m->gqueue, fcount + 1, m->gcap);
+            }
+#endif
+            if (!through_lds)
+                hipLaunchKernelGGL((raster_kernel<IMPLICIT>), dim3(grid), dim3(256), 0, st, m->vert, m->ind, m->valid,
+                                   (long long)m->n_tri, (long long)m->grid_w, v, m->vis, m->gqueue, fcount + 1,
+                                   m->gcap);
             ALP_HIP(hipGetLastError());
             if (int e = drain_rare(0)) return e;
         }

@@ -63,6 +63,7 @@ struct alp_mesh {
     float *vert = nullptr, *value = nullptr;
     int *ind = nullptr;
     unsigned char *valid = nullptr;    // optional, per vertex: 0 = nodata, its triangles are not drawn
+    float ind_sharing = -1.0f;         // INDEX_LDS_LAB builds only: distinct vertices / references per block of 256 triangles
     // A filtered index array of the regular grid (surface.py:203-205: the triangles of nodata vertices removed)
     // recognised at creation: rendered as the implicit grid with the vertex mask it implies; these map the
     // grid's triangle ids back to positions in the caller's array (alp_render_fetch_visibility)
