@@ -217,6 +217,7 @@ int alp_shutdown(void) {
     if (!c.ready) return ALP_OK;
     alp_comm_destroy();
     hipStreamSynchronize(c.stream);
+    points_release_staging();
     if (c.scratch) hipFree(c.scratch);
     c.scratch = nullptr;
     c.scratch_cap = 0;

@@ -75,6 +75,9 @@ struct KTimeScope {
 // Development switches compiled into the render translation unit ("" = none: a release build); alp_build_flags()
 const char *raster_dev_flags();
 
+// alp_shutdown: the pinned staging buffers and events of the converting fetch (alp_points.hip) belong to the device context
+void points_release_staging();
+
 // all-reduce (sum, double) of `count` doubles in place on the library stream; no-op
 // when no communicator exists.
 int comm_allreduce_sum_f64(double *dev_buf, int64_t count);

@@ -186,27 +186,6 @@ __global__ __launch_bounds__(256) void project_kernel(const T *__restrict__ x, c
 
 // ------------------------------------------------------------------ K3: residual vectors
 // out[b][2i] = uo - u_b, out[b][2i+1] = vo - v_b  (optimize.py:233-236), float64 output.
-// Residual vectors of B poses at once (finite-difference Jacobian of the least-squares path:
-// scipy's 2-point scheme needs D+1 evaluations per iteration, optimize.py:510-528).  Each point
-// is loaded once; the pose records are read with wave-uniform (scalar) loads.
-// out[b][i] = (uo - u_b, vo - v_b), b-major.
-template <typename T>
-__global__ __launch_bounds__(256) void residual_batch_kernel(const T *__restrict__ x, const T *__restrict__ y,
-                                                             const T *__restrict__ z, const T *__restrict__ uo,
-                                                             const T *__restrict__ vo, double2 *__restrict__ out,
-                                                             int64_t n, const PoseRec<T> *__restrict__ poses, int B) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const T qx = x[i], qy = y[i], qz = z[i], ou = uo[i], ov = vo[i];
-        for (int b = 0; b < B; ++b) {
-            T xd, yd, u, v;
-            project_norm<T>(poses[b].v, qx, qy, qz, xd, yd);
-            to_pixels<T>(poses[b].v, xd, yd, u, v);
-            Num<double>::nt_store(make_double2((double)(ou - u), (double)(ov - v)), out + ((int64_t)b * n + i));    // written once, read by the copy engine
-        }
-    }
-}
-
 // ------------------------------------------------------------------ wave64 sum
 // DPP butterfly inside each row of 16 lanes, then row_bcast15 / row_bcast31: lane 63 ends
 // up with the sum of all 64 lanes.  Fixed order -> bitwise reproducible.
@@ -354,23 +333,16 @@ __device__ __forceinline__ void norm_coords(const T *r, const T (&qx)[V], const 
     }
 }
 
-// SHARED_POSE: every candidate of the call has the same rows 0..11 (only distortion
-// coefficients are optimised, the reference's second phase, example.py:75-78): the
-// normalised coordinates `pre` were computed once per point outside the candidate loop.
-template <typename T, int LOSS, int V, bool MASKED, bool SHARED_POSE>
-__device__ __forceinline__ T group_loss_sum(const T *r, const T (&qx)[V], const T (&qy)[V], const T (&qz)[V],
-                                            const NormCoords<T, V> &pre, const T (&uoc)[V], const T (&voc)[V],
-                                            const bool (&ok)[V], T f_scale, T half_f2) {
+// normalised DISTORTED coordinates (x1_d, y1_d of optimize.py:112-116) of V points whose normalised coordinates are in nc;
+// the stages are written one after the other over all V points (see above)
+template <typename T, int V>
+__device__ __forceinline__ void distort_group(const T *r, const NormCoords<T, V> &nc, T (&a)[V], T (&b)[V]) {
     using N = Num<T>;
-    NormCoords<T, V> own;
-    if constexpr (!SHARED_POSE) norm_coords<T, V>(r, qx, qy, qz, own);
-    const NormCoords<T, V> &nc = SHARED_POSE ? pre : own;
     const T (&x1)[V] = nc.x1;
     const T (&y1)[V] = nc.y1;
     const T (&xx)[V] = nc.xx;
     const T (&yy)[V] = nc.yy;
     const T (&r2)[V] = nc.r2;
-    T d2[V], dist[V];
     T nx[V], ny[V], dx[V], dy[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
@@ -399,23 +371,40 @@ __device__ __forceinline__ T group_loss_sum(const T *r, const T (&qx)[V], const 
     for (int j = 0; j < V; ++j) {
         // x1_d = x1 num/den + 2 p1 x y + 2 p2 r2 x^2 + r2 (s1 + s2 r2)   (optimize.py:112-116, Q1)
         const T t1 = r[20] * (x1[j] * y1[j]);             // 2 p1 x y       (shared by x and y)
-        T a, b;
         if constexpr (sizeof(T) == 4 || POP_F64_HORNER) {
             // r2 (2 p2 x^2 + s1 + s2 r2) + t1: one multiply fewer per coordinate pair
-            a = N::fma(r2[j], N::fma(r[21], xx[j], N::fma(r[23], r2[j], r[22])), t1);
-            b = N::fma(r2[j], N::fma(r[21], yy[j], N::fma(r[25], r2[j], r[24])), t1);
+            a[j] = N::fma(r2[j], N::fma(r[21], xx[j], N::fma(r[23], r2[j], r[22])), t1);
+            b[j] = N::fma(r2[j], N::fma(r[21], yy[j], N::fma(r[25], r2[j], r[24])), t1);
         } else {
             const T pp = r[21] * r2[j];                   // 2 p2 r2        (shared)
-            a = N::fma(pp, xx[j], t1);
-            a = N::fma(N::fma(r[23], r2[j], r[22]), r2[j], a);
-            b = N::fma(pp, yy[j], t1);
-            b = N::fma(N::fma(r[25], r2[j], r[24]), r2[j], b);
+            a[j] = N::fma(pp, xx[j], t1);
+            a[j] = N::fma(N::fma(r[23], r2[j], r[22]), r2[j], a[j]);
+            b[j] = N::fma(pp, yy[j], t1);
+            b[j] = N::fma(N::fma(r[25], r2[j], r[24]), r2[j], b[j]);
         }
-        a = N::fma(x1[j], nx[j] * dx[j], a);
-        b = N::fma(y1[j], ny[j] * dy[j], b);
+        a[j] = N::fma(x1[j], nx[j] * dx[j], a[j]);
+        b[j] = N::fma(y1[j], ny[j] * dy[j], b[j]);
+    }
+}
+
+// SHARED_POSE: every candidate of the call has the same rows 0..11 (only distortion
+// coefficients are optimised, the reference's second phase, example.py:75-78): the
+// normalised coordinates `pre` were computed once per point outside the candidate loop.
+template <typename T, int LOSS, int V, bool MASKED, bool SHARED_POSE>
+__device__ __forceinline__ T group_loss_sum(const T *r, const T (&qx)[V], const T (&qy)[V], const T (&qz)[V],
+                                            const NormCoords<T, V> &pre, const T (&uoc)[V], const T (&voc)[V],
+                                            const bool (&ok)[V], T f_scale, T half_f2) {
+    using N = Num<T>;
+    NormCoords<T, V> own;
+    if constexpr (!SHARED_POSE) norm_coords<T, V>(r, qx, qy, qz, own);
+    const NormCoords<T, V> &nc = SHARED_POSE ? pre : own;
+    T a[V], b[V], d2[V], dist[V];
+    distort_group<T, V>(r, nc, a, b);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
         // pixels u = a c0 + c0 (optimize.py:117-118): residual uo - u = (uo - c0) - c0 a
-        const T du = N::fma(a, r[28], uoc[j]);
-        const T dv = N::fma(b, r[29], voc[j]);
+        const T du = N::fma(a[j], r[28], uoc[j]);
+        const T dv = N::fma(b[j], r[29], voc[j]);
         d2[j] = N::fma(dv, dv, du * du);
     }
 #pragma unroll
@@ -443,6 +432,51 @@ __device__ __forceinline__ T group_loss_sum(const T *r, const T (&qx)[V], const 
     }
     if constexpr (LOSS != ALP_LOSS_MEAN_DIST && (sizeof(T) == 4 || POP_F64_HUBER_MIN)) acc *= (T)0.5;      // one multiply per V evaluations instead of one each
     return acc;
+}
+
+// ------------------------------------------------------------------ K3: residual vectors of B poses
+// Residual vectors of B poses at once (finite-difference Jacobian of the least-squares path:
+// scipy's 2-point scheme needs D+1 evaluations per iteration, optimize.py:510-528).  Each point
+// is loaded once; the pose records are read with wave-uniform (scalar) loads.
+// out[b][i] = (uo - u_b, vo - v_b), b-major.
+// Round 5: RV points per lane through the population kernel's stages (norm_coords, distort_group: the float64 forms of round 5
+// -- one reciprocal for both denominators, v_div_fixup -- and RV independent chains between a transcendental and its use)
+// instead of one point through project_norm.
+#ifndef RES_V
+#define RES_V 2
+#endif
+template <typename T>
+__global__ __launch_bounds__(256) void residual_batch_kernel(const T *__restrict__ x, const T *__restrict__ y,
+                                                             const T *__restrict__ z, const T *__restrict__ uo,
+                                                             const T *__restrict__ vo, double2 *__restrict__ out,
+                                                             int64_t n, const PoseRec<T> *__restrict__ poses, int B) {
+    constexpr int V = RES_V;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * V;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x * V + threadIdx.x; base < n; base += stride) {
+        T qx[V], qy[V], qz[V], ou[V], ov[V];
+        int64_t idx[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int64_t i = base + (int64_t)j * blockDim.x;
+            idx[j] = i < n ? i : -1;
+            const int64_t k = i < n ? i : base;            // a lane's first point always exists
+            qx[j] = x[k]; qy[j] = y[k]; qz[j] = z[k]; ou[j] = uo[k]; ov[j] = vo[k];
+        }
+        for (int b = 0; b < B; ++b) {
+            const T *r = poses[b].v;
+            NormCoords<T, V> nc;
+            norm_coords<T, V>(r, qx, qy, qz, nc);
+            T xd[V], yd[V];
+            distort_group<T, V>(r, nc, xd, yd);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                T u, v;
+                to_pixels<T>(r, xd[j], yd[j], u, v);
+                if (idx[j] >= 0)      // written once, read by the copy engine
+                    Num<double>::nt_store(make_double2((double)(ou[j] - u), (double)(ov[j] - v)), out + ((int64_t)b * n + idx[j]));
+            }
+        }
+    }
 }
 
 // TS = element type of the planes in HBM, T = arithmetic type (TS = float with T = double is the

@@ -423,6 +423,20 @@ int fetch_converted_t(alp_points *p, D *u_out, D *v_out) {
     return ALP_OK;
 }
 
+}  // namespace
+namespace alp {
+void points_release_staging() {
+    for (auto &b : g_fetch_stage) {
+        if (b) hipHostFree(b);
+        b = nullptr;
+    }
+    for (auto &e : g_fetch_ev) {
+        if (e) hipEventDestroy(e);
+        e = nullptr;
+    }
+}
+}  // namespace alp
+namespace {
 int fetch_converted(alp_points *p, void *u_out, void *v_out, int out_dtype) {
     return out_dtype == ALP_F64 ? fetch_converted_t<float, double>(p, (double *)u_out, (double *)v_out)
                                 : fetch_converted_t<double, float>(p, (float *)u_out, (float *)v_out);

