@@ -117,10 +117,12 @@ const char *alp_build_flags(void);
 /* ---------------------------------------------------------------- multi-GPU (RCCL) ---- */
 /* One process per GPU.  Rank 0 calls alp_comm_unique_id and ships the 128 bytes to the
  * other ranks by any means (the Python side: a localhost socket served by its own launcher, alproj_amd/launch.py, a
- * shared file, or a torch.distributed process group -- alproj_amd/dist.py); every rank then
+ * shared file, or any callable that broadcasts 128 bytes -- alproj_amd/dist.py); every rank then
  * calls alp_comm_init.  With a communicator present, alp_eval_population sums the
  * per-candidate partial losses and the vertex counts of all ranks with ONE
- * ncclAllReduce(sum, double, P+1) per call, on the library stream. */
+ * ncclAllReduce(sum, double, P+1) per call, on the library stream.
+ * A failed ncclCommInitRank returns ALP_ERCCL and alp_last_error() then holds RCCL's error string, ncclGetLastError's
+ * text, this rank's world position, HIP device and PCI bus id, and the environment RCCL / ROCr read. */
 #define ALP_UNIQUE_ID_BYTES 128
 int alp_comm_unique_id(char id[ALP_UNIQUE_ID_BYTES]);
 int alp_comm_init(const char id[ALP_UNIQUE_ID_BYTES], int rank, int world_size);
@@ -166,7 +168,9 @@ int alp_points_set_observed(alp_points_t *pts, const void *uv, int in_dtype);
  * :8-44, extrinsic_mat :46-96 and _distort :98-120 fused into one kernel).
  * Results stay on the device (planar u[], v[] in the set's precision) ... */
 int alp_project(alp_points_t *pts, const double params[ALP_NPARAM]);
-/* ... until fetched: u_out/v_out are host arrays of n elements of out_dtype (F32/F64). */
+/* ... until fetched: u_out/v_out are host arrays of n elements of out_dtype (F32/F64).  out_dtype may differ from the set's
+ * precision (the reference's float64 from a float32 set): the narrower type crosses PCIe -- widened by host threads while the
+ * next chunk arrives, narrowed on the device -- and no temporary of the result's size is made. */
 int alp_projected_fetch(alp_points_t *pts, void *u_out, void *v_out, int out_dtype);
 /* Fetch a strided sample (indices first, first+stride, ...; count elements). */
 int alp_projected_fetch_strided(alp_points_t *pts, int64_t first, int64_t stride,

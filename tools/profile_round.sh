@@ -13,6 +13,7 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_
 timeout 300 rocprofv3 --kernel-trace --pmc TCC_ATOMIC_sum TCP_TOTAL_ATOMIC_WITHOUT_RET_sum SQ_INSTS_VMEM_WR SQ_INSTS_SALU -d gpurun_out/prof_$R/raster2 -o p -- python3 tools/probe_raster.py 100000000 5 > gpurun_out/prof_$R/raster2.log 2>&1 </dev/null
 python3 tools/rocpd_summary.py gpurun_out/prof_$R/raster1/p_results.db "" --csv gpurun_out/prof_$R/${R}_raster_frame_kernels_sq.csv > /dev/null
 python3 tools/rocpd_summary.py gpurun_out/prof_$R/raster2/p_results.db "" --csv gpurun_out/prof_$R/${R}_raster_frame_kernels_atomics.csv > /dev/null
+python3 tools/raster_binding_roof.py gpurun_out/prof_$R/${R}_raster_frame_kernels_sq.csv gpurun_out/prof_$R/${R}_raster_frame_kernels_atomics.csv > gpurun_out/prof_$R/${R}_raster_binding_roof.json
 # 3. HBM traffic (FETCH_SIZE / WRITE_SIZE passes)
 python3 tools/pmc_traffic.py gpurun_out/prof_$R/${R}_raster_implicit_grid_pmc_traffic.json 3 "raster_,resolve_,hiz_,tile_plan,tile_occ" -- python3 tools/probe_raster.py 100000000 3 > /dev/null 2>&1 </dev/null
 python3 tools/pmc_traffic.py gpurun_out/prof_$R/${R}_raster_int32_indices_pmc_traffic.json 3 "raster_,resolve_" -- python3 tools/probe_raster.py 100000000 3 explicit > /dev/null 2>&1 </dev/null
