@@ -189,9 +189,11 @@ _SIGNATURES = {
     "alp_comm_allgather_counts": [_c_i64, ctypes.POINTER(_c_i64)],
     "alp_comm_allgatherv": [_c_void_p, _c_void_p, ctypes.POINTER(_c_i64)],
     "alp_points_create": [_c_void_p, _c_int, _c_i64, _c_dp, _c_int, ctypes.POINTER(_c_void_p)],
+    "alp_points_create_columns": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_i64, _c_dp, _c_int, ctypes.POINTER(_c_void_p)],
     "alp_points_destroy": [_c_void_p],
     "alp_points_count": [_c_void_p, ctypes.POINTER(_c_i64)],
     "alp_points_set_observed": [_c_void_p, _c_void_p, _c_int],
+    "alp_points_set_observed_columns": [_c_void_p, _c_void_p, _c_void_p, _c_int],
     "alp_project": [_c_void_p, _c_dp],
     "alp_projected_fetch": [_c_void_p, _c_void_p, _c_void_p, _c_int],
     "alp_projected_fetch_strided": [_c_void_p, _c_i64, _c_i64, _c_i64, _c_dp, _c_dp],
@@ -352,24 +354,52 @@ def dtype_code(a):
 PRECISIONS = {"f32": ALP_F32, "f64": ALP_F64, ALP_F32: ALP_F32, ALP_F64: ALP_F64}
 
 
+def _same_float_columns(cols, k):
+    """k one-dimensional contiguous columns of one float type (float32 only if all of them are) and one length"""
+    cols = [np.asarray(c) for c in cols]
+    if len(cols) != k or any(c.ndim != 1 for c in cols) or len({len(c) for c in cols}) != 1:
+        raise ValueError(f"need {k} one-dimensional columns of one length")
+    dt = np.float32 if all(c.dtype == np.float32 for c in cols) else np.float64
+    return [np.ascontiguousarray(c, dtype=dt) for c in cols]
+
+
 class Points:
     """Device-resident point set (RAII wrapper of alp_points_t)."""
 
-    def __init__(self, xyz, origin, precision="f32"):
+    def __init__(self, xyz, origin, precision="f32", _columns=None):
+        """xyz: an (N, 3) array -- uploaded as it lies when it is row-major, and column by column when its COLUMNS are the
+        contiguous runs (the transposed view pandas hands out for a block of float columns): no host-side interleaving or
+        transposition either way.  ``Points.from_columns(x, y, z, ...)`` takes three 1-D columns."""
         l = lib()
-        xyz = np.ascontiguousarray(xyz)
-        if xyz.dtype not in (np.float32, np.float64):
-            xyz = xyz.astype(np.float64)
-        if xyz.ndim != 2 or xyz.shape[1] != 3:
-            raise ValueError("xyz must have shape (N, 3)")
-        self.n = int(xyz.shape[0])
+        cols = _columns
+        if cols is None:
+            xyz = np.asarray(xyz)
+            if xyz.ndim != 2 or xyz.shape[1] != 3:
+                raise ValueError("xyz must have shape (N, 3)")
+            if xyz.dtype not in (np.float32, np.float64):
+                xyz = xyz.astype(np.float64)
+            if not xyz.flags["C_CONTIGUOUS"] and xyz.shape[0] > 1 and all(xyz[:, k].flags["C_CONTIGUOUS"] for k in range(3)):
+                cols = [xyz[:, k] for k in range(3)]
         self.precision = PRECISIONS[precision]
         self.origin = np.ascontiguousarray(origin, dtype=np.float64).reshape(3)
         h = _c_void_p()
-        check(l.alp_points_create(xyz.ctypes.data_as(_c_void_p), dtype_code(xyz), self.n,
-                                  as_dp(self.origin), self.precision, ctypes.byref(h)))
+        if cols is not None:
+            cols = _same_float_columns(cols, 3)
+            self.n = int(len(cols[0]))
+            check(l.alp_points_create_columns(*[c.ctypes.data_as(_c_void_p) for c in cols], dtype_code(cols[0]), self.n,
+                                              as_dp(self.origin), self.precision, ctypes.byref(h)))
+        else:
+            xyz = np.ascontiguousarray(xyz)
+            self.n = int(xyz.shape[0])
+            check(l.alp_points_create(xyz.ctypes.data_as(_c_void_p), dtype_code(xyz), self.n,
+                                      as_dp(self.origin), self.precision, ctypes.byref(h)))
         self._h = h
         self._lib = l
+
+    @classmethod
+    def from_columns(cls, x, y, z, origin, precision="f32"):
+        """The point set from its three columns as they lie (alp_points_create_columns)"""
+        return cls(None, origin, precision, _columns=[x, y, z])
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -385,12 +415,24 @@ class Points:
         self.close()
 
     def set_observed(self, uv):
-        uv = np.ascontiguousarray(uv)
+        """uv: (N, 2), row-major or with contiguous columns (uploaded column by column then)"""
+        uv = np.asarray(uv)
         if uv.dtype not in (np.float32, np.float64):
             uv = uv.astype(np.float64)
         if uv.shape != (self.n, 2):
             raise ValueError(f"observed uv must have shape ({self.n}, 2)")
+        if not uv.flags["C_CONTIGUOUS"] and self.n > 1 and uv[:, 0].flags["C_CONTIGUOUS"] and uv[:, 1].flags["C_CONTIGUOUS"]:
+            return self.set_observed_columns(uv[:, 0], uv[:, 1])
+        uv = np.ascontiguousarray(uv)
         check(self._lib.alp_points_set_observed(self._h, uv.ctypes.data_as(_c_void_p), dtype_code(uv)))
+
+    def set_observed_columns(self, u, v):
+        """the observed pixels from their two columns as they lie (alp_points_set_observed_columns)"""
+        cols = _same_float_columns([u, v], 2)
+        if len(cols[0]) != self.n:
+            raise ValueError(f"observed u, v must have {self.n} elements")
+        check(self._lib.alp_points_set_observed_columns(self._h, cols[0].ctypes.data_as(_c_void_p), cols[1].ctypes.data_as(_c_void_p),
+                                                        dtype_code(cols[0])))
 
     def project(self, pvec):
         pvec = np.ascontiguousarray(pvec, dtype=np.float64)

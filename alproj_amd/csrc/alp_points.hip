@@ -111,6 +111,47 @@ int upload_any(const void *host, int in_dtype, int64_t n, const double o[3], int
     return fail(ALP_EINVAL, "in_dtype must be ALP_F32 or ALP_F64");
 }
 
+// One host COLUMN (n contiguous values of TIn) -> one device plane of T, minus its origin component in float64: the columns of a
+// table as they lie (a pandas block is columns x rows: a DataFrame's x, y, z are three contiguous runs), no host-side
+// interleaving.  Same chunking as upload_columns.
+template <typename TIn, typename T>
+__global__ __launch_bounds__(256) void column_to_plane_kernel(const TIn *__restrict__ src, int64_t count, int64_t dst_off, double o,
+                                                              T *__restrict__ plane) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+        plane[dst_off + i] = (T)((double)src[i] - o);
+}
+
+template <typename TIn, typename T>
+int upload_planes_t(const void *const *cols, int ncols, int64_t n, const double *o, void *const *planes) {
+    const int64_t CH = 48 << 20;                      // values per staging chunk (192 MB of float32)
+    const int64_t ch = n < CH ? (n > 0 ? n : 1) : CH;
+    TIn *stage = nullptr;
+    ALP_HIP(hipMalloc((void **)&stage, (size_t)ch * sizeof(TIn)));
+    int rc = ALP_OK;
+    for (int c = 0; c < ncols && !rc; ++c)
+        for (int64_t off = 0; off < n; off += ch) {
+            const int64_t cnt = (n - off < ch) ? (n - off) : ch;
+            hipError_t e = hipMemcpyAsync(stage, (const TIn *)cols[c] + off, (size_t)cnt * sizeof(TIn), hipMemcpyHostToDevice, ctx().stream);
+            if (e != hipSuccess) { rc = fail(ALP_EHIP, "H2D upload: %s", hipGetErrorString(e)); break; }
+            const int grid = (int)((cnt + 255) / 256 < 4096 ? (cnt + 255) / 256 : 4096);
+            hipLaunchKernelGGL((column_to_plane_kernel<TIn, T>), dim3(grid), dim3(256), 0, ctx().stream, stage, cnt, off, o[c], (T *)planes[c]);
+            e = hipGetLastError();                    // the staging buffer is reused in stream order
+            if (e != hipSuccess) { rc = fail(ALP_EHIP, "upload kernel: %s", hipGetErrorString(e)); break; }
+        }
+    if (hipStreamSynchronize(ctx().stream) != hipSuccess && !rc) rc = fail(ALP_EHIP, "upload: stream failed");
+    hipFree(stage);
+    return rc;
+}
+
+int upload_planes(const void *const *cols, int ncols, int in_dtype, int64_t n, const double *o, int precision, void *const *planes) {
+    if (in_dtype == ALP_F64 && precision == ALP_F64) return upload_planes_t<double, double>(cols, ncols, n, o, planes);
+    if (in_dtype == ALP_F64 && precision == ALP_F32) return upload_planes_t<double, float>(cols, ncols, n, o, planes);
+    if (in_dtype == ALP_F32 && precision == ALP_F64) return upload_planes_t<float, double>(cols, ncols, n, o, planes);
+    if (in_dtype == ALP_F32 && precision == ALP_F32) return upload_planes_t<float, float>(cols, ncols, n, o, planes);
+    return fail(ALP_EINVAL, "in_dtype must be ALP_F32 or ALP_F64");
+}
+
 int stream_grid(int64_t items) {
     // memory-bound streaming kernels: enough workgroups to fill 256 CUs x 8, grid-stride beyond
     const int64_t want = (items + 255) / 256;
@@ -445,13 +486,14 @@ int fetch_converted(alp_points *p, void *u_out, void *v_out, int out_dtype) {
 
 extern "C" {
 
-int alp_points_create(const void *xyz, int in_dtype, int64_t n, const double origin[3], int precision,
-                      alp_points_t **out) {
+// xyz: n x 3 row-major (cols == NULL), or cols[0..2]: the three columns as they lie
+static int points_create(const void *xyz, const void *const *cols, int in_dtype, int64_t n, const double origin[3], int precision,
+                         alp_points_t **out) {
     if (int rc = require_init()) return rc;
     ALP_REQUIRE(out, "out is NULL");
     *out = nullptr;
     ALP_REQUIRE(n >= 0, "n is negative");
-    ALP_REQUIRE(n == 0 || xyz, "xyz is NULL");
+    ALP_REQUIRE(n == 0 || xyz || (cols && cols[0] && cols[1] && cols[2]), "coordinates are NULL");
     ALP_REQUIRE(origin, "origin is NULL");
     ALP_REQUIRE(precision == ALP_F32 || precision == ALP_F64, "precision must be ALP_F32 or ALP_F64");
     ALP_REQUIRE(in_dtype == ALP_F32 || in_dtype == ALP_F64, "in_dtype must be ALP_F32 or ALP_F64");
@@ -463,7 +505,11 @@ int alp_points_create(const void *xyz, int in_dtype, int64_t n, const double ori
     int rc = ALP_OK;
     for (void **pl : {&p->x, &p->y, &p->z, &p->u, &p->v})
         if ((rc = alloc_plane(pl, p->n_pad, p->esize()))) break;
-    if (!rc && n > 0) rc = upload_any<3>(xyz, in_dtype, n, origin, precision, p->x, p->y, p->z);
+    if (!rc && n > 0) {
+        void *const planes[3] = {p->x, p->y, p->z};
+        rc = cols ? upload_planes(cols, 3, in_dtype, n, origin, precision, planes)
+                  : upload_any<3>(xyz, in_dtype, n, origin, precision, p->x, p->y, p->z);
+    }
     if (!rc) {
         hipError_t e = hipStreamSynchronize(ctx().stream);
         if (e != hipSuccess) rc = fail(ALP_EHIP, "points upload: %s", hipGetErrorString(e));
@@ -474,6 +520,17 @@ int alp_points_create(const void *xyz, int in_dtype, int64_t n, const double ori
     }
     *out = p;
     return ALP_OK;
+}
+
+int alp_points_create(const void *xyz, int in_dtype, int64_t n, const double origin[3], int precision,
+                      alp_points_t **out) {
+    return points_create(xyz, nullptr, in_dtype, n, origin, precision, out);
+}
+
+int alp_points_create_columns(const void *x, const void *y, const void *z, int in_dtype, int64_t n, const double origin[3],
+                              int precision, alp_points_t **out) {
+    const void *const cols[3] = {x, y, z};
+    return points_create(nullptr, cols, in_dtype, n, origin, precision, out);
 }
 
 int alp_points_destroy(alp_points_t *p) {
@@ -510,6 +567,24 @@ int alp_points_set_observed(alp_points_t *p, const void *uv, int in_dtype) {
     const double zero[3] = {0, 0, 0};
     if (p->n > 0)
         if (int rc = upload_any<2>(uv, in_dtype, p->n, zero, p->precision, p->uo, p->vo, nullptr)) return rc;
+    ALP_HIP(hipStreamSynchronize(ctx().stream));
+    return ALP_OK;
+}
+
+int alp_points_set_observed_columns(alp_points_t *p, const void *u, const void *v, int in_dtype) {
+    if (int rc = require_init()) return rc;
+    ALP_REQUIRE(p, "points handle is NULL");
+    ALP_REQUIRE(p->n == 0 || (u && v), "u or v is NULL");
+    ALP_REQUIRE(in_dtype == ALP_F32 || in_dtype == ALP_F64, "in_dtype must be ALP_F32 or ALP_F64");
+    if (!p->uo) {
+        if (int rc = alloc_plane(&p->uo, p->n_pad, p->esize())) return rc;
+        if (int rc = alloc_plane(&p->vo, p->n_pad, p->esize())) return rc;
+    }
+    const double zero[2] = {0, 0};
+    const void *const cols[2] = {u, v};
+    void *const planes[2] = {p->uo, p->vo};
+    if (p->n > 0)
+        if (int rc = upload_planes(cols, 2, in_dtype, p->n, zero, p->precision, planes)) return rc;
     ALP_HIP(hipStreamSynchronize(ctx().stream));
     return ALP_OK;
 }

@@ -71,16 +71,51 @@ def _camera_origin(params):
     return np.array([float(params["x"]), float(params["y"]), float(params["z"])])
 
 
+def _columns(frame, names):
+    """The named columns of a DataFrame as the device upload takes them, WITHOUT the copies of the reference's
+    `obj_points[["x", "y", "z"]]` + `np.array(...)` (optimize.py:139-141; 96 ms for 10 M rows on one core): a frame that holds
+    exactly these float64 columns hands out its block -- an (N, k) array, row-major or the transposed view of a columns x rows
+    block, both of which `_lib.Points` uploads as they lie; any other frame gives its columns one by one."""
+    if list(frame.columns) == list(names) and all(dt == np.float64 for dt in frame.dtypes):
+        a = frame.to_numpy(copy=False)
+        if a.flags["C_CONTIGUOUS"] or all(a[:, k].flags["C_CONTIGUOUS"] for k in range(a.shape[1])):
+            return a
+    return [np.ascontiguousarray(frame[c].to_numpy(dtype=np.float64)) for c in names]
+
+
 def _xyz_array(obj_points):
     if isinstance(obj_points, pd.DataFrame):
-        return np.ascontiguousarray(obj_points[["x", "y", "z"]].to_numpy(dtype=np.float64))
-    return np.ascontiguousarray(obj_points, dtype=np.float64)
+        return _columns(obj_points, ["x", "y", "z"])
+    return np.asarray(obj_points, dtype=np.float64)
 
 
 def _uv_array(img_points):
     if isinstance(img_points, pd.DataFrame):
-        return np.ascontiguousarray(img_points[["u", "v"]].to_numpy(dtype=np.float64))
-    return np.ascontiguousarray(img_points, dtype=np.float64)
+        return _columns(img_points, ["u", "v"])
+    return np.asarray(img_points, dtype=np.float64)
+
+
+def _rows(a):
+    return len(a[0]) if isinstance(a, list) else len(a)
+
+
+def _points(xyz, origin, precision):
+    """device point set from what _xyz_array returned: an (N, 3) array or a list of three columns"""
+    if isinstance(xyz, list):
+        return _lib.Points.from_columns(xyz[0], xyz[1], xyz[2], origin, precision)
+    return _lib.Points(xyz, origin, precision)
+
+
+def _set_observed(pts, uv):
+    if isinstance(uv, list):
+        pts.set_observed_columns(uv[0], uv[1])
+    else:
+        pts.set_observed(uv)
+
+
+def _as_rows(a):
+    """(N, k) row-major float64 for the few callers that need the array itself"""
+    return np.ascontiguousarray(np.column_stack(a) if isinstance(a, list) else a, dtype=np.float64)
 
 
 # ------------------------------------------------------------------------------------------
@@ -109,14 +144,14 @@ def project(obj_points, params, precision="f64"):
     ``"f32"`` streams 20 B/vertex and is accurate to ~1e-3 px.
     """
     xyz = _xyz_array(obj_points)
-    with _lib.Points(xyz, _camera_origin(params), precision) as pts:
+    with _points(xyz, _camera_origin(params), precision) as pts:
         pts.project(_lib.params_vector(params))
         u, v = pts.fetch(np.float64)
-    return pd.DataFrame({"u": u, "v": v})
+    return pd.DataFrame({"u": u, "v": v}, copy=False)      # the two result arrays ARE the columns (no 16 N-byte copy)
 
 
 def _loss_uv(img_points, projected, kind, f_scale):
-    obs = _uv_array(img_points)
+    obs = _as_rows(_uv_array(img_points))
     prj = np.ascontiguousarray(
         projected.to_numpy(dtype=np.float64) if isinstance(projected, pd.DataFrame) else projected,
         dtype=np.float64)
@@ -142,8 +177,8 @@ def huber_loss(img_points, projected, f_scale=10.0):
 def compute_residuals(obj_points, img_points, params):
     """Flattened residual vector (observed - projected), reference optimize.py:215-237."""
     xyz = _xyz_array(obj_points)
-    with _lib.Points(xyz, _camera_origin(params), "f64") as pts:
-        pts.set_observed(_uv_array(img_points))
+    with _points(xyz, _camera_origin(params), "f64") as pts:
+        _set_observed(pts, _uv_array(img_points))
         return pts.residuals(_lib.params_vector(params))
 
 
@@ -187,8 +222,8 @@ class BaseOptimizer:
     # -- device-resident copy of the GCPs, shared by both optimisers -------------------------
     def _device_points(self, precision=None):
         xyz = _xyz_array(self.obj_points)
-        pts = _lib.Points(xyz, _camera_origin(self.params_init), default_precision(len(xyz), precision))
-        pts.set_observed(_uv_array(self.img_points))
+        pts = _points(xyz, _camera_origin(self.params_init), default_precision(_rows(xyz), precision))
+        _set_observed(pts, _uv_array(self.img_points))
         return pts
 
     def _candidate_matrix(self, values):

@@ -762,6 +762,17 @@ def main():
                   "roofline": {"bound": "hbm", "achieved": len(x10) * 20 / k10 / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                "frac": len(x10) * 20 / k10 / HBM_PEAK, "kernel_ms": k10 * 1e3, "frac_at_median": len(x10) * 20 / med10 / HBM_PEAK}}
             out["roofline"].update({"c2_gpoints_per_s_kernel_median": c2["gpoints_per_s_kernel_median"], "c2_hbm_frac_at_median": c2["roofline"]["frac_at_median"]})
+            # SURVEY 8(d) c2 "end-to-end incl. H2D / D2H": the reference's own call, optimize.project(DataFrame[x, y, z], params) ->
+            # DataFrame[u, v] (float64 in, float64 out, the float64 point set that is its default)
+            import pandas as pd
+            from alproj_amd import optimize as aopt
+            df10 = pd.DataFrame(x10.astype(np.float64), columns=["x", "y", "z"])
+            aopt.project(df10.iloc[:1000], t10)                        # warm-up of the small things
+            t_call = best_of(lambda: aopt.project(df10, t10), 2)
+            c2["dropin_project_call"] = {"call": "optimize.project(DataFrame(10 M x 3 float64), params) -> DataFrame[u, v] float64",
+                                         "seconds": t_call, "gpoints_per_s": len(df10) / t_call / 1e9,
+                                         "reference_seconds_survey_container": 1.98}
+            del df10
             uu, vv = p10.fetch(np.float32)
             o10 = np.stack([uu, vv], 1) + np.random.default_rng(1).normal(0, 1.0, (len(x10), 2)).astype(np.float32)
             o10[~np.isfinite(o10)] = 0.0

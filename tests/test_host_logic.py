@@ -124,6 +124,31 @@ def test_default_precision_is_the_references_float64_at_gcp_scale(monkeypatch):
     assert made == [(len(g["xyz"]), "f32")]
 
 
+def test_table_columns_reach_the_upload_without_host_copies():
+    """optimize._columns: a frame of exactly the float64 columns hands out its block (row-major, or the transposed view of a
+    columns x rows block -- both uploaded as they lie); other frames give their columns one by one.  No GPU."""
+    rng = np.random.default_rng(0)
+    a = rng.random((1000, 3))
+    f1 = pd.DataFrame(a, columns=["x", "y", "z"])
+    g1 = opt._xyz_array(f1)
+    assert isinstance(g1, np.ndarray) and g1.flags["C_CONTIGUOUS"] and np.shares_memory(g1, f1.to_numpy(copy=False))
+    f2 = pd.DataFrame({"x": a[:, 0].copy(), "y": a[:, 1].copy(), "z": a[:, 2].copy()})
+    g2 = opt._xyz_array(f2)
+    if isinstance(g2, np.ndarray):       # pandas consolidated the three columns into one block: its transposed view
+        assert not g2.flags["C_CONTIGUOUS"] and all(g2[:, k].flags["C_CONTIGUOUS"] for k in range(3))
+    else:
+        assert len(g2) == 3 and all(c.flags["C_CONTIGUOUS"] for c in g2)
+    np.testing.assert_array_equal(opt._as_rows(g2), a)
+    f3 = pd.DataFrame({"id": np.arange(1000), "z": a[:, 2], "x": a[:, 0], "y": a[:, 1]})
+    g3 = opt._xyz_array(f3)
+    assert isinstance(g3, list) and opt._rows(g3) == 1000
+    np.testing.assert_array_equal(opt._as_rows(g3), a)
+    f4 = pd.DataFrame({"u": a[:, 0].astype(np.float32), "v": a[:, 1]})          # mixed types: per column, as float64
+    g4 = opt._uv_array(f4)
+    assert isinstance(g4, list) and all(c.dtype == np.float64 for c in g4)
+    assert opt._rows(np.zeros((7, 3))) == 7 and opt._xyz_array(a) is a
+
+
 def test_lsq_argument_errors_need_no_gpu():
     o = opt.LsqOptimizer(pd.DataFrame(np.zeros((3, 3)), columns=["x", "y", "z"]),
                          pd.DataFrame(np.zeros((3, 2)), columns=["u", "v"]), {k: 1.0 for k in orc.PARAM_KEYS})
