@@ -204,6 +204,7 @@ _SIGNATURES = {
     "alp_eval_population_wait": [_c_void_p, _c_dp, ctypes.POINTER(_c_i64)],
     "alp_eval_population_timing": [_c_void_p, _c_fp, _c_fp],
     "alp_loss_uv": [_c_dp, _c_dp, _c_i64, _c_int, _c_double, _c_dp],
+    "alp_loss_uv_columns": [_c_dp, _c_dp, _c_dp, _c_dp, _c_i64, _c_int, _c_double, _c_dp],
     "alp_cma_sample": [_c_dp, _c_double, _c_dp, _c_dp, _c_dp, _c_int, _c_i64, _c_int, ctypes.c_uint64, ctypes.c_uint64, _c_dp,
                        ctypes.POINTER(ctypes.c_int32)],
     "alp_mesh_create": [_c_void_p, _c_int, _c_void_p, _c_int, _c_i64, _c_void_p, _c_int, _c_i64, _c_i64, _c_i64,

@@ -589,16 +589,21 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__re
     if (blockIdx.x == 0 && threadIdx.x == 0) sums[P] = n_local;
 }
 
-// Stand-alone loss of two interleaved (n x 2) float64 arrays: one float64 partial per workgroup.
-template <int LOSS>
-__global__ __launch_bounds__(256) void loss_uv_kernel(const double2 *__restrict__ obs,
-                                                      const double2 *__restrict__ prj, int64_t n,
+// Stand-alone loss of two (n x 2) float64 arrays, each either interleaved (b == NULL: a holds u0 v0 u1 v1 ...) or as its two
+// columns (a = u[n], b = v[n]): one float64 partial per workgroup.  The order of the additions does not depend on the layout.
+template <int LOSS, bool OBS_COLUMNS, bool PRJ_COLUMNS>
+__global__ __launch_bounds__(256) void loss_uv_kernel(const double *__restrict__ obs_a, const double *__restrict__ obs_b,
+                                                      const double *__restrict__ prj_a, const double *__restrict__ prj_b, int64_t n,
                                                       double f_scale, double *__restrict__ partials) {
     __shared__ double s[4];
     double acc = 0.0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const double2 o = obs[i], q = prj[i];
+        double2 o, q;
+        if constexpr (OBS_COLUMNS) o = make_double2(obs_a[i], obs_b[i]);
+        else o = reinterpret_cast<const double2 *>(obs_a)[i];
+        if constexpr (PRJ_COLUMNS) q = make_double2(prj_a[i], prj_b[i]);
+        else q = reinterpret_cast<const double2 *>(prj_a)[i];
         const double du = o.x - q.x, dv = o.y - q.y;
         const double r = __builtin_sqrt(du * du + dv * dv);
         if constexpr (LOSS == ALP_LOSS_MEAN_DIST) acc += r;

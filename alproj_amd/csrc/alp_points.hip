@@ -658,8 +658,9 @@ int alp_residuals_batch(alp_points_t *p, const double *cand, int64_t B, double *
     return p->precision == ALP_F64 ? residuals_impl<double>(p, cand, B, out) : residuals_impl<float>(p, cand, B, out);
 }
 
-int alp_loss_uv(const double *observed, const double *projected, int64_t n, int loss_kind, double f_scale,
-                double *loss_out) {
+// obs_b / prj_b NULL: that array is interleaved (n x 2 row-major); else a = the u column, b = the v column
+static int loss_uv_any(const double *obs_a, const double *obs_b, const double *prj_a, const double *prj_b, int64_t n, int loss_kind,
+                       double f_scale, double *loss_out) {
     if (int rc = require_init()) return rc;
     ALP_REQUIRE(loss_out, "loss_out is NULL");
     ALP_REQUIRE(n >= 0, "n is negative");
@@ -668,32 +669,46 @@ int alp_loss_uv(const double *observed, const double *projected, int64_t n, int 
         *loss_out = NAN;
         return ALP_OK;
     }
-    ALP_REQUIRE(observed && projected, "NULL input");
+    ALP_REQUIRE(obs_a && prj_a, "NULL input");
     const int grid = stream_grid(n);
     char *dev = nullptr;
-    const size_t bytes = (size_t)n * sizeof(double2);
-    if (int rc = scratch_reserve(2 * bytes + (size_t)(grid + 2) * sizeof(double), (void **)&dev)) return rc;
-    double *partials = (double *)(dev + 2 * bytes);
-    hipError_t e = hipMemcpyAsync(dev, observed, bytes, hipMemcpyHostToDevice, ctx().stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(dev + bytes, projected, bytes, hipMemcpyHostToDevice, ctx().stream);
+    const size_t col = (size_t)n * sizeof(double);
+    if (int rc = scratch_reserve(4 * col + (size_t)(grid + 2) * sizeof(double), (void **)&dev)) return rc;
+    double *d_obs = (double *)dev, *d_prj = (double *)(dev + 2 * col);
+    double *partials = (double *)(dev + 4 * col);
+    hipStream_t st = ctx().stream;
+    hipError_t e = hipMemcpyAsync(d_obs, obs_a, obs_b ? col : 2 * col, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && obs_b) e = hipMemcpyAsync(d_obs + n, obs_b, col, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_prj, prj_a, prj_b ? col : 2 * col, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && prj_b) e = hipMemcpyAsync(d_prj + n, prj_b, col, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        if (loss_kind == ALP_LOSS_HUBER)
-            hipLaunchKernelGGL(loss_uv_kernel<ALP_LOSS_HUBER>, dim3(grid), dim3(256), 0, ctx().stream,
-                               (const double2 *)dev, (const double2 *)(dev + bytes), n, f_scale, partials);
-        else
-            hipLaunchKernelGGL(loss_uv_kernel<ALP_LOSS_MEAN_DIST>, dim3(grid), dim3(256), 0, ctx().stream,
-                               (const double2 *)dev, (const double2 *)(dev + bytes), n, f_scale, partials);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, ctx().stream, partials, grid, 1,
-                           (double)n, partials + grid);
+        using Kernel = void (*)(const double *, const double *, const double *, const double *, int64_t, double, double *);
+        static const Kernel kernels[2][2][2] = {
+            {{loss_uv_kernel<ALP_LOSS_MEAN_DIST, false, false>, loss_uv_kernel<ALP_LOSS_MEAN_DIST, false, true>},
+             {loss_uv_kernel<ALP_LOSS_MEAN_DIST, true, false>, loss_uv_kernel<ALP_LOSS_MEAN_DIST, true, true>}},
+            {{loss_uv_kernel<ALP_LOSS_HUBER, false, false>, loss_uv_kernel<ALP_LOSS_HUBER, false, true>},
+             {loss_uv_kernel<ALP_LOSS_HUBER, true, false>, loss_uv_kernel<ALP_LOSS_HUBER, true, true>}}};
+        hipLaunchKernelGGL(kernels[loss_kind == ALP_LOSS_HUBER][obs_b != nullptr][prj_b != nullptr], dim3(grid), dim3(256), 0, st,
+                           d_obs, d_obs + n, d_prj, d_prj + n, n, f_scale, partials);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, partials, grid, 1, (double)n, partials + grid);
         e = hipGetLastError();
     }
     double res[2] = {0, 0};
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(res, partials + grid, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx().stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx().stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(res, partials + grid, 2 * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return fail(ALP_EHIP, "alp_loss_uv: %s", hipGetErrorString(e));
     *loss_out = res[0] / (double)n;
     return ALP_OK;
+}
+
+int alp_loss_uv(const double *observed, const double *projected, int64_t n, int loss_kind, double f_scale,
+                double *loss_out) {
+    return loss_uv_any(observed, nullptr, projected, nullptr, n, loss_kind, f_scale, loss_out);
+}
+
+int alp_loss_uv_columns(const double *obs_u, const double *obs_v, const double *prj_u, const double *prj_v, int64_t n,
+                        int loss_kind, double f_scale, double *loss_out) {
+    return loss_uv_any(obs_u, obs_v, prj_u, prj_v, n, loss_kind, f_scale, loss_out);
 }
 
 int alp_eval_population_enqueue(alp_points_t *p, const double *cand, int64_t P, int loss_kind,

@@ -73,14 +73,17 @@ def _camera_origin(params):
 
 def _columns(frame, names):
     """The named columns of a DataFrame as the device upload takes them, WITHOUT the copies of the reference's
-    `obj_points[["x", "y", "z"]]` + `np.array(...)` (optimize.py:139-141; 96 ms for 10 M rows on one core): a frame that holds
-    exactly these float64 columns hands out its block -- an (N, k) array, row-major or the transposed view of a columns x rows
-    block, both of which `_lib.Points` uploads as they lie; any other frame gives its columns one by one."""
+    `obj_points[["x", "y", "z"]]` + `np.array(...)` (optimize.py:139-141; 96 ms for 10 M rows on one core): columns that lie
+    contiguous in the frame's blocks are handed out as they are (a list of 1-D views); a frame that IS a row-major (N, k)
+    float64 array hands out that array; only strided or non-float64 columns are copied, one by one."""
+    cols = [frame[c].to_numpy() for c in names]                   # views of the frame's blocks: nothing is copied yet
+    if all(c.dtype == np.float64 and c.flags["C_CONTIGUOUS"] for c in cols):
+        return cols                                                # columns x rows blocks (or one block per column): as they lie
     if list(frame.columns) == list(names) and all(dt == np.float64 for dt in frame.dtypes):
-        a = frame.to_numpy(copy=False)
-        if a.flags["C_CONTIGUOUS"] or all(a[:, k].flags["C_CONTIGUOUS"] for k in range(a.shape[1])):
+        a = frame.to_numpy(copy=False)                             # one block holding a row-major (N, k) array: as it lies
+        if a.flags["C_CONTIGUOUS"]:
             return a
-    return [np.ascontiguousarray(frame[c].to_numpy(dtype=np.float64)) for c in names]
+    return [np.ascontiguousarray(c, dtype=np.float64) for c in cols]
 
 
 def _xyz_array(obj_points):
@@ -150,16 +153,32 @@ def project(obj_points, params, precision="f64"):
     return pd.DataFrame({"u": u, "v": v}, copy=False)      # the two result arrays ARE the columns (no 16 N-byte copy)
 
 
+def _uv_pointers(a):
+    """(pointer to u or to the interleaved pairs, pointer to v or None, rows, what must stay alive) for alp_loss_uv_columns"""
+    if isinstance(a, list):
+        cols = [np.ascontiguousarray(c, dtype=np.float64) for c in a]
+        return _lib.as_dp(cols[0]), _lib.as_dp(cols[1]), len(cols[0]), cols
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim != 2 or a.shape[1] != 2:
+        raise ValueError("pixel coordinates must have shape (N, 2)")
+    if not a.flags["C_CONTIGUOUS"] and a.shape[0] > 1 and a[:, 0].flags["C_CONTIGUOUS"] and a[:, 1].flags["C_CONTIGUOUS"]:
+        cols = [a[:, 0], a[:, 1]]
+        return _lib.as_dp(cols[0]), _lib.as_dp(cols[1]), a.shape[0], cols
+    a = np.ascontiguousarray(a)
+    return _lib.as_dp(a), None, a.shape[0], a
+
+
 def _loss_uv(img_points, projected, kind, f_scale):
-    obs = _as_rows(_uv_array(img_points))
-    prj = np.ascontiguousarray(
-        projected.to_numpy(dtype=np.float64) if isinstance(projected, pd.DataFrame) else projected,
-        dtype=np.float64)
-    if obs.shape != prj.shape:
+    """rmse / huber_loss of two tables of pixel coordinates: each goes to the device as it lies -- row-major pairs or two
+    columns (what project() returns) -- through alp_loss_uv_columns; no host-side interleaving"""
+    prj = _columns(projected, ["u", "v"]) if isinstance(projected, pd.DataFrame) else projected
+    ou, ov, n_obs, keep_o = _uv_pointers(_uv_array(img_points))
+    pu, pv, n_prj, keep_p = _uv_pointers(prj)
+    if n_obs != n_prj:
         raise ValueError("img_points and projected must have the same shape")
     out = _lib.ctypes.c_double()
-    _lib.check(_lib.lib().alp_loss_uv(_lib.as_dp(obs), _lib.as_dp(prj), obs.shape[0], kind,
-                                      float(f_scale), _lib.ctypes.byref(out)))
+    _lib.check(_lib.lib().alp_loss_uv_columns(ou, ov, pu, pv, n_obs, kind, float(f_scale), _lib.ctypes.byref(out)))
+    del keep_o, keep_p
     return float(out.value)
 
 

@@ -771,8 +771,16 @@ def main():
             t_call = best_of(lambda: aopt.project(df10, t10), 2)
             c2["dropin_project_call"] = {"call": "optimize.project(DataFrame(10 M x 3 float64), params) -> DataFrame[u, v] float64",
                                          "seconds": t_call, "gpoints_per_s": len(df10) / t_call / 1e9,
+                                         "pcie_floor_seconds_at_56_GB_per_s": len(df10) * 40 / 56e9,
                                          "reference_seconds_survey_container": 1.98}
-            del df10
+            # ... and the reference's stand-alone losses on that result (optimize.py:157-212): two tables in, a float out
+            prj10 = aopt.project(df10, t10)
+            img10 = pd.DataFrame({"u": prj10["u"].to_numpy() + 0.5, "v": prj10["v"].to_numpy() - 0.25})
+            c2["dropin_loss_calls"] = {"rmse_seconds": best_of(lambda: aopt.rmse(img10, prj10), 2),
+                                       "huber_loss_seconds": best_of(lambda: aopt.huber_loss(img10, prj10, 10.0), 2),
+                                       "pcie_floor_seconds_at_56_GB_per_s": len(df10) * 32 / 56e9,
+                                       "reference_seconds_survey_container": {"rmse": 0.159, "huber_loss": 0.262}}
+            del df10, prj10, img10
             uu, vv = p10.fetch(np.float32)
             o10 = np.stack([uu, vv], 1) + np.random.default_rng(1).normal(0, 1.0, (len(x10), 2)).astype(np.float32)
             o10[~np.isfinite(o10)] = 0.0

@@ -187,6 +187,30 @@ def test_losses_golden(L):
     assert opt.huber_loss(dfo, dfp, 0.5) == pytest.approx(float(g["huber_0p5"]), rel=1e-13)
 
 
+def test_losses_take_either_table_layout(L):
+    """rmse / huber_loss (optimize.py:157-212) through alp_loss_uv_columns: row-major pairs, two columns (what project()
+    returns), DataFrames of either build, a mix of both -- the same bits every time, and the reference's value"""
+    from alproj_amd import optimize as opt
+    rng = np.random.default_rng(8)
+    n = 70_001
+    obs = rng.uniform(0, 5000, (n, 2))
+    prj = obs + rng.normal(0, 6.0, (n, 2))
+    forms_o = [obs, np.asfortranarray(obs), pd.DataFrame(obs, columns=["u", "v"]), pd.DataFrame({"u": obs[:, 0], "v": obs[:, 1]}),
+               pd.DataFrame({"v": obs[:, 1], "k": 1, "u": obs[:, 0]})]
+    forms_p = [prj, np.asfortranarray(prj), pd.DataFrame(prj, columns=["u", "v"]), pd.DataFrame({"u": prj[:, 0].copy(), "v": prj[:, 1].copy()}, copy=False)]
+    want_r, want_h = orc.mean_distance(obs, prj), orc.huber(obs, prj, 10.0)
+    seen = set()
+    for a in forms_o:
+        for b in forms_p:
+            seen.add((opt.rmse(a, b), opt.huber_loss(a, b, 10.0)))
+    assert len(seen) == 1
+    r, h = seen.pop()
+    assert r == pytest.approx(want_r, rel=1e-13) and h == pytest.approx(want_h, rel=1e-13)
+    with pytest.raises(ValueError):
+        opt.rmse(obs, prj[:-1])
+    assert np.isnan(opt.rmse(np.zeros((0, 2)), np.zeros((0, 2))))
+
+
 def test_residuals_golden(L):
     from alproj_amd import optimize as opt
     g = load("g8_residuals.npz")

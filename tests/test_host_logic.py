@@ -94,8 +94,14 @@ def test_default_precision_is_the_references_float64_at_gcp_scale(monkeypatch):
             made.append((len(xyz), precision))
             self.precision, self.n = (_lib.ALP_F64 if precision == "f64" else _lib.ALP_F32), len(xyz)
 
+        @classmethod
+        def from_columns(cls, x, y, z, origin, precision="f32"):
+            return cls(x, origin, precision)
+
         def set_observed(self, uv):
             pass
+
+        set_observed_columns = lambda self, u, v: None
 
         def eval_population(self, cand, kind, f_scale, want_argmin=True):
             return np.arange(len(cand), dtype=np.float64), 0
@@ -134,11 +140,12 @@ def test_table_columns_reach_the_upload_without_host_copies():
     assert isinstance(g1, np.ndarray) and g1.flags["C_CONTIGUOUS"] and np.shares_memory(g1, f1.to_numpy(copy=False))
     f2 = pd.DataFrame({"x": a[:, 0].copy(), "y": a[:, 1].copy(), "z": a[:, 2].copy()})
     g2 = opt._xyz_array(f2)
-    if isinstance(g2, np.ndarray):       # pandas consolidated the three columns into one block: its transposed view
-        assert not g2.flags["C_CONTIGUOUS"] and all(g2[:, k].flags["C_CONTIGUOUS"] for k in range(3))
-    else:
-        assert len(g2) == 3 and all(c.flags["C_CONTIGUOUS"] for c in g2)
+    assert isinstance(g2, list) and len(g2) == 3 and all(c.flags["C_CONTIGUOUS"] and np.shares_memory(c, f2[k].to_numpy()) for c, k in zip(g2, "xyz"))
     np.testing.assert_array_equal(opt._as_rows(g2), a)
+    u, v = a[:, 0].copy(), a[:, 1].copy()
+    f5 = pd.DataFrame({"u": u, "v": v}, copy=False)                 # what project() returns: one block per column
+    g5 = opt._uv_array(f5)
+    assert isinstance(g5, list) and np.shares_memory(g5[0], u) and np.shares_memory(g5[1], v)
     f3 = pd.DataFrame({"id": np.arange(1000), "z": a[:, 2], "x": a[:, 0], "y": a[:, 1]})
     g3 = opt._xyz_array(f3)
     assert isinstance(g3, list) and opt._rows(g3) == 1000
