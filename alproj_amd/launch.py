@@ -33,6 +33,7 @@ import sys
 import tempfile
 import threading
 import time
+from multiprocessing import AuthenticationError
 from multiprocessing.connection import Client, Listener
 
 __all__ = ["Hub", "Control", "spawn", "LaunchError", "gpu_nodes", "preflight"]
@@ -124,8 +125,15 @@ class Hub:
                 self.listener._listener._socket.settimeout(COLLECTIVE_TIMEOUT_S)
             except AttributeError:      # another Python's Listener internals: the launcher's wall-clock limit still holds
                 pass
-            for _ in range(self.world):
-                c = self.listener.accept()
+            joined = 0
+            while joined < self.world:
+                try:
+                    c = self.listener.accept()
+                except TimeoutError:
+                    raise LaunchError(f"only {joined} of {self.world} ranks reached the hub within {COLLECTIVE_TIMEOUT_S:.0f} s") from None
+                except (AuthenticationError, EOFError, ConnectionError):
+                    continue            # a stranger, or a rank of another job with that job's key: not ours, keep listening
+                joined += 1
                 op, rank = _recv(c)
                 if op != "hello" or not isinstance(rank, int) or not (0 <= rank < self.world) or conns[rank] is not None:
                     raise LaunchError(f"unexpected greeting {op!r} from rank {rank!r}")

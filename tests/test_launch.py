@@ -151,6 +151,29 @@ def test_hub_announcement_is_private_and_its_key_is_not_derivable(tmp_path, monk
     os.chmod(d, 0o700)
 
 
+def test_a_stranger_at_the_door_does_not_stop_the_hub():
+    """a connection that fails the key handshake (another job's rank, a port scanner) is turned away and the hub keeps
+    waiting for its own ranks"""
+    from multiprocessing.connection import Client
+    hub = launch.Hub(2).start()
+    with pytest.raises(Exception):
+        Client(hub.address, authkey=b"not the key of this hub")
+    s = socket.create_connection(hub.address)          # ... and one that says nothing at all
+    s.close()
+    res = []
+
+    def rank(r):
+        c = launch.Control(r, 2, r, launch.Control._connect(lambda: (hub.address, hub.authkey), r, 30.0))
+        res.append(c.gather(r))
+        c.close()
+
+    th = [threading.Thread(target=rank, args=(r,)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(30) for t in th]
+    hub.join(5)
+    assert hub.error is None and res == [[0, 1], [0, 1]]
+
+
 def test_nothing_received_is_unpickled():
     """a peer that knows the key and speaks pickle (Connection.send) gets an error; the hub does not build its object"""
     from multiprocessing.connection import Client
