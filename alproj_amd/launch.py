@@ -96,7 +96,8 @@ class Hub:
     def __init__(self, world, authkey=None, host="127.0.0.1"):
         self.world = int(world)
         self.authkey = authkey or os.urandom(16)
-        self.listener = Listener((host, 0), authkey=self.authkey)
+        # every rank knocks at once, before the serving thread exists (spawn starts the children first): room for all of them
+        self.listener = Listener((host, 0), backlog=max(16, 2 * self.world), authkey=self.authkey)
         self.address = self.listener.address          # (host, port) actually bound
         self.error = None
         self.collectives = 0
