@@ -252,12 +252,16 @@ def committed_summary(name):
     return None, None
 
 
-def expectation_from_one_gpu(n_gpus, measured_all_reduce_ms):
+def expectation_from_one_gpu(n_gpus, measured_all_reduce_ms, vertices=None, population=None):
     """For N > 1: what the committed N = 1 run predicts for this N -- kernel time / N (rows are sharded evenly, strong scaling)
     plus the all-reduce THIS run measured, the host share of a generation unchanged -- so that the first scaling curve can be
     read at a glance.  None without a committed N = 1 line."""
     one, src = committed_summary("bench_default_run")
     if not one or one.get("n_gpus") != 1:
+        return None
+    if vertices is not None and one.get("config", {}).get("vertices") != vertices:
+        return None                      # another workload than the committed line's: nothing to compare with
+    if population is not None and (one.get("cma") or {}).get("population") not in (None, population):
         return None
     r = dict(one.get("roofline_detail", {}), **one.get("roofline", {}))
     exp = {"source": src, "n_gpus": n_gpus, "rule": "kernel_ms(N=1) / N + all-reduce measured here; host share of a generation as at N = 1"}
@@ -980,7 +984,7 @@ def main():
         out["speedup_vs_cpu_baseline"] = gpts / out["cpu_baseline"]["value"]
 
     if ctl.world > 1 and ctl.rank == 0:
-        exp = expectation_from_one_gpu(ctl.world, out.get("cma", {}).get("all_reduce_ms"))
+        exp = expectation_from_one_gpu(ctl.world, out.get("cma", {}).get("all_reduce_ms"), n_total, args.pop if "cma" in out else None)
         if exp:
             exp["projection_measured_over_expected"] = (out["roofline"]["kernel_ms"] / exp["projection_kernel_ms"]) if exp.get("projection_kernel_ms") else None
             if "cma" in out and exp.get("cma_ms_per_iter"):

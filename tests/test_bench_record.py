@@ -72,5 +72,7 @@ def test_expectation_for_n_gpus_is_kernel_time_over_n(tmp_path, monkeypatch):
     e = bench.expectation_from_one_gpu(8, 0.05)
     assert e["projection_kernel_ms"] == pytest.approx(0.04) and e["projection_gpoints_per_s"] == pytest.approx(2500.0)
     assert e["cma_kernel_ms"] == pytest.approx(26.75) and e["cma_ms_per_iter"] == pytest.approx(26.75 + 0.05 + 2.0)
+    assert bench.expectation_from_one_gpu(8, 0.05, vertices=100_000_000)["cma_kernel_ms"] == pytest.approx(26.75)
+    assert bench.expectation_from_one_gpu(8, 0.05, vertices=4_000_000) is None          # another workload: no expectation
     monkeypatch.setattr(bench, "PROFILES", str(tmp_path / "nothing"))
     assert bench.expectation_from_one_gpu(8, 0.05) is None
