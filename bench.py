@@ -437,7 +437,7 @@ def next_rows_leg(L, syn, orc, df, ras_dev=None):
                      "unit": "GB/s", "frac": alg / (k_ms / 1e3) / HBM_PEAK, "kernel": "residual_batch_kernel<double>",
                      # SURVEY prices the row in bytes; what binds it is the float64 arithmetic of B projections per point:
                      "binding_roof": "valu_fp64", "pose_point_evals_per_s": n * B / (k_ms / 1e3),
-                     "note": "the float64 population kernel, same arithmetic, runs at 2.2e11 evaluations/s"},
+                     "note": "the float64 population kernel, same stages (norm_coords, distort_group) without the 16 B of residuals written per evaluation, runs at 3.7-3.9e11 evaluations/s"},
         "cpu_port": {"pose_point_residuals_per_s": ns / t_cpu, "sample": f"oracle.residual_vector, {ns} points, 1 pose, 1 core"}}
     del res, x10, s10
     # ---- f3: mesh construction from rasters at 10 000 x 10 000 (surface.py:173-212)
