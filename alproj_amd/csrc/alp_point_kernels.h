@@ -439,11 +439,12 @@ __device__ __forceinline__ T group_loss_sum(const T *r, const T (&qx)[V], const 
 // scipy's 2-point scheme needs D+1 evaluations per iteration, optimize.py:510-528).  Each point
 // is loaded once; the pose records are read with wave-uniform (scalar) loads.
 // out[b][i] = (uo - u_b, vo - v_b), b-major.
-// Round 5: RV points per lane through the population kernel's stages (norm_coords, distort_group: the float64 forms of round 5
+// Round 5: RES_V points per lane through the population kernel's stages (norm_coords, distort_group: the float64 forms of round 5
 // -- one reciprocal for both denominators, v_div_fixup -- and RV independent chains between a transcendental and its use)
 // instead of one point through project_norm.
+// 22 poses x 10 M points, float64, kernel ms on one box: RES_V = 1: 0.825 | 2: 0.834 | 3: 0.771 | 4: 0.782
 #ifndef RES_V
-#define RES_V 2
+#define RES_V 3
 #endif
 template <typename T>
 __global__ __launch_bounds__(256) void residual_batch_kernel(const T *__restrict__ x, const T *__restrict__ y,
