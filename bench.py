@@ -89,6 +89,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the reference-typed sim_image + reverse_proj call pair (9.6 GB of host arrays)")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the SURVEY 8(f) rows f1-f4 and the full-size pipeline")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two rocprofv3 --pmc passes of a child process, ~40 s): take the committed summary's")
     ap.add_argument("--launch-timeout", type=float, default=3000.0, help="wall-clock limit of a self-launched multi-rank job (s)")
     ap.add_argument("--debug-share-device", nargs="?", const="nocomm", default=None, choices=["nocomm", "rccl"],
                     help="DEVELOPMENT: all ranks use device 0.  'nocomm' (default): no RCCL communicator is made (RCCL refuses two ranks "
@@ -289,6 +291,47 @@ def pmc_traffic(name):
             except (OSError, ValueError):      # an unreadable summary must not stop the measurement
                 continue
     return None, None
+
+
+def live_traffic(vertices, timeout_s=170.0):
+    """roofline.traffic MEASURED in this run: HBM bytes per launch of the headline kernel from the PMC counters, collected as
+    MI355X_MICROARCH.md prescribes -- two separate `rocprofv3 --kernel-trace --pmc` passes (FETCH_SIZE, doubled on gfx950;
+    WRITE_SIZE) -- over a CHILD process (tools/probe_project.py: the same kernel on a DSM of the same size; this process
+    cannot put itself under the profiler).  Returns (bytes per launch, source) or (None, why not): the caller then falls back
+    on the committed summary.  The child is ended by PID if it outlives the limit."""
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not on PATH"
+    tool, probe = os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(ROOT, "tools", "probe_project.py")
+    if not (os.path.exists(tool) and os.path.exists(probe)):
+        return None, "tools/pmc_traffic.py or tools/probe_project.py missing"
+    out_json = os.path.join(tempfile.mkdtemp(prefix="alproj_pmc_"), "traffic.json")
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)        # the tool keeps its rocprof output there
+    cmd = [sys.executable, tool, out_json, "3", "project_kernel", "--", sys.executable, probe, str(vertices), "3", "f32"]
+    try:
+        p = subprocess.Popen(cmd, cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp"), stdin=subprocess.DEVNULL,
+                             stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+        try:
+            rc = p.wait(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, 15)                 # exactly the process group this call started
+            except OSError:
+                pass
+            p.wait(timeout=20)
+            return None, f"the PMC passes did not finish within {timeout_s:.0f} s"
+        if rc != 0:
+            return None, f"tools/pmc_traffic.py exited with {rc}"
+        doc = json.load(open(out_json))
+        k = [v for name, v in doc["kernels"].items() if "project_kernel<float>" in name]
+        if not k or not k[0].get("hbm_bytes_per_frame"):
+            return None, "no counters for project_kernel<float> in the passes"
+        return float(k[0]["hbm_bytes_per_frame"]), ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE (x 2 on gfx950) and WRITE_SIZE, separate "
+                                                    f"passes over tools/probe_project.py {vertices} 3 f32 (a child process, the same kernel and size)")
+    except Exception as e:                       # the measurement must never take the line down with it
+        return None, f"{type(e).__name__}: {e}"
 
 
 def cma_loop(L, CMA, pts, base, targets, bounds_fn, pop, loss_kind, f_scale, seed=1234):
@@ -991,8 +1034,19 @@ def main():
                 exp["cma_kernel_measured_over_expected"] = out["cma"]["roofline"]["kernel_ms"] / exp["cma_kernel_ms"]
                 exp["cma_ms_per_iter_measured_over_expected"] = out["cma"]["ms_per_iter"] / exp["cma_ms_per_iter"]
             out["expected_from_1gpu"] = exp
-    out["roofline"], out["roofline_detail"] = driver_roofline(out["roofline"])
     pts.close()
+    # roofline.traffic, live: after everything else (the GPU is idle, the big host arrays are still this process's own)
+    if ctl.world == 1 and args.precision == "f32" and not args.no_live_traffic and not args.debug_share_device:
+        t_pmc = time.perf_counter()
+        measured, why = live_traffic(n_total)
+        out["roofline"]["traffic_committed_summary"] = out["roofline"].get("traffic")
+        if measured is not None:
+            out["roofline"]["traffic"] = measured
+            out["roofline"]["traffic_source"] = why
+        else:
+            out["roofline"]["traffic_live_measurement_failed"] = why
+        out["roofline"]["traffic_live_seconds"] = time.perf_counter() - t_pmc
+    out["roofline"], out["roofline_detail"] = driver_roofline(out["roofline"])
     ctl.barrier()            # every rank has finished its collectives
     adist.shutdown()         # ncclCommDestroy (no-op without a communicator)
     ctl.close()

@@ -76,3 +76,16 @@ def test_expectation_for_n_gpus_is_kernel_time_over_n(tmp_path, monkeypatch):
     assert bench.expectation_from_one_gpu(8, 0.05, vertices=4_000_000) is None          # another workload: no expectation
     monkeypatch.setattr(bench, "PROFILES", str(tmp_path / "nothing"))
     assert bench.expectation_from_one_gpu(8, 0.05) is None
+
+
+def test_live_traffic_never_takes_the_line_down(monkeypatch):
+    """bench.live_traffic: without rocprofv3, or when its passes fail (this container has no GPU), the answer is (None, why)
+    and bench.py keeps the committed summary's figure"""
+    import shutil
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    got, why = bench.live_traffic(1_000_000)
+    assert got is None and "rocprofv3" in why
+    monkeypatch.undo()
+    if shutil.which("rocprofv3"):
+        got, why = bench.live_traffic(100_000, timeout_s=120.0)
+        assert got is None and why                              # no GPU here: the passes fail, the reason comes back
