@@ -29,6 +29,10 @@ float32 planes, row-sharded over the ranks (strong scaling: the total is fixed).
   `cpu_baseline` (rank 0, N=1 only): the numpy float64 restatement of the reference
         (oracle/ref_numpy.py) timed on this host on a bounded sample.
 
+  `roofline.traffic` (N=1): measured IN the run -- after the legs a child process runs the headline kernel on a DSM of the same
+        size under `rocprofv3 --kernel-trace --pmc` (FETCH_SIZE and WRITE_SIZE in separate passes; `--no-live-traffic` or a failure:
+        the committed summary's figure, and the line says which).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse

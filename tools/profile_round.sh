@@ -6,7 +6,7 @@ R=${1:-r03}
 export TMPDIR=/tmp
 mkdir -p gpurun_out/prof_$R
 # 1. kernel durations of the default bench run (what --stats prints), as csv
-timeout 1200 rocprofv3 --kernel-trace -d gpurun_out/prof_$R/bench -o p -- python3 bench.py --steps 200 --warmup 10 > gpurun_out/prof_$R/bench_under_rocprof.json 2> gpurun_out/prof_$R/bench.err </dev/null
+timeout 1200 rocprofv3 --kernel-trace -d gpurun_out/prof_$R/bench -o p -- python3 bench.py --steps 200 --warmup 10 --no-live-traffic > gpurun_out/prof_$R/bench_under_rocprof.json 2> gpurun_out/prof_$R/bench.err </dev/null
 python3 tools/rocpd_summary.py gpurun_out/prof_$R/bench/p_results.db "" --csv gpurun_out/prof_$R/${R}_bench_kernel_stats.csv > /dev/null
 # 2. the render frame: per-kernel durations + instruction / atomic counters (separate passes)
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS -d gpurun_out/prof_$R/raster1 -o p -- python3 tools/probe_raster.py 100000000 5 > gpurun_out/prof_$R/raster1.log 2>&1 </dev/null
