@@ -275,16 +275,8 @@ template <> struct PopCfg<float> : PopCfgT<float, POP_V, POP_TC, POP_MINW> {};
 #define POP_MINWD 1
 #endif
 template <> struct PopCfg<double> : PopCfgT<double, POP_VD, POP_TCD, POP_MINWD> {};
-// float64 forms of the evaluation (round 5; each measured on its own, profiles/r05_popeval_f64_isa_census.txt)
-#ifndef POP_F64_SHARED_RCP
-#define POP_F64_SHARED_RCP 1
-#endif
-#ifndef POP_F64_HORNER
-#define POP_F64_HORNER 1
-#endif
-#ifndef POP_F64_HUBER_MIN
-#define POP_F64_HUBER_MIN 1
-#endif
+// Q2 in the float64 evaluation (profiles/r05_popeval_f64_isa_census.txt: 0 saves 11 instructions of 83 and moves one pole-adjacent
+// fixture value by 1.3e-12 -- kept at 1, the reference's form)
 #ifndef POP_F64_Q2
 #define POP_F64_Q2 1
 #endif
@@ -355,33 +347,20 @@ __device__ __forceinline__ void distort_group(const T *r, const NormCoords<T, V>
     }
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-        if constexpr (sizeof(T) == 4 || POP_F64_SHARED_RCP) {
-            // one reciprocal for both denominators: 1/dx = dy / (dx dy), 1/dy = dx / (dx dy)  (float32: a quarter-rate
-            // v_rcp_f32 saved; float64: 3 multiplies instead of a second v_rcp_f64 + Newton steps + fix-up)
-            const T inv = N::rcp_pop(dx[j] * dy[j]);
-            const T idx = dy[j] * inv;
-            dy[j] = dx[j] * inv;
-            dx[j] = idx;
-        } else {
-            dx[j] = N::rcp_pop(dx[j]);
-            dy[j] = N::rcp_pop(dy[j]);
-        }
+        // one reciprocal for both denominators: 1/dx = dy / (dx dy), 1/dy = dx / (dx dy)  (float32: a quarter-rate
+        // v_rcp_f32 saved; float64, since round 5: 3 multiplies instead of a second v_rcp_f64 + Newton steps + fix-up)
+        const T inv = N::rcp_pop(dx[j] * dy[j]);
+        const T idx = dy[j] * inv;
+        dy[j] = dx[j] * inv;
+        dx[j] = idx;
     }
 #pragma unroll
     for (int j = 0; j < V; ++j) {
         // x1_d = x1 num/den + 2 p1 x y + 2 p2 r2 x^2 + r2 (s1 + s2 r2)   (optimize.py:112-116, Q1)
         const T t1 = r[20] * (x1[j] * y1[j]);             // 2 p1 x y       (shared by x and y)
-        if constexpr (sizeof(T) == 4 || POP_F64_HORNER) {
-            // r2 (2 p2 x^2 + s1 + s2 r2) + t1: one multiply fewer per coordinate pair
-            a[j] = N::fma(r2[j], N::fma(r[21], xx[j], N::fma(r[23], r2[j], r[22])), t1);
-            b[j] = N::fma(r2[j], N::fma(r[21], yy[j], N::fma(r[25], r2[j], r[24])), t1);
-        } else {
-            const T pp = r[21] * r2[j];                   // 2 p2 r2        (shared)
-            a[j] = N::fma(pp, xx[j], t1);
-            a[j] = N::fma(N::fma(r[23], r2[j], r[22]), r2[j], a[j]);
-            b[j] = N::fma(pp, yy[j], t1);
-            b[j] = N::fma(N::fma(r[25], r2[j], r[24]), r2[j], b[j]);
-        }
+        // r2 (2 p2 x^2 + s1 + s2 r2) + t1: one multiply fewer per coordinate pair than 2 p2 r2 formed on its own
+        a[j] = N::fma(r2[j], N::fma(r[21], xx[j], N::fma(r[23], r2[j], r[22])), t1);
+        b[j] = N::fma(r2[j], N::fma(r[21], yy[j], N::fma(r[25], r2[j], r[24])), t1);
         a[j] = N::fma(x1[j], nx[j] * dx[j], a[j]);
         b[j] = N::fma(y1[j], ny[j] * dy[j], b[j]);
     }
@@ -393,7 +372,7 @@ __device__ __forceinline__ void distort_group(const T *r, const NormCoords<T, V>
 template <typename T, int LOSS, int V, bool MASKED, bool SHARED_POSE>
 __device__ __forceinline__ T group_loss_sum(const T *r, const T (&qx)[V], const T (&qy)[V], const T (&qz)[V],
                                             const NormCoords<T, V> &pre, const T (&uoc)[V], const T (&voc)[V],
-                                            const bool (&ok)[V], T f_scale, T half_f2) {
+                                            const bool (&ok)[V], T f_scale) {
     using N = Num<T>;
     NormCoords<T, V> own;
     if constexpr (!SHARED_POSE) norm_coords<T, V>(r, qx, qy, qz, own);
@@ -414,23 +393,18 @@ __device__ __forceinline__ T group_loss_sum(const T *r, const T (&qx)[V], const 
     for (int j = 0; j < V; ++j) {
         if constexpr (LOSS == ALP_LOSS_MEAN_DIST) {
             acc += (MASKED && !ok[j]) ? (T)0 : dist[j];                                  // optimize.py:176
-        } else if constexpr (sizeof(T) == 4 || POP_F64_HUBER_MIN) {
+        } else {
             // Huber (optimize.py:207-211) without a branch: with c = min(r, f),
             // 0.5 c (2r - c) = 0.5 r^2 for r <= f and f (r - 0.5 f) beyond; a NaN r gives c = f and
             // a NaN term, an infinite r an infinite term, like np.where
-            // (float64: min, two fma instead of two multiplies, an fma, a compare, two selects and an add)
+            // (float64, since round 5: min and two fma instead of two multiplies, an fma, a compare, two selects and an add)
             const T c = sizeof(T) == 4 ? (T)__builtin_fminf((float)dist[j], (float)f_scale) : (T)__builtin_fmin((double)dist[j], (double)f_scale);
             const T t = N::fma((T)2, dist[j], -c);
             if (MASKED && !ok[j]) continue;
             acc = N::fma(c, t, acc);                      // twice the loss: halved once below (exact: a power of two)
-        } else {
-            const T quad = (T)0.5 * (dist[j] * dist[j]);
-            const T lin = N::fma(f_scale, dist[j], -half_f2);
-            // NaN <= f is false -> the linear branch propagates the NaN like np.where does
-            acc += (MASKED && !ok[j]) ? (T)0 : ((dist[j] <= f_scale) ? quad : lin);
         }
     }
-    if constexpr (LOSS != ALP_LOSS_MEAN_DIST && (sizeof(T) == 4 || POP_F64_HUBER_MIN)) acc *= (T)0.5;      // one multiply per V evaluations instead of one each
+    if constexpr (LOSS != ALP_LOSS_MEAN_DIST) acc *= (T)0.5;      // one multiply per V evaluations instead of one each
     return acc;
 }
 
@@ -486,8 +460,7 @@ template <typename T, int LOSS, int V, bool MASKED, bool SHARED_POSE, typename T
 __device__ __forceinline__ void pop_group(const TS *__restrict__ x, const TS *__restrict__ y,
                                           const TS *__restrict__ z, const TS *__restrict__ uo,
                                           const TS *__restrict__ vo, int64_t base, int64_t end,
-                                          const PoseRec<T> *s_c, double *s_sum_wave, int tc,
-                                          T f_scale, T half_f2) {
+                                          const PoseRec<T> *s_c, double *s_sum_wave, int tc, T f_scale) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     T qx[V], qy[V], qz[V], uoc[V], voc[V];
@@ -513,7 +486,7 @@ __device__ __forceinline__ void pop_group(const TS *__restrict__ x, const TS *__
 #pragma unroll
             for (int e = 0; e < Num<T>::VEC; ++e) r[k * Num<T>::VEC + e] = vget<T>(t, e);
         }
-        T acc = group_loss_sum<T, LOSS, V, MASKED, SHARED_POSE>(r, qx, qy, qz, pre, uoc, voc, ok, f_scale, half_f2);
+        T acc = group_loss_sum<T, LOSS, V, MASKED, SHARED_POSE>(r, qx, qy, qz, pre, uoc, voc, ok, f_scale);
         acc = wave_sum_to_lane63(acc);
         if (lane == 63) s_sum_wave[c] += (double)acc;
     }
@@ -530,7 +503,6 @@ __global__ __launch_bounds__(256, Cfg::MINW) void popeval_kernel(
     __shared__ double s_sum[4][TC];
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
-    const T half_f2 = (T)0.5 * f_scale * f_scale;
 
     // stripe of this workgroup: multiples of 256 points so that only the last stripe is ragged
     const int64_t rows = (n + 255) / 256;
@@ -554,12 +526,12 @@ __global__ __launch_bounds__(256, Cfg::MINW) void popeval_kernel(
         int64_t base = beg;
         const PoseRec<T> *recs = s_c;
         for (; base + 256 * V <= end; base += 256 * V)
-            pop_group<T, LOSS, V, false, SHARED_POSE, TS>(x, y, z, uo, vo, base, end, recs, s_sum[wave], tc, f_scale, half_f2);
+            pop_group<T, LOSS, V, false, SHARED_POSE, TS>(x, y, z, uo, vo, base, end, recs, s_sum[wave], tc, f_scale);
         if constexpr (V > 2)       // the rows left over by the wide groups, two at a time
             for (; base + 512 <= end; base += 512)
-                pop_group<T, LOSS, 2, false, SHARED_POSE, TS>(x, y, z, uo, vo, base, end, recs, s_sum[wave], tc, f_scale, half_f2);
+                pop_group<T, LOSS, 2, false, SHARED_POSE, TS>(x, y, z, uo, vo, base, end, recs, s_sum[wave], tc, f_scale);
         for (; base < end; base += 256)
-            pop_group<T, LOSS, 1, true, SHARED_POSE, TS>(x, y, z, uo, vo, base, end, recs, s_sum[wave], tc, f_scale, half_f2);
+            pop_group<T, LOSS, 1, true, SHARED_POSE, TS>(x, y, z, uo, vo, base, end, recs, s_sum[wave], tc, f_scale);
         __syncthreads();
         if (tid < tc)
             partials[(int64_t)blockIdx.x * P + c0 + tid] =

@@ -47,7 +47,6 @@ __global__ __launch_bounds__(256) void popeval_lc_kernel(const float *__restrict
         }
     }
     const float c0 = cands[0].v[26], c1 = cands[0].v[27];      // identical in every record of a call
-    const float half_f2 = 0.5f * f_scale * f_scale;
     const int64_t beg = (int64_t)blockIdx.x * stripe;
     const int64_t end = beg + stripe < n ? beg + stripe : n;
     double acc64[CPL];
@@ -73,7 +72,7 @@ __global__ __launch_bounds__(256) void popeval_lc_kernel(const float *__restrict
             }
 #pragma unroll
             for (int k = 0; k < CPL; ++k)
-                acc[k] += group_loss_sum<float, LOSS, V, false, false>(r[k], qx, qy, qz, none, uoc, voc, ok, f_scale, half_f2);
+                acc[k] += group_loss_sum<float, LOSS, V, false, false>(r[k], qx, qy, qz, none, uoc, voc, ok, f_scale);
         }
 #pragma unroll
         for (int k = 0; k < CPL; ++k) acc64[k] += (double)acc[k];
@@ -87,7 +86,7 @@ __global__ __launch_bounds__(256) void popeval_lc_kernel(const float *__restrict
             const bool ok[1] = {true};
 #pragma unroll
             for (int k = 0; k < CPL; ++k)
-                acc[k] += group_loss_sum<float, LOSS, 1, false, false>(r[k], qx, qy, qz, none1, uoc, voc, ok, f_scale, half_f2);
+                acc[k] += group_loss_sum<float, LOSS, 1, false, false>(r[k], qx, qy, qz, none1, uoc, voc, ok, f_scale);
         }
 #pragma unroll
         for (int k = 0; k < CPL; ++k) acc64[k] += (double)acc[k];
