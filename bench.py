@@ -141,11 +141,12 @@ def launch_times(L, fn, launches=24):
     return np.array([L.event_elapsed_ms(2 + i, 3 + i) for i in range(launches)])
 
 
-def selftest(ctl, args):
+def selftest(ctl, args, emit=print):
     """The stub worker of --launch-selftest: what a rank does with the control plane around the real benchmark --
     rendezvous of a 128-byte id from rank 0, barriers, a max over ranks, a gather -- without GPU or library."""
     import hashlib
     print(f"selftest: rank {ctl.rank} pid {os.getpid()}", file=sys.stderr, flush=True)
+    os.write(1, b"selftest: a library writes to file descriptor 1 (as RCCL does with its banner): this must not reach stdout\n")
     uid = ctl.bcast_bytes(bytes((7 * i + 1) % 256 for i in range(128)) if ctl.rank == 0 else b"\0" * 128)
     ctl.barrier()
     if ctl.rank == args.selftest_fail_rank:
@@ -160,7 +161,7 @@ def selftest(ctl, args):
                        "env": {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}})
     ctl.close()
     if ctl.rank == 0:
-        print(json.dumps({"selftest": True, "n_gpus": ctl.world, "max_over_ranks": worst, "ranks": recs}), flush=True)
+        emit(json.dumps({"selftest": True, "n_gpus": ctl.world, "max_over_ranks": worst, "ranks": recs}))
 
 
 def cpu_model():
@@ -572,13 +573,23 @@ def main():
                 print(f"bench.py: build skipped: {e}", file=sys.stderr)
         sys.exit(launch.spawn([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, timeout_s=args.launch_timeout))
 
+    # ONE JSON line on stdout, whatever the libraries underneath print: RCCL writes its banner and NCCL_DEBUG output to file
+    # descriptor 1 (the GPU boxes export NCCL_DEBUG=VERSION), which would land in front of the line as soon as a communicator
+    # is made.  From here on descriptor 1 IS stderr; the line goes to the saved descriptor at the very end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(real_stdout, (line + "\n").encode())
+
     ctl = launch.Control.from_env()
     if ctl.world != args.gpus:
         if ctl.rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ctl.world}", file=sys.stderr)
         sys.exit(2)
     if args.launch_selftest:
-        return selftest(ctl, args)
+        return selftest(ctl, args, emit)
 
     if ctl.local_rank == 0 and ctl.world == 1:  # harness convenience: (re)build a missing/stale library (the launcher did it for its ranks)
         try:
@@ -1054,8 +1065,9 @@ def main():
     ctl.barrier()            # every rank has finished its collectives
     adist.shutdown()         # ncclCommDestroy (no-op without a communicator)
     ctl.close()
+    sys.stdout.flush()
     if ctl.rank == 0:
-        print(json.dumps(out))
+        emit(json.dumps(out))
 
 
 if __name__ == "__main__":
