@@ -292,6 +292,16 @@ def lib():
     return init()
 
 
+def device_count():
+    """HIP devices this process can see (alp_device_count; 0 without a driver or a GPU)"""
+    n = _c_int()
+    try:
+        check(load().alp_device_count(ctypes.byref(n)))
+    except AlprojHipError:
+        return 0
+    return int(n.value)
+
+
 def device_info():
     l = lib()
     name = ctypes.create_string_buffer(128)

@@ -20,6 +20,7 @@ The reduction contract itself (``combine_partials``) is plain numpy so that it c
 on CPU with the gloo backend (tests/test_dist_gloo.py).
 """
 import os
+import sys
 import time
 
 import numpy as np
@@ -66,7 +67,16 @@ def combine_partials(reduced):
 # ------------------------------------------------------------------------------------------
 def init_comm(rank, world_size, bcast_bytes, device=None):
     """Initialise the library on ``device`` (default LOCAL_RANK) and create the communicator.
-    ``bcast_bytes(b: bytes) -> bytes`` must return rank 0's argument on every rank."""
+    ``bcast_bytes(b: bytes) -> bytes`` must return rank 0's argument on every rank.
+
+    A launcher may give every rank a device of its own by restricting what the rank SEES (``HIP_VISIBLE_DEVICES=k`` per
+    rank): then the one visible device is number 0 whatever LOCAL_RANK says."""
+    if world_size > 1:
+        want = device if device is not None else int(os.environ.get("LOCAL_RANK", "0"))
+        if want >= 1 and _lib.device_count() == 1:
+            print(f"alproj_amd.dist: rank {rank} sees ONE device ({os.environ.get('HIP_VISIBLE_DEVICES', os.environ.get('ROCR_VISIBLE_DEVICES'))!r} "
+                  f"visible): using it as device 0 instead of device {want}", file=sys.stderr, flush=True)
+            device = 0
     _lib.init(device)
     if world_size <= 1:
         return

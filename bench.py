@@ -634,7 +634,7 @@ def main():
         comm_rank, comm_world = ctl.rank, ctl.world
     # the communicator the LIBRARY reports must be the job: a rank that fell back to a world of its own would add
     # nothing to the all-reduce and the line would still look plausible
-    device = 0 if args.debug_share_device else ctl.local_rank
+    device = L._device if L._device is not None else (0 if args.debug_share_device else ctl.local_rank)   # where alp_init really went
     print(f"bench.py: rank {ctl.rank}/{ctl.world} on device {device} ({info.get('pci_bus_id')}): rccl rank {comm_rank} of {comm_world}"
           + (" [--debug-share-device: no communicator]" if args.debug_share_device else ""),
           file=sys.stderr, flush=True)
