@@ -101,6 +101,9 @@ def parse():
                          "on one GPU): walks the multi-rank control flow of this script on a 1-GPU box; the line it prints is marked and "
                          "means nothing.  'rccl': ncclCommInitRank IS called and fails -- shows what a failed RCCL set-up prints and "
                          "that every rank ends")
+    ap.add_argument("--debug-comm-world1", action="store_true",
+                    help="DEVELOPMENT (N = 1): make a REAL RCCL communicator of one rank, so that every population evaluation goes "
+                         "through ncclAllReduce on the library stream -- all a 1-GPU box can show of the collective's cost inside the loop")
     ap.add_argument("--debug-fail-comm-init-rank", type=int, default=-1,
                     help="DEVELOPMENT: this rank gives up right before alp_comm_init (its peers are then inside ncclCommInitRank "
                          "waiting for it): the launcher must end them")
@@ -628,6 +631,9 @@ def main():
             # one block per rank, RCCL's own text included (alp_comm_init); the launcher ends the other ranks
             print(f"bench.py: rank {ctl.rank}/{ctl.world} (LOCAL_RANK {ctl.local_rank}) could not set up: {e}", file=sys.stderr, flush=True)
             sys.exit(5)
+    if args.debug_comm_world1 and ctl.world == 1:
+        L.comm_init(L.comm_unique_id(), 0, 1)
+        print("bench.py: --debug-comm-world1: a one-rank RCCL communicator exists; alp_eval_population all-reduces through it", file=sys.stderr, flush=True)
     info = L.device_info()
     comm_rank, comm_world = L.comm_info()
     if args.debug_share_device == "nocomm":
@@ -752,7 +758,8 @@ def main():
             "population": args.pop, "dims": len(targets), "loss": "huber f_scale=10",
             "point_candidate_evals_per_s": n_total * args.pop * k_cma / wall_c,
             "best_loss_last_generation": state.get("best"),
-            "collective": "ncclAllReduce(sum, f64, P+1) per generation" if ctl.world > 1 else "none (1 GPU)",
+            "collective": "ncclAllReduce(sum, f64, P+1) per generation" if ctl.world > 1 else
+                          ("ncclAllReduce(sum, f64, P+1) per generation over a ONE-rank communicator (--debug-comm-world1)" if args.debug_comm_world1 else "none (1 GPU)"),
             "all_reduce_ms": ar_ms, "all_reduce_share_of_generation": ar_ms / (wall_c / k_cma * 1e3),
             "host_ms_per_generation": {"ask": state["t_ask"] / n_gen * 1e3, "eval_call": state["t_eval"] / n_gen * 1e3,
                                        "tell": state["t_tell"] / n_gen * 1e3},
