@@ -187,6 +187,25 @@ def test_losses_golden(L):
     assert opt.huber_loss(dfo, dfp, 0.5) == pytest.approx(float(g["huber_0p5"]), rel=1e-13)
 
 
+def test_float32_observations_into_a_float64_set(L):
+    """alp_points_set_observed with float32 pixels on a float64 point set (the one aos_to_planes instantiation the suite
+    had not launched): the observations are widened exactly"""
+    from alproj_amd import synthetic as syn
+    truth = syn.truth_params(316)
+    xyz = syn.gcp_points(3001, truth, seed=5)
+    uv32 = (orc.project_points(xyz, truth) + np.random.default_rng(5).normal(0, 1.0, (3001, 2))).astype(np.float32)
+    cand = np.stack([L.params_vector(truth), L.params_vector(dict(truth, pan=truth["pan"] + 0.3))])
+    with L.Points(xyz, [truth["x"], truth["y"], truth["z"]], "f64") as a, L.Points(xyz, [truth["x"], truth["y"], truth["z"]], "f64") as b:
+        a.set_observed(uv32)
+        b.set_observed(uv32.astype(np.float64))
+        la, _ = a.eval_population(cand, L.LOSS_HUBER, 10.0)
+        lb, _ = b.eval_population(cand, L.LOSS_HUBER, 10.0)
+        np.testing.assert_array_equal(la, lb)
+        np.testing.assert_array_equal(a.residuals(cand[1]), b.residuals(cand[1]))
+    ref = orc.huber(uv32.astype(np.float64), orc.project_points(xyz, orc.vector_to_params(cand[1])), 10.0)
+    assert la[1] == pytest.approx(ref, rel=1e-9)
+
+
 def test_losses_take_either_table_layout(L):
     """rmse / huber_loss (optimize.py:157-212) through alp_loss_uv_columns: row-major pairs, two columns (what project()
     returns), DataFrames of either build, a mix of both -- the same bits every time, and the reference's value"""

@@ -38,6 +38,22 @@ def test_unbounded_draws_have_the_requested_mean_and_covariance(L):
     assert abs(np.mean(z ** 3)) < 0.03 and abs(np.mean(z ** 4) - 3.0) < 0.08
 
 
+def test_thirty_dimensions(L):
+    """D in (24, 32]: the widest instantiation of cma_sample_kernel (the reference optimises at most 21 parameters; the
+    sampler takes up to 32) -- same statistics, same box rule"""
+    rng = np.random.default_rng(30)
+    D, P = 30, 60_000
+    cov, BD = _bd(rng, D)
+    mean = rng.uniform(-1, 1, D)
+    x = L.cma_sample(mean, 0.5, BD, None, P, 100, seed=3, generation=1)
+    assert x.shape == (P, D) and np.isfinite(x).all()
+    np.testing.assert_allclose(x.mean(0), mean, atol=6 * 0.5 * np.sqrt(np.diag(cov).max() / P))
+    np.testing.assert_allclose(np.cov(x.T), 0.25 * cov, rtol=0.06, atol=0.06 * 0.25 * np.abs(cov).max())
+    b = np.column_stack([mean - 0.4, mean + 0.4])
+    y = L.cma_sample(mean, 0.5, BD, b, 500, 100, seed=3, generation=1)
+    assert ((y >= b[:, 0]) & (y <= b[:, 1])).all()
+
+
 def test_deterministic_and_keyed_by_seed_generation_candidate(L):
     rng = np.random.default_rng(1)
     D = 21

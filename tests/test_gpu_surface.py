@@ -309,3 +309,26 @@ def test_mesh_from_rasters_any_shape(L, shape, dsm_dtype):
     np.testing.assert_array_equal(vert, (ev - eoff).astype(np.float32))
     np.testing.assert_array_equal(col, (aerial.reshape(3, -1).T.astype(np.float64) / 255.0).astype(np.float32))
     np.testing.assert_array_equal(valid, ~nodata.ravel())
+
+
+@pytest.mark.parametrize("aerial_dtype,div", [(np.uint16, 65535.0), (np.float32, 1.0)])
+def test_mesh_from_rasters_float64_dsm_with_wide_aerial_types(L, aerial_dtype, div):
+    """the float64-DSM instantiations of surface_build_kernel for uint16 and float32 aerial bands (tools/kernel_coverage.py found
+    them unlaunched by the suite): the numpy expressions of surface.py:173-193 bit for bit"""
+    rows, cols = 21, 34
+    rng = np.random.default_rng(77)
+    dsm = 900 + rng.normal(0, 12, (rows, cols))                                          # float64
+    aerial = (rng.random((3, rows, cols)) * (60000 if aerial_dtype == np.uint16 else 1.0)).astype(aerial_dtype)
+    nodata = rng.random((rows, cols)) < 0.15
+    t = (1.0, 0.0, 500.0, 0.0, -1.0, 700.0 + rows)
+    zmax = 950.0
+    mesh, off = L.Mesh.from_rasters(dsm, t, zmax, aerial, div, nodata)
+    with mesh:
+        vert, col, valid = mesh.fetch_arrays()
+    z = np.clip(dsm, 0, zmax)
+    xx, yy = np.meshgrid(np.arange(cols) * t[0] + t[2], np.arange(rows) * t[4] + t[5])
+    ev = np.stack([xx.ravel(), z.ravel(), yy.ravel()], axis=1)
+    np.testing.assert_array_equal(off, ev.min(axis=0))
+    np.testing.assert_array_equal(vert, (ev - ev.min(axis=0)).astype(np.float32))
+    np.testing.assert_array_equal(col, (aerial.reshape(3, -1).T.astype(np.float64) / div).astype(np.float32))
+    np.testing.assert_array_equal(valid, ~nodata.ravel())
