@@ -30,3 +30,31 @@ def built_library():
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def abi_call_coverage():
+    """ALP_ABI_COVERAGE=<file>: record which entry points of the C ABI the session calls (every ctypes function of
+    alproj_amd._lib is wrapped by a counting closure) and write the ones that were never called.  Off by default."""
+    out = os.environ.get("ALP_ABI_COVERAGE")
+    if not out:
+        yield
+        return
+    from alproj_amd import _lib
+    lib = _lib.load()
+    calls = {name: 0 for name in _lib._SIGNATURES}
+
+    def wrap(name, fn):
+        def counted(*a):
+            calls[name] += 1
+            return fn(*a)
+        return counted
+
+    for name in calls:
+        setattr(lib, name, wrap(name, getattr(lib, name)))
+    yield
+    never = sorted(n for n, c in calls.items() if c == 0)
+    with open(out, "w") as f:
+        f.write(f"{len(calls) - len(never)} of {len(calls)} entry points of the C ABI were called by this session; never called: {never}\n")
+        for n in sorted(calls):
+            f.write(f"{calls[n]:9d}  {n}\n")
