@@ -58,3 +58,37 @@ def abi_call_coverage():
         f.write(f"{len(calls) - len(never)} of {len(calls)} entry points of the C ABI were called by this session; never called: {never}\n")
         for n in sorted(calls):
             f.write(f"{calls[n]:9d}  {n}\n")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def python_line_coverage():
+    """ALP_PY_COVERAGE=<file>: which lines of alproj_amd/*.py the session executes (a sys.settrace collector restricted to the
+    package's files; no coverage tool is installed here).  Writes "path:line" of every executed line; tools/py_coverage.py
+    merges several such files and lists the lines never executed.  Off by default."""
+    out = os.environ.get("ALP_PY_COVERAGE")
+    if not out:
+        yield
+        return
+    import threading
+    pkg = os.path.join(ROOT, "alproj_amd") + os.sep
+    seen = set()
+
+    def local(frame, event, arg):
+        if event == "line":
+            seen.add((frame.f_code.co_filename, frame.f_lineno))
+        return local
+
+    def tracer(frame, event, arg):
+        if frame.f_code.co_filename.startswith(pkg):
+            seen.add((frame.f_code.co_filename, frame.f_lineno))
+            return local
+        return None
+
+    sys.settrace(tracer)
+    threading.settrace(tracer)
+    yield
+    sys.settrace(None)
+    threading.settrace(None)
+    with open(out, "w") as f:
+        for path, line in sorted(seen):
+            f.write(f"{os.path.relpath(path, ROOT)}:{line}\n")

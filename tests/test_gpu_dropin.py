@@ -313,3 +313,26 @@ def test_new_entry_points_report_misuse(L, scene):
         assert L.kernel_time_ms() == (0.0, 0)
     L.kernel_timing(False)
     assert L.build_flags() == ""
+
+
+def test_timing_records_and_the_wrappers_refusals(L, scene):
+    """project.set_timing (what bench.py reads: stage seconds and the frame's device ms) and the ValueErrors the wrappers share
+    with the reference (project.py:357-359: channel count; numpy's concatenate error for an image of another size)"""
+    from alproj_amd import project as aproj
+    aproj.set_timing(True)
+    try:
+        sim = aproj.sim_image(scene["vert64"], scene["col64"], scene["ind64"], scene["params"], scene["offsets"])
+        t = dict(aproj.LAST_TIMING)
+        assert {"mesh_s", "enqueue_s", "fetch_s", "device_ms", "resident", "resolve_only"} <= set(t) and 0 < t["device_ms"] < 1000
+        df = aproj.reverse_proj(sim, scene["vert64"], scene["ind64"], scene["params"], scene["offsets"])
+        assert {"fetch_s", "frame_s", "device_ms"} <= set(aproj.LAST_TIMING) and len(df) > 0
+    finally:
+        aproj.set_timing(False)
+    assert not aproj.LAST_TIMING
+    with pytest.raises(ValueError, match="chnames has length"):
+        aproj.reverse_proj(sim, scene["vert64"], scene["ind64"], scene["params"], scene["offsets"], chnames=["B", "G"])
+    with pytest.raises(ValueError, match="must match exactly"):
+        aproj.reverse_proj(sim[:-1], scene["vert64"], scene["ind64"], scene["params"], scene["offsets"])
+    with aproj.reverse_proj_device(scene["vert64"], scene["ind64"], scene["params"], scene["offsets"]) as rp:
+        with pytest.raises(ValueError, match="must match exactly"):
+            rp.rasterize(sim[:-1], ["B", "G", "R"])

@@ -332,3 +332,66 @@ def test_mesh_from_rasters_float64_dsm_with_wide_aerial_types(L, aerial_dtype, d
     np.testing.assert_array_equal(vert, (ev - ev.min(axis=0)).astype(np.float32))
     np.testing.assert_array_equal(col, (aerial.reshape(3, -1).T.astype(np.float64) / div).astype(np.float32))
     np.testing.assert_array_equal(valid, ~nodata.ravel())
+
+
+def _stand_in_rasterio(monkeypatch, fill_value=900.0):
+    import sys
+    import types
+
+    def merge(datasets, bounds=None, res=None, resampling=None):
+        return datasets[0].data.copy(), datasets[0].transform
+
+    def fillnodata(arr, mask, max_search_distance=None):
+        out = arr.copy()
+        out[~mask] = fill_value
+        return out
+
+    mods = {"rasterio": types.ModuleType("rasterio"), "rasterio.merge": types.ModuleType("rasterio.merge"),
+            "rasterio.enums": types.ModuleType("rasterio.enums"), "rasterio.fill": types.ModuleType("rasterio.fill")}
+    mods["rasterio.merge"].merge = merge
+    mods["rasterio.enums"].Resampling = types.SimpleNamespace(cubic_spline="cubic_spline")
+    mods["rasterio.fill"].fillnodata = fillnodata
+    for k, v in mods.items():
+        monkeypatch.setitem(sys.modules, k, v)
+
+
+class _Dataset:
+    def __init__(self, data, nodata, transform):
+        self.data, self.nodata, self.transform = data, nodata, transform
+        self.dtypes = tuple(str(data.dtype) for _ in range(data.shape[0]))
+
+
+def test_get_colored_surface_integer_rasters_and_its_refusals(L, monkeypatch):
+    """the branches of get_colored_surface (surface.py:69-121, 160-171) the g11 rasters do not take: INTEGER rasters whose
+    nodata is a value (the DSM's nodata vertices masked and filled, the aerial's zeroed), rasters without any nodata, the
+    transform-mismatch refusal and the large-area warning -- against the numpy expressions of the reference"""
+    from alproj_amd import surface as asurf
+    _stand_in_rasterio(monkeypatch, fill_value=900)
+    rng = np.random.default_rng(9)
+    rows = cols = 20
+    t = (1.0, 0.0, -10.0, 0.0, -1.0, 10.0)
+    dsm = rng.integers(800, 1000, (1, rows, cols)).astype(np.int16)
+    dsm[0, 3:6, 4:9] = -9999                                       # the DSM's nodata VALUE
+    aerial = rng.integers(1, 255, (3, rows, cols)).astype(np.uint8)
+    aerial[:, 0, 0] = 255                                           # the aerial's nodata value: zeroed (:102-106)
+    mesh, _, _, off = asurf.get_colored_surface(_Dataset(aerial, 255, t), _Dataset(dsm, -9999, t), {"x": 0.0, "y": 0.0}, distance=10, res=1.0)
+    with mesh:
+        vert, col, valid = mesh.fetch_arrays()
+    nod = dsm[0] == -9999
+    np.testing.assert_array_equal(valid, ~nod.ravel())
+    z = np.where(nod, 900, dsm[0]).astype(np.float64)               # fillnodata's stand-in
+    z = np.clip(z, 0, dsm[0][~nod].max())                           # :169, :175-176
+    assert off[1] == z.min() and np.array_equal(vert[:, 1], (z.ravel() - z.min()).astype(np.float32))
+    a0 = aerial.copy()
+    a0[a0 == 255] = 0
+    np.testing.assert_array_equal(col, (a0.reshape(3, -1).T.astype(np.float64) / 255.0).astype(np.float32))
+    # no nodata anywhere: no mask at all
+    dsm2 = rng.integers(800, 1000, (1, rows, cols)).astype(np.int32)
+    mesh, _, _, _ = asurf.get_colored_surface(_Dataset(aerial, None, t), _Dataset(dsm2, None, t), {"x": 0.0, "y": 0.0}, distance=10, res=1.0)
+    with mesh:
+        assert mesh.fetch_arrays()[2].all()
+    with pytest.raises(ValueError, match="Transform mismatch"):
+        asurf.get_colored_surface(_Dataset(aerial, None, t), _Dataset(dsm2, None, (1.0, 0.0, -11.0, 0.0, -1.0, 10.0)), {"x": 0.0, "y": 0.0}, distance=10, res=1.0)
+    with pytest.warns(UserWarning, match="Requested area is very large"):
+        mesh, _, _, _ = asurf.get_colored_surface(_Dataset(aerial, None, t), _Dataset(dsm2, None, t), {"x": 0.0, "y": 0.0}, distance=6000, res=1.0)
+        mesh.close()

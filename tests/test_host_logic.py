@@ -156,6 +156,54 @@ def test_table_columns_reach_the_upload_without_host_copies():
     assert opt._rows(np.zeros((7, 3))) == 7 and opt._xyz_array(a) is a
 
 
+def test_init_comm_and_the_file_rendezvous_without_a_gpu(monkeypatch, tmp_path):
+    """alproj_amd.dist.init_comm / init_from_file with the library stood in for: rank 0's 128 bytes reach every rank, every rank
+    initialises its device first, and a rank that SEES one device although LOCAL_RANK >= 1 (a launcher isolating ranks by
+    HIP_VISIBLE_DEVICES) takes device 0"""
+    import threading
+    from alproj_amd import _lib
+    from alproj_amd import dist as adist
+    log = []
+    monkeypatch.setattr(_lib, "init", lambda device=None: log.append(("init", device)))
+    monkeypatch.setattr(_lib, "comm_unique_id", lambda: bytes(range(128)))
+    monkeypatch.setattr(_lib, "comm_init", lambda uid, rank, world: log.append(("comm_init", uid, rank, world)))
+    monkeypatch.setattr(_lib, "device_count", lambda: 8)
+    adist.init_comm(0, 1, None, device=0)                         # one rank: no id, no communicator
+    assert log == [("init", 0)]
+    del log[:]
+    adist.init_comm(0, 2, lambda b: b, device=0)
+    adist.init_comm(1, 2, lambda b: bytes(range(128)), device=1)
+    assert log == [("init", 0), ("comm_init", bytes(range(128)), 0, 2), ("init", 1), ("comm_init", bytes(range(128)), 1, 2)]
+    del log[:]
+    monkeypatch.setattr(_lib, "device_count", lambda: 1)          # isolated by visibility
+    adist.init_comm(3, 8, lambda b: bytes(range(128)), device=3)
+    assert log[0] == ("init", 0) and log[1][2:] == (3, 8)
+    del log[:]
+    # the file rendezvous: rank 1 polls until rank 0 has written
+    path = str(tmp_path / "uid")
+    got = {}
+
+    def rank1():
+        got["r1"] = adist.init_from_file(path, 1, 2, device=1, timeout_s=20.0)
+
+    monkeypatch.setattr(_lib, "device_count", lambda: 8)
+    th = threading.Thread(target=rank1)
+    th.start()
+    assert adist.init_from_file(path, 0, 2, device=0) == (0, 2)
+    th.join(20)
+    assert got["r1"] == (1, 2) and sorted(e for e in log if e[0] == "comm_init") == [("comm_init", bytes(range(128)), 0, 2), ("comm_init", bytes(range(128)), 1, 2)]
+    with pytest.raises(TimeoutError):
+        adist.init_from_file(str(tmp_path / "never"), 1, 2, device=1, timeout_s=0.2)
+    assert adist.shard_bounds(10, 0, 3) == (0, 3) and adist.shard_rows(10, 2, 3) == (6, 10)
+    with pytest.raises(ValueError):
+        adist.shard_bounds(10, 3, 3)
+
+
+def test_pixel_tables_of_the_wrong_shape_are_refused():
+    with pytest.raises(ValueError, match="shape"):
+        opt._uv_pointers(np.zeros((5, 3)))
+
+
 def test_lsq_argument_errors_need_no_gpu():
     o = opt.LsqOptimizer(pd.DataFrame(np.zeros((3, 3)), columns=["x", "y", "z"]),
                          pd.DataFrame(np.zeros((3, 2)), columns=["u", "v"]), {k: 1.0 for k in orc.PARAM_KEYS})
