@@ -106,3 +106,69 @@ print("two lives ok")
 """ % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "two lives ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_the_bindings_refuse_what_the_library_would_misread(L):
+    """every shape / type check of alproj_amd._lib (a wrong shape handed to the C side would be read as something else) and
+    the integer inputs it converts itself"""
+    from alproj_amd import synthetic as syn
+    truth = syn.truth_params(316)
+    xyz = syn.gcp_points(64, truth, seed=1)
+    origin = [truth["x"], truth["y"], truth["z"]]
+    for bad in (np.zeros((5, 2)), np.zeros(7), np.zeros((2, 3, 3))):
+        with pytest.raises(ValueError, match=r"\(N, 3\)"):
+            L.Points(bad, origin)
+    with L.Points(np.round(xyz).astype(np.int64), origin, "f64") as pi, L.Points(np.round(xyz), origin, "f64") as pf:      # integer coordinates
+        pi.project(L.params_vector(truth)), pf.project(L.params_vector(truth))
+        np.testing.assert_array_equal(pi.fetch()[0], pf.fetch()[0])
+        uv = np.round(orc.project_points(np.round(xyz), truth))
+        pi.set_observed(uv.astype(np.int32)), pf.set_observed(uv)                                                       # integer pixels
+        c = np.stack([L.params_vector(truth)])
+        np.testing.assert_array_equal(pi.eval_population(c, L.LOSS_HUBER, 10.0)[0], pf.eval_population(c, L.LOSS_HUBER, 10.0)[0])
+        with pytest.raises(ValueError, match="observed uv"):
+            pi.set_observed(np.zeros((63, 2)))
+        with pytest.raises(ValueError, match="observed u, v"):
+            pi.set_observed_columns(np.zeros(63), np.zeros(63))
+        with pytest.raises(ValueError, match=r"\(P, 25\)"):
+            pi.eval_population(np.zeros((3, 24)), L.LOSS_HUBER)
+        with pytest.raises(ValueError, match=r"\(B, 25\)"):
+            pi.residuals_batch(np.zeros(25))
+    with pytest.raises(TypeError, match="unsupported dtype"):
+        L.dtype_code(np.zeros(3, np.complex64))
+    with pytest.raises(ValueError, match="C-contiguous"):
+        L.host_hash64(np.zeros((4, 4))[:, ::2])
+    v = np.zeros((9, 3), np.float32)
+    with pytest.raises(ValueError, match="vert must have shape"):
+        L.Mesh(np.zeros((9, 2), np.float32), None, None, grid=(3, 3))
+    with pytest.raises(ValueError, match="value must have the shape"):
+        L.Mesh(v, np.zeros((8, 3), np.float32), None, grid=(3, 3))
+    with pytest.raises(ValueError, match="either ind or grid"):
+        L.Mesh(v)
+    with pytest.raises(ValueError, match=r"ind must have shape"):
+        L.Mesh(v, None, np.zeros((4, 2), np.int32))
+    with L.Mesh(v, None, np.array([[0, 1, 4], [0, 4, 3]], dtype=np.int16)) as m:                                          # a narrow integer index type
+        assert m.info()["n_tri"] == 2
+        with pytest.raises(ValueError, match=r"\(h, w, 3\)"):
+            m.load_image(np.zeros((4, 4), np.float32))
+    with pytest.raises(ValueError, match="dsm must have shape"):
+        L.Mesh.from_rasters(np.zeros(9), (1, 0, 0, 0, -1, 3), 1.0, np.zeros((3, 3, 3), np.uint8), 255.0)
+    with pytest.raises(ValueError, match="nodata must have the shape"):
+        L.Mesh.from_rasters(np.zeros((3, 3)), (1, 0, 0, 0, -1, 3), 1.0, np.zeros((3, 3, 3), np.uint8), 255.0, np.zeros((2, 3), bool))
+    with pytest.raises(ValueError, match=r"\(n, 3\)"):
+        L.distance_mask(np.zeros((4, 2)), [0, 0, 0], 1.0, 2.0)
+    with pytest.raises(ValueError, match="x, y"):
+        L.rasterize_points_f32(np.zeros(4), np.zeros(5), np.zeros((4, 1)))
+    with pytest.raises(ValueError, match="Invalid raster dimensions"):
+        L.rasterize_points_f32(np.full(4, 3.0), np.arange(4.0), np.zeros((4, 1)))
+    with pytest.raises(ValueError, match="img must be"):
+        L.distort_image(np.zeros(5, np.float32), np.zeros(14))
+    with pytest.raises(ValueError, match="14 entries"):
+        L.distort_image(np.zeros((4, 4), np.float32), np.zeros(13))
+    with pytest.raises(ValueError, match="14 entries"):
+        L.distort_map(4, 4, np.zeros(3))
+    with pytest.raises(ValueError, match="BD must be"):
+        L.cma_sample(np.zeros(3), 1.0, np.zeros((3, 2)), None, 4, 10, 1, 0)
+    with pytest.raises(ValueError, match="128 bytes"):
+        L.comm_init(b"short", 0, 1)
+    with pytest.raises(ValueError, match="C-contiguous"):
+        L.comm_bcast(np.zeros((4, 4))[:, ::2])
