@@ -88,4 +88,4 @@ def test_live_traffic_never_takes_the_line_down(monkeypatch):
     monkeypatch.undo()
     if shutil.which("rocprofv3"):
         got, why = bench.live_traffic(100_000, timeout_s=120.0)
-        assert got is None and why                              # no GPU here: the passes fail, the reason comes back
+        assert why and (got is None or got > 0)                 # no GPU here: the passes fail and the reason comes back (on a GPU box: a figure)
