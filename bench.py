@@ -319,7 +319,7 @@ def live_traffic(vertices, timeout_s=170.0):
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)        # the tool keeps its rocprof output there
     cmd = [sys.executable, tool, out_json, "3", "project_kernel", "--", sys.executable, probe, str(vertices), "3", "f32"]
     try:
-        p = subprocess.Popen(cmd, cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp"), stdin=subprocess.DEVNULL,
+        p = subprocess.Popen(cmd, cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp", PMC_TRAFFIC_CLEANUP="1"), stdin=subprocess.DEVNULL,
                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
         try:
             rc = p.wait(timeout=timeout_s)
@@ -333,6 +333,7 @@ def live_traffic(vertices, timeout_s=170.0):
         if rc != 0:
             return None, f"tools/pmc_traffic.py exited with {rc}"
         doc = json.load(open(out_json))
+        shutil.rmtree(os.path.dirname(out_json), ignore_errors=True)
         k = [v for name, v in doc["kernels"].items() if "project_kernel<float>" in name]
         if not k or not k[0].get("hbm_bytes_per_frame"):
             return None, "no counters for project_kernel<float> in the passes"

@@ -22,12 +22,14 @@ out_json, divisor, flt = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 cmd = sys.argv[sys.argv.index("--") + 1:]
 filters = [f for f in flt.split(",") if f]
 res = {}
+made = []                   # the rocprofv3 output directories of this call (removed at the end when PMC_TRAFFIC_CLEANUP is set: bench.py's live pass)
 env = dict(os.environ, TMPDIR="/tmp")
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     d = tempfile.mkdtemp(prefix="pmc_", dir=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"))
     subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--"] + cmd, check=True, env=env,
                    stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
     db = sqlite3.connect(os.path.join(d, "p_results.db"))
+    made.append(d)
     q = db.execute("select kernel_name, sum(value), count(distinct dispatch_id) from counters_collection where counter_name = ? "
                    "group by kernel_name", (counter,)).fetchall()
     for kn, tot, nd in q:
@@ -54,3 +56,8 @@ doc = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two p
        "kernels": frame, "hbm_bytes_per_frame": total}
 json.dump(doc, open(out_json, "w"), indent=1)
 print(json.dumps(doc, indent=1))
+if os.environ.get("PMC_TRAFFIC_CLEANUP"):
+    import shutil
+    db.close()
+    for d in made:
+        shutil.rmtree(d, ignore_errors=True)
