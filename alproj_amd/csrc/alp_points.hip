@@ -33,6 +33,10 @@ struct alp_points {
     int64_t n_pad = 0;
     int precision = ALP_F32;
     double origin[3] = {0, 0, 0};
+    // the planes live in at most three allocations (a hipMalloc / hipFree pair of this size costs ~1 ms: seven of them were a
+    // third of what compute_residuals spent at 10 M points): coordinates at creation, observed pixels at alp_points_set_observed*,
+    // projected pixels at the first alp_project
+    void *slab_xyz = nullptr, *slab_obs = nullptr, *slab_uv = nullptr;
     void *x = nullptr, *y = nullptr, *z = nullptr;
     void *uo = nullptr, *vo = nullptr;
     void *u = nullptr, *v = nullptr;
@@ -66,9 +70,11 @@ constexpr double CONFIRM_GAP = 5e-5;
 
 namespace {
 
-int alloc_plane(void **p, int64_t n_pad, size_t es) {
-    ALP_HIP(hipMalloc(p, (size_t)n_pad * es));
-    ALP_HIP(hipMemsetAsync(*p, 0, (size_t)n_pad * es, ctx().stream));
+// k planes of n_pad elements in ONE zeroed allocation (n_pad is a multiple of 1024 elements: every plane starts 4 KB-aligned)
+int alloc_planes(void **slab, int k, int64_t n_pad, size_t es, void **planes[]) {
+    ALP_HIP(hipMalloc(slab, (size_t)k * n_pad * es));
+    ALP_HIP(hipMemsetAsync(*slab, 0, (size_t)k * n_pad * es, ctx().stream));
+    for (int i = 0; i < k; ++i) *planes[i] = (char *)*slab + (size_t)i * n_pad * es;
     return ALP_OK;
 }
 
@@ -368,9 +374,13 @@ int residuals_impl(alp_points *p, const double *cand, int64_t B, double *out) {
                            res_dev, cnt, poses_dev, (int)B);
         ktime_end();
         ALP_HIP(hipGetLastError());
-        // row b of the chunk -> out[b][off .. off + cnt)
-        ALP_HIP(hipMemcpy2DAsync(out + 2 * off, (size_t)p->n * sizeof(double2), res_dev, (size_t)cnt * sizeof(double2),
-                                 (size_t)cnt * sizeof(double2), (size_t)B, hipMemcpyDeviceToHost, st));
+        // row b of the chunk -> out[b][off .. off + cnt); a chunk that holds whole rows is one contiguous run (a pitched copy of
+        // the same bytes took 2-3 x as long)
+        if (cnt == p->n)
+            ALP_HIP(hipMemcpyAsync(out, res_dev, (size_t)B * cnt * sizeof(double2), hipMemcpyDeviceToHost, st));
+        else
+            ALP_HIP(hipMemcpy2DAsync(out + 2 * off, (size_t)p->n * sizeof(double2), res_dev, (size_t)cnt * sizeof(double2),
+                                     (size_t)cnt * sizeof(double2), (size_t)B, hipMemcpyDeviceToHost, st));
         ALP_HIP(hipStreamSynchronize(st));       // the staging buffer is reused; poses must outlive their copy
     }
     return ALP_OK;
@@ -502,9 +512,8 @@ static int points_create(const void *xyz, const void *const *cols, int in_dtype,
     p->n_pad = round_up(n > 0 ? n : 1, 1024);
     p->precision = precision;
     memcpy(p->origin, origin, sizeof(p->origin));
-    int rc = ALP_OK;
-    for (void **pl : {&p->x, &p->y, &p->z, &p->u, &p->v})
-        if ((rc = alloc_plane(pl, p->n_pad, p->esize()))) break;
+    void **xyz_planes[3] = {&p->x, &p->y, &p->z};
+    int rc = alloc_planes(&p->slab_xyz, 3, p->n_pad, p->esize(), xyz_planes);
     if (!rc && n > 0) {
         void *const planes[3] = {p->x, p->y, p->z};
         rc = cols ? upload_planes(cols, 3, in_dtype, n, origin, precision, planes)
@@ -536,8 +545,7 @@ int alp_points_create_columns(const void *x, const void *y, const void *z, int i
 int alp_points_destroy(alp_points_t *p) {
     if (!p) return ALP_OK;
     if (ctx().ready) hipStreamSynchronize(ctx().stream);
-    for (void *q : {p->x, p->y, p->z, p->uo, p->vo, p->u, p->v, p->cand_dev, (void *)p->partials,
-                    (void *)p->sums_dev})
+    for (void *q : {p->slab_xyz, p->slab_obs, p->slab_uv, p->cand_dev, (void *)p->partials, (void *)p->sums_dev})
         if (q) hipFree(q);
     if (p->cand_host) hipHostFree(p->cand_host);
     if (p->sums_host) hipHostFree(p->sums_host);
@@ -561,8 +569,8 @@ int alp_points_set_observed(alp_points_t *p, const void *uv, int in_dtype) {
     ALP_REQUIRE(p->n == 0 || uv, "uv is NULL");
     ALP_REQUIRE(in_dtype == ALP_F32 || in_dtype == ALP_F64, "in_dtype must be ALP_F32 or ALP_F64");
     if (!p->uo) {
-        if (int rc = alloc_plane(&p->uo, p->n_pad, p->esize())) return rc;
-        if (int rc = alloc_plane(&p->vo, p->n_pad, p->esize())) return rc;
+        void **obs_planes[2] = {&p->uo, &p->vo};
+        if (int rc = alloc_planes(&p->slab_obs, 2, p->n_pad, p->esize(), obs_planes)) return rc;
     }
     const double zero[3] = {0, 0, 0};
     if (p->n > 0)
@@ -577,8 +585,8 @@ int alp_points_set_observed_columns(alp_points_t *p, const void *u, const void *
     ALP_REQUIRE(p->n == 0 || (u && v), "u or v is NULL");
     ALP_REQUIRE(in_dtype == ALP_F32 || in_dtype == ALP_F64, "in_dtype must be ALP_F32 or ALP_F64");
     if (!p->uo) {
-        if (int rc = alloc_plane(&p->uo, p->n_pad, p->esize())) return rc;
-        if (int rc = alloc_plane(&p->vo, p->n_pad, p->esize())) return rc;
+        void **obs_planes[2] = {&p->uo, &p->vo};
+        if (int rc = alloc_planes(&p->slab_obs, 2, p->n_pad, p->esize(), obs_planes)) return rc;
     }
     const double zero[2] = {0, 0};
     const void *const cols[2] = {u, v};
@@ -592,6 +600,10 @@ int alp_points_set_observed_columns(alp_points_t *p, const void *u, const void *
 int alp_project(alp_points_t *p, const double params[ALP_NPARAM]) {
     if (int rc = require_init()) return rc;
     ALP_REQUIRE(p && params, "NULL argument");
+    if (!p->u) {
+        void **uv_planes[2] = {&p->u, &p->v};
+        if (int rc = alloc_planes(&p->slab_uv, 2, p->n_pad, p->esize(), uv_planes)) return rc;
+    }
     p->projected = true;
     if (p->n == 0) return ALP_OK;
     return p->precision == ALP_F64 ? launch_project<double>(p, params) : launch_project<float>(p, params);
