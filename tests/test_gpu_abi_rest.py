@@ -172,3 +172,65 @@ def test_the_bindings_refuse_what_the_library_would_misread(L):
         L.comm_init(b"short", 0, 1)
     with pytest.raises(ValueError, match="C-contiguous"):
         L.comm_bcast(np.zeros((4, 4))[:, ::2])
+
+
+def test_handles_give_their_device_memory_back(L):
+    """forty lives of a point set (float32 and float64, row-major and column uploads, observed pixels, projection, both fetches,
+    population evaluation with argmin confirmation, residuals) and of a mesh (grid and index array, render, visibility, the
+    visible-pixel table, rasterisation from the frame, a mesh from rasters): the free device memory hipMemGetInfo reports after
+    them is what it was after the first two (grow-only scratch areas reach their size in those)"""
+    from alproj_amd import synthetic as syn
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        L.synchronize()
+        f, t = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+        return f.value
+
+    truth = syn.truth_params(316)
+    xyz = syn.gcp_points(300_000, truth, seed=2)
+    uv = orc.project_points(xyz, truth) + np.random.default_rng(2).normal(0, 1, (len(xyz), 2))
+    origin = [truth["x"], truth["y"], truth["z"]]
+    cand = np.stack([L.params_vector(truth), L.params_vector(truth), L.params_vector(dict(truth, pan=truth["pan"] + 1e-9))])
+    n = 200
+    s = syn.surface(n)
+    cam = dict(syn.base_params(n), w=480, h=320, cx=240.0, cy=160.0, tilt=-10.0)
+    ind = syn.grid_indices(n, np.int32)
+    rng = np.random.default_rng(3)
+    dsm = (1500 + rng.normal(0, 20, (n, n))).astype(np.float32)
+    aerial = rng.integers(0, 256, (3, n, n), dtype=np.uint8)
+    img = rng.integers(0, 256, (320, 480, 3), dtype=np.uint8)
+
+    def one_life(k):
+        prec = "f32" if k % 2 else "f64"
+        pts = L.Points(xyz, origin, prec) if k % 3 else L.Points.from_columns(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), origin, prec)
+        with pts as p:
+            p.set_observed(uv)
+            p.project(cand[0])
+            p.fetch(np.float64), p.fetch(np.float32), p.fetch_strided(0, 7, 1000)
+            p.eval_population(cand, L.LOSS_HUBER, 10.0)
+            if prec == "f64":
+                p.residuals(cand[0]), p.residuals_batch(cand)
+        os.environ["ALP_NO_GRID_DETECT"] = "1" if k % 2 else "0"
+        try:
+            mesh = L.Mesh(s["vert"], None, ind if k % 2 else None, grid=None if k % 2 else (n, n))
+        finally:
+            os.environ.pop("ALP_NO_GRID_DETECT", None)
+        with mesh as m:
+            m.render_enqueue(L.params_vector(cam), s["offsets"], coords=True)
+            m.fetch(), m.fetch_visibility(), m.fetch_valid(s["offsets"])
+            cnt, (x0, y0, x1, y1) = m.rasterize_plan(s["offsets"])
+            if cnt:
+                m.rasterize(img, [0, 1, 2], x0, y1, 2.0, int(np.ceil((x1 - x0) / 2.0)), int(np.ceil((y1 - y0) / 2.0)), 0, 1, 255)
+        m2, _ = L.Mesh.from_rasters(dsm, (1.0, 0.0, 0.0, 0.0, -1.0, float(n)), 1600.0, aerial, 255.0, None)
+        m2.close()
+
+    one_life(0), one_life(1)
+    L.clear_result_pool()
+    before = free_bytes()
+    for k in range(2, 42):
+        one_life(k)
+    L.clear_result_pool()
+    after = free_bytes()
+    assert before - after < (8 << 20), f"{(before - after) / 2**20:.1f} MiB of device memory did not come back after 40 handle lives"
