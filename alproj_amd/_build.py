@@ -15,7 +15,12 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 BUILD = os.path.join(ROOT, "build")
 LIB = os.path.join(HERE, "libalproj_hip.so")
-SOURCES = ["alp_core.hip", "alp_points.hip", "alp_raster.hip", "alp_mesh.hip", "alp_rasterize.hip", "alp_sampler.hip"]
+SOURCES = ["alp_core.hip", "alp_points.hip", "alp_raster.hip", "alp_mesh.hip", "alp_rasterize.hip", "alp_sampler.hip",
+           "host/alp_host.cpp"]
+# host/: the HIP-free part of the library (plain C++; build_host() compiles the same files with g++ under the sanitizers)
+HOST_DIR = os.path.join(CSRC, "host")
+HOST_SAN = os.path.join(BUILD, "host_san")
+HOST_KINDS = {"plain": [], "asan": ["-fsanitize=address,undefined", "-fno-sanitize-recover=all"], "tsan": ["-fsanitize=thread"]}
 # the raster's coverage/visibility arithmetic is specified operation by operation (DESIGN.md
 # section 5): no implicit fused multiply-adds there
 EXTRA_FLAGS = {"alp_raster.hip": ["-ffp-contract=off"], "alp_mesh.hip": ["-ffp-contract=off"]}
@@ -40,17 +45,22 @@ def build(force=False, verbose=False):
     """Compile every HIP translation unit for gfx950 and link libalproj_hip.so."""
     os.makedirs(BUILD, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + \
+              [os.path.join(HOST_DIR, f) for f in sorted(os.listdir(HOST_DIR)) if f.endswith(".h")] + \
               [os.path.join(INCLUDE, "alproj_hip.h"), os.path.abspath(__file__)]
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
              f"-I{INCLUDE}", f"-I{CSRC}"]
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(BUILD, src.replace(".hip", ".o"))
+        host_only = src.endswith(".cpp")
+        o = os.path.join(BUILD, os.path.basename(src).replace(".hip", ".o").replace(".cpp", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc()] + flags + EXTRA_FLAGS.get(src, []) + \
-                  ["-Rpass-analysis=kernel-resource-usage", "-c", s, "-o", o]
+            if host_only:       # no device code: plain C++ through the same driver (one C++ runtime in the library)
+                cmd = [hipcc(), "-x", "c++"] + flags[1:] + ["-c", s, "-o", o]
+            else:
+                cmd = [hipcc()] + flags + EXTRA_FLAGS.get(src, []) + \
+                      ["-Rpass-analysis=kernel-resource-usage", "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)
@@ -68,11 +78,41 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def host_compiler(name):
+    """``clang``: the clang++ hipcc drives (the library's own compiler); ``gcc``: g++"""
+    if name == "gcc":
+        return shutil.which("g++")
+    exe = "/opt/rocm/lib/llvm/bin/clang++"
+    return exe if os.path.exists(exe) else shutil.which("amdclang++")
+
+
+def build_host(kind="plain", compiler="clang", force=False):
+    """The HIP-free part of the library (csrc/host/) + its self-checking driver, compiled without HIP: ``plain``,
+    ``asan`` (-fsanitize=address,undefined, every report fatal) or ``tsan`` (-fsanitize=thread), by the library's own
+    clang++ or by g++.  Returns the driver executable build/host_san/alp_host_<kind>_<compiler>;
+    tests/test_host_sanitized.py runs it."""
+    cxx = host_compiler(compiler)
+    if not cxx:
+        raise RuntimeError(f"no {compiler} C++ compiler found")
+    os.makedirs(HOST_SAN, exist_ok=True)
+    srcs = [os.path.join(HOST_DIR, f) for f in ("alp_host.cpp", "alp_host_selfcheck.cpp")]
+    deps = srcs + [os.path.join(HOST_DIR, "alp_host.h"), os.path.join(INCLUDE, "alproj_hip.h"), os.path.abspath(__file__)]
+    exe = os.path.join(HOST_SAN, f"alp_host_{kind}_{compiler}")
+    if force or _stale(exe, deps):
+        cmd = [cxx, "-O1", "-g", "-fno-omit-frame-pointer", "-std=c++17", "-Wall", "-Wextra", f"-I{INCLUDE}", f"-I{CSRC}"] + \
+              HOST_KINDS[kind] + srcs + ["-o", exe, "-lpthread"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr)
+            raise RuntimeError(f"{cxx} failed on the host-only build ({kind})")
+    return exe
+
+
 def resource_usage():
     """Parse the kernel-resource-usage remarks of the last build: {kernel: {field: value}}."""
     out = {}
     for src in SOURCES:
-        log = os.path.join(BUILD, src.replace(".hip", ".o.log"))
+        log = os.path.join(BUILD, os.path.basename(src).replace(".hip", ".o.log").replace(".cpp", ".o.log"))
         if not os.path.exists(log):
             continue
         cur = None

@@ -3,18 +3,10 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
-#include <cstdarg>
-#include <cstdint>
-#include <cstdio>
-#include <cstring>
 
-#include "alproj_hip.h"
+#include "host/alp_host.h"      // errors (set_error / fail / ALP_REQUIRE), pose record + fold_pose, the HIP-free host helpers
 
 namespace alp {
-
-// ------------------------------------------------------------------ errors
-void set_error(const char *fmt, ...);
-int fail(int code, const char *fmt, ...);
 
 #define ALP_HIP(expr)                                                                     \
     do {                                                                                  \
@@ -22,11 +14,6 @@ int fail(int code, const char *fmt, ...);
         if (e__ != hipSuccess)                                                            \
             return ::alp::fail(ALP_EHIP, "%s failed: %s (%s:%d)", #expr,                  \
                                hipGetErrorString(e__), __FILE__, __LINE__);               \
-    } while (0)
-
-#define ALP_REQUIRE(cond, msg)                                                            \
-    do {                                                                                  \
-        if (!(cond)) return ::alp::fail(ALP_EINVAL, "%s: %s", __func__, msg);             \
     } while (0)
 
 // ------------------------------------------------------------------ global context
@@ -81,37 +68,5 @@ void points_release_staging();
 // all-reduce (sum, double) of `count` doubles in place on the library stream; no-op
 // when no communicator exists.
 int comm_allreduce_sum_f64(double *dev_buf, int64_t count);
-
-// ------------------------------------------------------------------ pose record
-// One camera pose folded, in float64 on the host, into the 32 numbers the kernels use.
-// Layout (index):
-//   0..3   row X' : x1 = (X'.[q;1]) / (Z.[q;1])   normalised, centred image x (see fold_pose)
-//   4..7   row Y' : y1 = (Y'.[q;1]) / (Z.[q;1])
-//   8..11  row Z  : depth along the optical axis
-//   12..17 k1..k6
-//   18,19  1+a1, 1+a2
-//   20,21  2*p1, 2*p2
-//   22..25 s1..s4
-//   26,27  c0, c1 : float32-rounded image centre (w-1)/2, (h-1)/2
-//   28,29  -c0, -c1
-//   30,31  unused (0)
-constexpr int POSE_WORDS = 32;
-
-template <typename T>
-struct alignas(16) PoseRec {
-    T v[POSE_WORDS];
-};
-
-// params: the 25 ABI parameters; origin: local origin of the point set (absolute coords).
-void fold_pose(const double params[ALP_NPARAM], const double origin[3], double rec[POSE_WORDS]);
-
-template <typename T>
-inline void fold_pose_t(const double params[ALP_NPARAM], const double origin[3], PoseRec<T> *out) {
-    double r[POSE_WORDS];
-    fold_pose(params, origin, r);
-    for (int i = 0; i < POSE_WORDS; ++i) out->v[i] = (T)r[i];
-}
-
-inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
 }  // namespace alp

@@ -19,7 +19,6 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
-#include <thread>
 #include <vector>
 
 #include "alp_point_kernels.h"
@@ -62,11 +61,8 @@ struct alp_points {
     size_t esize() const { return precision == ALP_F64 ? 8 : 4; }
 };
 
-// float32 point sets: when the smallest loss and its runner-up differ by less than CONFIRM_GAP
-// (relative) the candidates inside that band are evaluated again in float64 arithmetic before the
-// argmin is returned (north star: "argmin pose index bit-exact"; float32 losses carry ~1e-6..1e-5)
-constexpr int CONFIRM_MAX = 16;
-constexpr double CONFIRM_GAP = 5e-5;
+// argmin confirmation of float32 point sets: CONFIRM_MAX, CONFIRM_GAP and the selection itself live in host/alp_host.h
+using alp::host::CONFIRM_MAX;
 
 namespace {
 
@@ -399,33 +395,13 @@ constexpr int64_t FETCH_CHUNK = (int64_t)8 << 20;         // values per chunk: 3
 void *g_fetch_stage[2] = {nullptr, nullptr};               // pinned, FETCH_CHUNK * 8 bytes each; lives until the process ends
 hipEvent_t g_fetch_ev[2] = {nullptr, nullptr};
 
-template <typename S, typename D>
-void convert_slice(const S *__restrict__ src, D *__restrict__ dst, int64_t n) {
-    for (int64_t i = 0; i < n; ++i) __builtin_nontemporal_store((D)src[i], dst + i);     // the result is not read back here
-}
-
-template <typename S, typename D>
-void convert_threads(const S *src, D *dst, int64_t n, int T) {
-    if (T <= 1 || n < (1 << 16)) return convert_slice(src, dst, n);
-    std::vector<std::thread> th;
-    const int64_t per = ((n + T - 1) / T + 15) & ~(int64_t)15;
-    for (int t = 1; t < T; ++t) {
-        const int64_t a = std::min(n, per * t), b = std::min(n, per * (t + 1));
-        if (b > a) th.emplace_back([=] { convert_slice(src + a, dst + a, b - a); });
-    }
-    convert_slice(src, dst, std::min(n, per));
-    for (auto &x : th) x.join();
-}
+using alp::host::convert_threads;      // the widening / narrowing workers: host/alp_host.h (HIP-free, run under the sanitizers)
+using alp::host::fetch_threads;
 
 template <typename S, typename D>
 __global__ __launch_bounds__(256) void cast_plane_kernel(const S *__restrict__ src, D *__restrict__ dst, long long n) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (D)src[i];
-}
-
-int fetch_threads() {
-    if (const char *e = getenv("ALP_HOST_THREADS")) return std::max(1, std::min(64, atoi(e)));
-    return (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
 }
 
 template <typename S, typename D>
@@ -748,16 +724,9 @@ int alp_eval_population_wait(alp_points_t *p, double *loss_out, int64_t *argmin_
         local.resize((size_t)P);
         loss = local.data();
     }
-    int64_t best = -1;
+    // (the selection below is host/alp_host.h: NaN never wins, first index on ties, the CONFIRM_MAX smallest of a band)
     double best_v = 0;
-    for (int64_t i = 0; i < P; ++i) {
-        const double l = p->sums_host[i] / n_total;    // np.mean over all vertices
-        loss[i] = l;
-        if (l == l && (best < 0 || l < best_v)) {       // NaN never wins; first index on ties
-            best = i;
-            best_v = l;
-        }
-    }
+    int64_t best = host::losses_and_argmin(p->sums_host, P, n_total, loss, &best_v);
     // (a caller that passes no argmin_out wants the losses only: no confirmation -- CMAOptimizer needs the argmin of its LAST
     // generation alone, optimize.py:427, and the confirmation costs a float64 pass over every point)
     if (argmin_out && best >= 0 && p->precision == ALP_F32 && P > 1 && best_v < INFINITY) {
@@ -765,36 +734,12 @@ int alp_eval_population_wait(alp_points_t *p, double *loss_out, int64_t *argmin_
         // more than one, float32 cannot order them -- evaluate (up to CONFIRM_MAX of) them again in
         // float64 arithmetic and take the argmin of those; identical on every rank (the sums are
         // all-reduced, so every rank sees the same band and joins the same second all-reduce)
-        const double band = best_v + CONFIRM_GAP * std::fabs(best_v);
         int64_t which[CONFIRM_MAX];
         int K = 0;
-        int64_t in_band = 0;
-        for (int64_t i = 0; i < P; ++i)
-            if (loss[i] <= band) {
-                ++in_band;
-                if (K < CONFIRM_MAX) {
-                    which[K++] = i;
-                } else {           // keep the CONFIRM_MAX smallest: replace the largest kept one if this is smaller
-                    int worst = 0;
-                    for (int k = 1; k < CONFIRM_MAX; ++k)
-                        if (loss[which[k]] > loss[which[worst]] || (loss[which[k]] == loss[which[worst]] && which[k] > which[worst])) worst = k;
-                    if (loss[i] < loss[which[worst]]) which[worst] = i;
-                }
-            }
-        if (in_band > 1) {
-            std::sort(which, which + K);
+        if (host::confirm_band(loss, P, best_v, which, &K) > 1) {
             double sums[CONFIRM_MAX + 1];
             if (int rc = confirm_losses(p, p->cand_copy.data(), which, K, p->pending_loss, p->pending_f_scale, sums)) return rc;
-            best = -1;
-            for (int k = 0; k < K; ++k) {
-                const double l = sums[k] / sums[K];
-                loss[which[k]] = l;
-                if (l == l && (best < 0 || l < best_v)) {
-                    best = which[k];
-                    best_v = l;
-                }
-            }
-            if (best < 0) best = which[0];
+            best = host::merge_confirmed(loss, which, K, sums);
         }
     }
     if (argmin_out) *argmin_out = best < 0 ? 0 : best;

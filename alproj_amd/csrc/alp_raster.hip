@@ -768,66 +768,10 @@ int alp::upload_f32(float *dst, const void *src, int dtype, int64_t n_vert) {
     return ALP_OK;
 }
 
-// Is a host index array exactly the regular grid of surface.py:194-201 with gw columns?  Answered by a few host threads
-// WHILE the vertices and colours cross PCIe: a full-grid array then never crosses it at all (4.8 GB of int64 at 100 M
-// vertices = 86 ms of PCIe time, a third of the reference-typed first call).  Each thread walks whole grid rows of its
-// share of the cells (a streaming compare against a + {0, gw, gw+1, 0, gw+1, 1}); the first mismatch stops everybody.
-namespace {
-template <typename I>
-void grid_rows_check(const I *ind, long long gw, long long row0, long long row1, std::atomic<bool> *bad) {
-    const long long gc = gw - 1;
-    for (long long r = row0; r < row1 && !bad->load(std::memory_order_relaxed); ++r) {
-        const I *p = ind + (size_t)r * gc * 6;
-        long long a = r * gw;
-        bool diff = false;
-        for (long long c = 0; c < gc; ++c, ++a, p += 6)
-            diff |= (long long)p[0] != a || (long long)p[1] != a + gw || (long long)p[2] != a + gw + 1 || (long long)p[3] != a ||
-                    (long long)p[4] != a + gw + 1 || (long long)p[5] != a + 1;
-        if (diff) bad->store(true, std::memory_order_relaxed);
-    }
-}
-
-struct HostGridCheck {
-    std::vector<std::thread> threads;
-    std::atomic<bool> bad{false};
-    bool started = false;
-    void start(const void *ind, int ind_dtype, long long gh, long long gw, int n_threads) {
-        const long long rows = gh - 1;
-        const int T = (int)std::min<long long>(n_threads, rows);
-        try {
-            for (int t = 0; t < T; ++t) {
-                const long long r0 = rows * t / T, r1 = rows * (t + 1) / T;
-                if (ind_dtype == ALP_I32) threads.emplace_back(grid_rows_check<int>, (const int *)ind, gw, r0, r1, &bad);
-                else threads.emplace_back(grid_rows_check<long long>, (const long long *)ind, gw, r0, r1, &bad);
-            }
-            started = true;
-        } catch (...) {               // no threads to be had: the caller falls back to the check on the device
-            bad.store(true);
-            join();
-            bad.store(false);
-            started = false;
-        }
-    }
-    void join() {
-        for (auto &t : threads)
-            if (t.joinable()) t.join();
-        threads.clear();
-    }
-    bool is_grid() {                   // joins
-        join();
-        return started && !bad.load();
-    }
-    ~HostGridCheck() { bad.store(true); join(); }
-};
-
-// host threads for HostGridCheck: ALP_HOST_THREADS (0 = check on the device instead), else up to 8 of the machine's
-int host_check_threads(int64_t n_tri) {
-    if (const char *e = getenv("ALP_HOST_THREADS")) return std::max(0, std::min(64, atoi(e)));     // tests: either path at any size
-    if (n_tri < (1 << 18)) return 0;           // small arrays: the staged check costs nothing
-    const unsigned hc = std::thread::hardware_concurrency();
-    return hc >= 4 ? (int)std::min(8u, hc / 2) : 0;
-}
-}  // namespace
+// Regular-grid recognition in a host index array (HostGridCheck, host_check_threads, grid_candidate): host/alp_host.h --
+// HIP-free, so that its threads run under the sanitizers on the CPU build.
+using alp::host::HostGridCheck;
+using alp::host::host_check_threads;
 
 extern "C" {
 
@@ -861,16 +805,7 @@ int alp_mesh_create(const void *vert, int vert_dtype, const void *value, int val
     // filtered out: an array with the grid's first triangle and exactly its triangle count is a candidate
     const bool detect = !getenv("ALP_NO_GRID_DETECT");       // env: keep the index path (tests, benchmarks)
     long long cand_gh = 0, cand_gw = 0;
-    if (!implicit && detect && n_tri >= 2 && (n_tri & 1) == 0) {
-        long long first[3];
-        for (int k = 0; k < 3; ++k)
-            first[k] = ind_dtype == ALP_I32 ? (long long)((const int *)ind)[k] : ((const long long *)ind)[k];
-        const long long gw = first[1] - first[0];
-        if (first[0] == 0 && gw >= 2 && first[2] == gw + 1 && n_vert % gw == 0) {
-            const long long gh = n_vert / gw;
-            if (gh >= 2 && n_tri == 2 * (gh - 1) * (gw - 1)) { cand_gh = gh; cand_gw = gw; }
-        }
-    }
+    if (!implicit && detect) host::grid_candidate(ind, ind_dtype, n_tri, n_vert, &cand_gh, &cand_gw);
     HostGridCheck host_check;                 // its destructor joins on every way out of this function
     if (cand_gw) {
         const int T = host_check_threads(n_tri);
