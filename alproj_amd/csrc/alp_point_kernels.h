@@ -271,8 +271,10 @@ template <> struct PopCfg<float> : PopCfgT<float, POP_V, POP_TC, POP_MINW> {};
 #ifndef POP_TCD
 #define POP_TCD 128
 #endif
+// three waves per SIMD asked for (<= 168 VGPRs): what the compiler chose by itself for the main variants (154-158); round 6's
+// second walk made it give the shared-pose Huber variant 192 without the hint
 #ifndef POP_MINWD
-#define POP_MINWD 1
+#define POP_MINWD 3
 #endif
 template <> struct PopCfg<double> : PopCfgT<double, POP_VD, POP_TCD, POP_MINWD> {};
 // Q2 in the float64 evaluation (profiles/r05_popeval_f64_isa_census.txt: 0 saves 11 instructions of 83 and moves one pole-adjacent
@@ -327,7 +329,12 @@ __device__ __forceinline__ void norm_coords(const T *r, const T (&qx)[V], const 
 
 // normalised DISTORTED coordinates (x1_d, y1_d of optimize.py:112-116) of V points whose normalised coordinates are in nc;
 // the stages are written one after the other over all V points (see above)
-template <typename T, int V>
+// EXACT_POLES: one reciprocal per denominator, as the reference divides (optimize.py:112-116).  The shared reciprocal below
+// is wrong exactly where ONE denominator is zero: 1/dx = dy . inf is still +-inf, but 1/dy = dx . inf = 0 . inf = NaN where the
+// reference's y1_d is finite -- a NaN loss instead of an infinite one.  popeval_kernel therefore walks a wave's share of a
+// stripe again with EXACT_POLES when one of its candidate sums came out infinite or NaN (rare: an out-of-frame vertex exactly
+// on a pole of the rational lens model, a vertex at the camera, a float32 overflow next to the camera plane).
+template <typename T, int V, bool EXACT_POLES = false>
 __device__ __forceinline__ void distort_group(const T *r, const NormCoords<T, V> &nc, T (&a)[V], T (&b)[V]) {
     using N = Num<T>;
     const T (&x1)[V] = nc.x1;
@@ -349,10 +356,15 @@ __device__ __forceinline__ void distort_group(const T *r, const NormCoords<T, V>
     for (int j = 0; j < V; ++j) {
         // one reciprocal for both denominators: 1/dx = dy / (dx dy), 1/dy = dx / (dx dy)  (float32: a quarter-rate
         // v_rcp_f32 saved; float64, since round 5: 3 multiplies instead of a second v_rcp_f64 + Newton steps + fix-up)
-        const T inv = N::rcp_pop(dx[j] * dy[j]);
-        const T idx = dy[j] * inv;
-        dy[j] = dx[j] * inv;
-        dx[j] = idx;
+        if constexpr (EXACT_POLES) {
+            dx[j] = N::rcp_pop(dx[j]);
+            dy[j] = N::rcp_pop(dy[j]);
+        } else {
+            const T inv = N::rcp_pop(dx[j] * dy[j]);
+            const T idx = dy[j] * inv;
+            dy[j] = dx[j] * inv;
+            dx[j] = idx;
+        }
     }
 #pragma unroll
     for (int j = 0; j < V; ++j) {
@@ -369,7 +381,7 @@ __device__ __forceinline__ void distort_group(const T *r, const NormCoords<T, V>
 // SHARED_POSE: every candidate of the call has the same rows 0..11 (only distortion
 // coefficients are optimised, the reference's second phase, example.py:75-78): the
 // normalised coordinates `pre` were computed once per point outside the candidate loop.
-template <typename T, int LOSS, int V, bool MASKED, bool SHARED_POSE>
+template <typename T, int LOSS, int V, bool MASKED, bool SHARED_POSE, bool EXACT_POLES = false>
 __device__ __forceinline__ T group_loss_sum(const T *r, const T (&qx)[V], const T (&qy)[V], const T (&qz)[V],
                                             const NormCoords<T, V> &pre, const T (&uoc)[V], const T (&voc)[V],
                                             const bool (&ok)[V], T f_scale) {
@@ -378,7 +390,7 @@ __device__ __forceinline__ T group_loss_sum(const T *r, const T (&qx)[V], const 
     if constexpr (!SHARED_POSE) norm_coords<T, V>(r, qx, qy, qz, own);
     const NormCoords<T, V> &nc = SHARED_POSE ? pre : own;
     T a[V], b[V], d2[V], dist[V];
-    distort_group<T, V>(r, nc, a, b);
+    distort_group<T, V, EXACT_POLES>(r, nc, a, b);
 #pragma unroll
     for (int j = 0; j < V; ++j) {
         // pixels u = a c0 + c0 (optimize.py:117-118): residual uo - u = (uo - c0) - c0 a
@@ -413,10 +425,9 @@ __device__ __forceinline__ T group_loss_sum(const T *r, const T (&qx)[V], const 
 // scipy's 2-point scheme needs D+1 evaluations per iteration, optimize.py:510-528).  Each point
 // is loaded once; the pose records are read with wave-uniform (scalar) loads.
 // out[b][i] = (uo - u_b, vo - v_b), b-major.
-// Round 5: RES_V points per lane through the population kernel's stages (norm_coords, distort_group: the float64 forms of round 5
-// -- one reciprocal for both denominators, v_div_fixup -- and RV independent chains between a transcendental and its use)
-// instead of one point through project_norm.
-// 22 poses x 10 M points, float64, kernel ms on one box: RES_V = 1: 0.825 | 2: 0.834 | 3: 0.771 | 4: 0.782
+// RES_V points per lane: independent chains between a transcendental and its use.  float32 runs the population kernel's stages
+// (norm_coords, distort_group with a reciprocal per denominator), float64 K1's project_norm (round 6: bit-equal to project()).
+// 22 poses x 10 M points, float64 through the population stages (round 5), kernel ms: RES_V = 1: 0.825 | 2: 0.834 | 3: 0.771 | 4: 0.782
 #ifndef RES_V
 #define RES_V 3
 #endif
@@ -439,10 +450,18 @@ __global__ __launch_bounds__(256) void residual_batch_kernel(const T *__restrict
         }
         for (int b = 0; b < B; ++b) {
             const T *r = poses[b].v;
-            NormCoords<T, V> nc;
-            norm_coords<T, V>(r, qx, qy, qz, nc);
             T xd[V], yd[V];
-            distort_group<T, V>(r, nc, xd, yd);
+            if constexpr (sizeof(T) == 8) {
+                // float64 (the parity mode): K1's own arithmetic point by point, so that the residuals ARE observed - project()
+                // bit for bit, as in the reference (optimize.py:233-236).  Round 5 ran the population kernel's stages here
+                // (0.77 against 0.83 ms of kernel at 22 poses x 10 M points, inside a call of 11 ms of PCIe time).
+#pragma unroll
+                for (int j = 0; j < V; ++j) project_norm<T>(r, qx[j], qy[j], qz[j], xd[j], yd[j]);
+            } else {
+                NormCoords<T, V> nc;
+                norm_coords<T, V>(r, qx, qy, qz, nc);
+                distort_group<T, V, true>(r, nc, xd, yd);           // a reciprocal per denominator: +-inf at a pole, like the reference
+            }
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 T u, v;
@@ -456,7 +475,7 @@ __global__ __launch_bounds__(256) void residual_batch_kernel(const T *__restrict
 
 // TS = element type of the planes in HBM, T = arithmetic type (TS = float with T = double is the
 // float64 re-evaluation of a float32 point set: alp_eval_population's argmin confirmation)
-template <typename T, int LOSS, int V, bool MASKED, bool SHARED_POSE, typename TS = T>
+template <typename T, int LOSS, int V, bool MASKED, bool SHARED_POSE, typename TS = T, bool EXACT_POLES = false>
 __device__ __forceinline__ void pop_group(const TS *__restrict__ x, const TS *__restrict__ y,
                                           const TS *__restrict__ z, const TS *__restrict__ uo,
                                           const TS *__restrict__ vo, int64_t base, int64_t end,
@@ -486,10 +505,29 @@ __device__ __forceinline__ void pop_group(const TS *__restrict__ x, const TS *__
 #pragma unroll
             for (int e = 0; e < Num<T>::VEC; ++e) r[k * Num<T>::VEC + e] = vget<T>(t, e);
         }
-        T acc = group_loss_sum<T, LOSS, V, MASKED, SHARED_POSE>(r, qx, qy, qz, pre, uoc, voc, ok, f_scale);
+        T acc = group_loss_sum<T, LOSS, V, MASKED, SHARED_POSE, EXACT_POLES>(r, qx, qy, qz, pre, uoc, voc, ok, f_scale);
         acc = wave_sum_to_lane63(acc);
         if (lane == 63) s_sum_wave[c] += (double)acc;
     }
+}
+
+// one workgroup's stripe [beg, end) against the tc staged records: wide groups of V rows, the rows they leave over two at a
+// time, the ragged last row masked
+template <typename T, int LOSS, int V, bool SHARED_POSE, typename TS, bool EXACT_POLES>
+__device__ __forceinline__ void pop_walk_stripe(const TS *__restrict__ x, const TS *__restrict__ y, const TS *__restrict__ z,
+                                                const TS *__restrict__ uo, const TS *__restrict__ vo, int64_t beg, int64_t end,
+                                                const PoseRec<T> *recs, double *s_sum_wave, int tc, T f_scale) {
+    // (the second walk, EXACT_POLES, goes row by row: it is rare, and its two reciprocals per point over V points in flight
+    // would set the kernel's register count -- 178 instead of 154 VGPRs in float64, two waves per SIMD instead of three)
+    constexpr int VW = EXACT_POLES ? 1 : V;
+    int64_t base = beg;
+    for (; base + 256 * VW <= end; base += 256 * VW)
+        pop_group<T, LOSS, VW, false, SHARED_POSE, TS, EXACT_POLES>(x, y, z, uo, vo, base, end, recs, s_sum_wave, tc, f_scale);
+    if constexpr (VW > 2)      // the rows left over by the wide groups, two at a time
+        for (; base + 512 <= end; base += 512)
+            pop_group<T, LOSS, 2, false, SHARED_POSE, TS, EXACT_POLES>(x, y, z, uo, vo, base, end, recs, s_sum_wave, tc, f_scale);
+    for (; base < end; base += 256)
+        pop_group<T, LOSS, 1, true, SHARED_POSE, TS, EXACT_POLES>(x, y, z, uo, vo, base, end, recs, s_sum_wave, tc, f_scale);
 }
 
 template <typename T, int LOSS, typename Cfg = PopCfg<T>, bool SHARED_POSE = false, typename TS = T>
@@ -523,15 +561,19 @@ __global__ __launch_bounds__(256, Cfg::MINW) void popeval_kernel(
             for (int i = tid; i < 4 * TC; i += 256) (&s_sum[0][0])[i] = 0.0;
         }
         __syncthreads();
-        int64_t base = beg;
-        const PoseRec<T> *recs = s_c;
-        for (; base + 256 * V <= end; base += 256 * V)
-            pop_group<T, LOSS, V, false, SHARED_POSE, TS>(x, y, z, uo, vo, base, end, recs, s_sum[wave], tc, f_scale);
-        if constexpr (V > 2)       // the rows left over by the wide groups, two at a time
-            for (; base + 512 <= end; base += 512)
-                pop_group<T, LOSS, 2, false, SHARED_POSE, TS>(x, y, z, uo, vo, base, end, recs, s_sum[wave], tc, f_scale);
-        for (; base < end; base += 256)
-            pop_group<T, LOSS, 1, true, SHARED_POSE, TS>(x, y, z, uo, vo, base, end, recs, s_sum[wave], tc, f_scale);
+        pop_walk_stripe<T, LOSS, V, SHARED_POSE, TS, false>(x, y, z, uo, vo, beg, end, s_c, s_sum[wave], tc, f_scale);
+        // A sum that is not finite stays so (inf and NaN are sticky under +): looked for ONCE per wave, tile and stripe -- nothing
+        // in the loop above pays for it.  The wave's rows are its own (lane t owns points t, t + 256, ...), so are its sums:
+        // it clears them and walks its share again with a reciprocal per denominator (distort_group), no barrier needed.
+        __builtin_amdgcn_wave_barrier();       // lane 63 wrote the sums, every lane reads them: same wave, LDS in order
+        bool bad = false;
+        for (int c = tid & 63; c < tc; c += 64)
+            bad |= (__builtin_bit_cast(unsigned long long, s_sum[wave][c]) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
+        if (__builtin_amdgcn_ballot_w64(bad) != 0) {
+            for (int c = tid & 63; c < tc; c += 64) s_sum[wave][c] = 0.0;
+            __builtin_amdgcn_wave_barrier();
+            pop_walk_stripe<T, LOSS, V, SHARED_POSE, TS, true>(x, y, z, uo, vo, beg, end, s_c, s_sum[wave], tc, f_scale);
+        }
         __syncthreads();
         if (tid < tc)
             partials[(int64_t)blockIdx.x * P + c0 + tid] =

@@ -265,7 +265,17 @@ int enqueue_popeval(alp_points *p, const double *cand, int64_t P, int loss_kind,
             }
         }
     }
-    if (const char *e = getenv("ALP_POP_GRID")) {           // tuning hook: "stripes,ytiles" (float32: any value gives the same losses)
+    if (sizeof(T) == 8) {
+        // the per-stripe partial sums (nblk x P doubles, read once per generation by reduce_partials_kernel) stay below 128 MB:
+        // 24 stripes per CU at P = 2048 are 100 MB (kept: 527 ms against 533 with 8 per CU); a population of 8192 gets 2048 stripes
+        const int64_t cap = ((int64_t)128 << 20) / (8 * P);
+        const int64_t lo = (int64_t)ctx().cu_count * 3;                  // one round of the three resident workgroups per CU
+        if (nblk > cap) nblk = (int)(cap > lo ? cap : lo);
+    }
+    // tuning hook: "stripes,ytiles".  float32: any value gives the same losses (float64 additions of float32 group sums of this
+    // magnitude are exact).  float64: the stripe count sets the ORDER of the float64 additions, so the last bits of the losses move
+    // with it -- a development switch, not a setting
+    if (const char *e = getenv("ALP_POP_GRID")) {
         const int tiles = (int)((P + PopCfg<T>::TC - 1) / PopCfg<T>::TC);
         int a = 0, b = 0;
         if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && b >= 1 && b <= tiles) { nblk = a; ytiles = b; }

@@ -34,12 +34,17 @@ import tempfile
 import threading
 import time
 from multiprocessing import AuthenticationError
-from multiprocessing.connection import Client, Listener
+from multiprocessing.connection import Client, Listener, answer_challenge, deliver_challenge
 
 __all__ = ["Hub", "Control", "spawn", "LaunchError", "gpu_nodes", "preflight"]
 
 HUB_ENV, KEY_ENV = "ALPROJ_HUB", "ALPROJ_HUB_KEY"
 COLLECTIVE_TIMEOUT_S = 3600.0
+HANDSHAKE_TIMEOUT_S = 10.0          # a peer that connects to the hub has this long to answer the key challenge
+
+
+class _HandshakeTimeout(Exception):
+    """a peer connected to the hub and did not answer the key challenge in time"""
 
 
 class LaunchError(RuntimeError):
@@ -118,6 +123,38 @@ class Hub:
         except OSError:
             pass
 
+    def _accept_authenticated(self):
+        """Listener.accept() with a deadline on the key handshake.  Listener's own runs the HMAC challenge on the accepted,
+        BLOCKING connection: a local process that connects and then says nothing would park the hub in it for ever (the
+        listening socket's timeout does not reach that far).  Here the challenge runs on a helper thread; a peer that has
+        not answered within HANDSHAKE_TIMEOUT_S is hung up on."""
+        try:
+            raw = self.listener._listener.accept()            # the connection, no handshake yet
+        except AttributeError:                                 # another Python's Listener internals: its own accept, as before
+            return self.listener.accept()
+        failure = []
+
+        def handshake():
+            try:
+                deliver_challenge(raw, self.authkey)
+                answer_challenge(raw, self.authkey)
+            except BaseException as e:                         # noqa: BLE001 -- handed to the accepting thread below
+                failure.append(e)
+
+        t = threading.Thread(target=handshake, name="alproj-hub-handshake", daemon=True)
+        t.start()
+        t.join(HANDSHAKE_TIMEOUT_S)
+        if t.is_alive():
+            raw.close()                                        # the helper's recv fails and it ends
+            t.join(1.0)
+            raise _HandshakeTimeout()
+        if failure:
+            raw.close()
+            if isinstance(failure[0], (AuthenticationError, EOFError, OSError)):
+                raise AuthenticationError(str(failure[0]))
+            raise failure[0]
+        return raw
+
     def _serve(self):
         conns = [None] * self.world
         try:
@@ -129,11 +166,11 @@ class Hub:
             joined = 0
             while joined < self.world:
                 try:
-                    c = self.listener.accept()
+                    c = self._accept_authenticated()
                 except TimeoutError:
                     raise LaunchError(f"only {joined} of {self.world} ranks reached the hub within {COLLECTIVE_TIMEOUT_S:.0f} s") from None
-                except (AuthenticationError, EOFError, ConnectionError):
-                    continue            # a stranger, or a rank of another job with that job's key: not ours, keep listening
+                except (AuthenticationError, EOFError, ConnectionError, _HandshakeTimeout):
+                    continue            # a stranger, a silent one, or a rank of another job with that job's key: not ours, keep listening
                 joined += 1
                 op, rank = _recv(c)
                 if op != "hello" or not isinstance(rank, int) or not (0 <= rank < self.world) or conns[rank] is not None:

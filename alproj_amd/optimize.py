@@ -86,6 +86,16 @@ def _columns(frame, names):
     return [np.ascontiguousarray(c, dtype=np.float64) for c in cols]
 
 
+def _first_two_columns(frame):
+    """columns 0 and 1 of a DataFrame, whatever their labels, without copying where they lie contiguous"""
+    if frame.shape[1] < 2:
+        raise IndexError("index 1 is out of bounds for axis 1 with size %d" % frame.shape[1])      # numpy's, as the reference raises it
+    cols = [frame.iloc[:, k].to_numpy() for k in (0, 1)]
+    if all(c.dtype == np.float64 and c.flags["C_CONTIGUOUS"] for c in cols):
+        return cols
+    return [np.ascontiguousarray(c, dtype=np.float64) for c in cols]
+
+
 def _xyz_array(obj_points):
     if isinstance(obj_points, pd.DataFrame):
         return _columns(obj_points, ["x", "y", "z"])
@@ -171,7 +181,9 @@ def _uv_pointers(a):
 def _loss_uv(img_points, projected, kind, f_scale):
     """rmse / huber_loss of two tables of pixel coordinates: each goes to the device as it lies -- row-major pairs or two
     columns (what project() returns) -- through alp_loss_uv_columns; no host-side interleaving"""
-    prj = _columns(projected, ["u", "v"]) if isinstance(projected, pd.DataFrame) else projected
+    # the reference takes `projected` BY POSITION (projected.to_numpy()[:, 0], [:, 1]: optimize.py:175-176, 203-206) and only
+    # img_points by name: an unlabelled frame works, a frame ordered [v, u] is read as it lies
+    prj = _first_two_columns(projected) if isinstance(projected, pd.DataFrame) else projected
     ou, ov, n_obs, keep_o = _uv_pointers(_uv_array(img_points))
     pu, pv, n_prj, keep_p = _uv_pointers(prj)
     if n_obs != n_prj:

@@ -52,13 +52,13 @@ VALU_PEAK_F64 = 78.6e12    # flop/s fp64 vector (MI355X_MICROARCH.md)
 BYTES_PER_VERTEX = {"f32": 20, "f64": 40}     # 3 coordinates in + 2 pixel coordinates out
 EVAL_FLOPS = 76            # flop per point-candidate evaluation (Huber): 30 fma + 12 + 4 transcendental (+ 1/6 multiply), DESIGN.md section 4 (K2)
 PROFILES = os.path.join(ROOT, "profiles")
-ROUNDS = ("r05", "r04", "r03", "r02", "r01")      # committed counter summaries: the newest round wins
+ROUNDS = ("r06", "r05", "r04", "r03", "r02", "r01")      # committed counter summaries: the newest round wins
 
 # The driver's record keeps the first 24 keys of `roofline`: exactly these, in this order, are emitted there -- the five BASELINE
 # configs (c2-sized headline, c5-shaped CMA-ES, c3, c4) and the float64 mode; everything else goes to `roofline_detail`
 # (tests/test_bench_record.py holds the cap and the names).
-ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "bytes_per_vertex",
-                 "strict_1e-5_relative_pass",
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms",
+                 "scaled_1e-5_pass", "strict_1e-5_relative_pass",
                  "cma_iters_per_s", "cma_kernel_ms", "cma_valu_frac", "cma_all_reduce_ms",
                  "f64_gpoints_per_s", "f64_hbm_frac", "f64_strict_1e-5_pass",
                  "c3_iters_per_s", "c3_kernel_ms", "c3_valu_frac",
@@ -236,18 +236,30 @@ def cpu_baseline(orc, truth, base, targets, bounds_fn, xyz_l, obs, n_total, pop)
     }
 
 
+TOLERANCES = {
+    # north_star: "outputs match the reference ... to 1e-5 relative".  The two readings the record reports:
+    "strict": "|got - ref| <= 1e-5 * |ref|  (north_star as worded)",
+    "scaled": "|got - ref| <= 1e-5 * max(|ref|, image width)  (relative to the size of the image)",
+}
+
+
 def parity_report(got, ref, w):
-    """float32 (or float64) projection against the float64 oracle: the bound the mode is held to
-    (1e-5 of max(|ref|, image width): float32 COORDINATES at distance D are uncertain by D * 2^-24, which
-    moves a pixel by up to fx * 2^-24 ~ 2e-4 px whatever the arithmetic), plus what the strict
-    north-star reading (1e-5 of |ref|) gives."""
+    """A projection against the float64 oracle under BOTH readings of north_star's "1e-5 relative" (TOLERANCES).
+    float64 mode meets the strict one on every value.  float32 meets the scaled one on every value and the strict one on
+    all but the small |ref|: a float32 COORDINATE at distance D is uncertain by D * 2^-24, which moves a pixel by up to
+    fx * 2^-24 ~ 2e-4 px whatever the arithmetic -- more than 1e-5 |ref| below |ref| ~ 20 px."""
     d = np.abs(got - ref)
     fin = np.isfinite(ref) & np.isfinite(got)
+    strict = float((d[fin] <= 1e-5 * np.abs(ref[fin])).mean())
+    scaled = float((d[fin] <= 1e-5 * np.maximum(np.abs(ref[fin]), w)).mean())
     return {"checked_values": int(fin.sum()),
+            "definitions": TOLERANCES,
+            "strict_1e-5_relative_pass_fraction": strict,
+            "scaled_1e-5_pass_fraction": scaled,
+            "meets": "strict" if strict == 1.0 else ("scaled" if scaled == 1.0 else "neither"),
             "max_err_rel_to_max(|ref|,w)_vs_f64_oracle": float((d[fin] / np.maximum(np.abs(ref[fin]), w)).max()),
             "tolerance": 1e-5,
-            "max_abs_err_px": float(d[fin].max()),
-            "strict_1e-5_relative_pass_fraction": float((d[fin] <= 1e-5 * np.abs(ref[fin])).mean())}
+            "max_abs_err_px": float(d[fin].max())}
 
 
 def committed_summary(name):
@@ -301,25 +313,46 @@ def pmc_traffic(name):
     return None, None
 
 
+PROFILER_ENV_MARKS = ("ROCP_", "ROCPROF", "ROCPROFILER_", "ROCTRACER_")
+
+
+def under_a_profiler(env=None):
+    """is this process itself running under rocprofv3 / rocprof?  (its tool library is preloaded and its ROCP_* variables are
+    inherited by every child: a second profiler nested inside would count into the first one's output, or fail)"""
+    env = os.environ if env is None else env
+    if any(k.startswith(PROFILER_ENV_MARKS) for k in env):
+        return True
+    return any(w in env.get("LD_PRELOAD", "") for w in ("rocprofiler", "roctracer", "rocprof"))
+
+
 def live_traffic(vertices, timeout_s=170.0):
     """roofline.traffic MEASURED in this run: HBM bytes per launch of the headline kernel from the PMC counters, collected as
     MI355X_MICROARCH.md prescribes -- two separate `rocprofv3 --kernel-trace --pmc` passes (FETCH_SIZE, doubled on gfx950;
     WRITE_SIZE) -- over a CHILD process (tools/probe_project.py: the same kernel on a DSM of the same size; this process
     cannot put itself under the profiler).  Returns (bytes per launch, source) or (None, why not): the caller then falls back
-    on the committed summary.  The child is ended by PID if it outlives the limit."""
+    on the committed summary and the line names the reason.  The child is ended by PID if it outlives the limit.
+
+    Nothing is written inside the checkout (it may be read-only): the profiler's output and the summary live in ONE
+    tempfile.mkdtemp() directory outside the tree, removed on every way out -- success, timeout, a failing pass."""
     import shutil
     import subprocess
     import tempfile
+    if under_a_profiler():
+        return None, "this run is itself under a profiler (ROCP_* / rocprofiler preload in the environment): no nested PMC pass"
     if not shutil.which("rocprofv3"):
         return None, "rocprofv3 not on PATH"
     tool, probe = os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(ROOT, "tools", "probe_project.py")
     if not (os.path.exists(tool) and os.path.exists(probe)):
         return None, "tools/pmc_traffic.py or tools/probe_project.py missing"
-    out_json = os.path.join(tempfile.mkdtemp(prefix="alproj_pmc_"), "traffic.json")
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)        # the tool keeps its rocprof output there
-    cmd = [sys.executable, tool, out_json, "3", "project_kernel", "--", sys.executable, probe, str(vertices), "3", "f32"]
     try:
-        p = subprocess.Popen(cmd, cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp", PMC_TRAFFIC_CLEANUP="1"), stdin=subprocess.DEVNULL,
+        work = tempfile.mkdtemp(prefix="alproj_pmc_")            # $TMPDIR or /tmp: never the checkout
+    except OSError as e:
+        return None, f"no writable temporary directory ({e})"
+    try:
+        out_json = os.path.join(work, "traffic.json")
+        cmd = [sys.executable, tool, out_json, "3", "project_kernel", "--", sys.executable, probe, str(vertices), "3", "f32"]
+        env = dict(os.environ, TMPDIR=work, PMC_TRAFFIC_DIR=work, PYTHONDONTWRITEBYTECODE="1")
+        p = subprocess.Popen(cmd, cwd=work, env=env, stdin=subprocess.DEVNULL,
                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
         try:
             rc = p.wait(timeout=timeout_s)
@@ -333,7 +366,6 @@ def live_traffic(vertices, timeout_s=170.0):
         if rc != 0:
             return None, f"tools/pmc_traffic.py exited with {rc}"
         doc = json.load(open(out_json))
-        shutil.rmtree(os.path.dirname(out_json), ignore_errors=True)
         k = [v for name, v in doc["kernels"].items() if "project_kernel<float>" in name]
         if not k or not k[0].get("hbm_bytes_per_frame"):
             return None, "no counters for project_kernel<float> in the passes"
@@ -341,6 +373,8 @@ def live_traffic(vertices, timeout_s=170.0):
                                                     f"passes over tools/probe_project.py {vertices} 3 f32 (a child process, the same kernel and size)")
     except Exception as e:                       # the measurement must never take the line down with it
         return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def cma_loop(L, CMA, pts, base, targets, bounds_fn, pop, loss_kind, f_scale, seed=1234):
@@ -713,16 +747,20 @@ def main():
         "value": gpts, "unit": "Gpoints/s", "n_gpus": ctl.world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": f"{n_total}-vertex synthetic DSM ({n_side}x{n_side} grid), single-pose forward "
-                               "projection, 5616x3744 camera, vertices resident in HBM as SoA planes",
+        # (strings of at most 128 characters: the driver's record cuts longer ones)
+        "config": {"workload": f"{n_total}-vertex synthetic DSM ({n_side}x{n_side}), single-pose projection, 5616x3744 camera, SoA planes in HBM",
                    "vertices": n_total, "vertices_per_gpu": n_local, "sharding": f"rows/{ctl.world}",
-                   "precision": args.precision},
+                   "precision": args.precision, "bytes_per_vertex": bpv,
+                   # which number meets which reading of north_star's "1e-5 relative" (pass fractions: roofline.*_pass)
+                   "tol_strict": "|d|<=1e-5|ref|: met by the float64 mode (roofline.f64_gpoints_per_s, f64_hbm_frac; 40 B/vertex)",
+                   "tol_scaled": "|d|<=1e-5 max(|ref|,w): met by `value` (float32, 20 B/vertex); strict: roofline.strict_1e-5_relative_pass"},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "traffic": traffic,
                      "traffic_source": f"{traffic_src} (rocprofv3 --pmc, bytes/vertex x vertices per launch)" if traffic else None,
                      "kernel": "project_kernel", "kernel_ms": kern_s * 1e3,
                      "kernel_ms_median_of_single_launches": float(np.median(per_launch)), "single_launches": len(per_launch),
                      "bytes_per_vertex": bpv, "vertices_per_launch": n_local,
+                     "scaled_1e-5_pass": parity["scaled_1e-5_pass_fraction"],
                      "strict_1e-5_relative_pass": parity["strict_1e-5_relative_pass_fraction"]},
         "parity": parity,
         "device": info, "setup_s": t_gen,
@@ -1068,6 +1106,7 @@ def main():
             out["roofline"]["traffic_source"] = why
         else:
             out["roofline"]["traffic_live_measurement_failed"] = why
+            out["roofline"]["traffic_source"] = (f"{out['roofline'].get('traffic_source') or 'no committed summary'}; NOT measured in this run: {why}")
         out["roofline"]["traffic_live_seconds"] = time.perf_counter() - t_pmc
     out["roofline"], out["roofline_detail"] = driver_roofline(out["roofline"])
     ctl.barrier()            # every rank has finished its collectives

@@ -184,7 +184,10 @@ int alp_projected_fetch_strided(alp_points_t *pts, int64_t first, int64_t stride
                                 int64_t count, double *u_out, double *v_out);
 
 /* Residual vector (observed - projected), interleaved du0,dv0,du1,dv1,... (2n doubles):
- * replaces compute_residuals(), src/alproj/optimize.py:215-237.  Needs observed uv. */
+ * replaces compute_residuals(), src/alproj/optimize.py:215-237.  Needs observed uv.
+ * Float64 point sets: bit for bit `observed - alp_project()`, the identity the reference has by construction
+ * (:233-236) -- the kernel runs alp_project's own arithmetic.  Float32 sets: same formula, one reciprocal per
+ * denominator (+-inf at a pole of the lens model, like the reference), not bit-equal to alp_project's float32. */
 int alp_residuals(alp_points_t *pts, const double params[ALP_NPARAM], double *out);
 /* The same for B parameter vectors in one launch (cand: B x 25 row-major; out: B x 2n doubles,
  * row b = residual vector of pose b): the D+1 evaluations of a 2-point finite-difference
@@ -204,6 +207,12 @@ int alp_residuals_batch(alp_points_t *pts, const double *cand, int64_t B, double
  * of those candidates are evaluated again in float64 arithmetic on the stored points before
  * the index is returned (the north star's "argmin bit-exact"); loss_out then holds the
  * float64 re-evaluations for THOSE candidates and the float32-path losses for all others.
+ * Poles of the rational lens model (src/alproj/optimize.py:112-116: a vertex for which EXACTLY one of
+ * 1 + k4 r2 + k5 r4 + k6 r6 and 1 + a2 + k4 r2 + ... is zero): the reference's coordinate on that axis is +-inf, the
+ * other finite, the candidate's loss +inf.  The kernel shares one reciprocal between the two denominators, which
+ * would turn the finite coordinate into NaN; a wave whose sum for a candidate comes out infinite or NaN therefore walks
+ * its share of the points again with a reciprocal per denominator, so the loss is +inf as in the reference (NaN only
+ * where the reference is NaN too: a vertex at the camera, 0 * inf).  tests/test_gpu_points.py constructs the case.
  * argmin_out == NULL: losses only, no confirmation pass (the reference uses the argmin of the LAST
  * generation only, src/alproj/optimize.py:427; every earlier generation needs the losses for
  * CMA.tell and nothing else).

@@ -108,9 +108,17 @@ def test_population_100m_shard_additivity(L, dsm):
 
 
 def test_projection_100m_every_vertex(L, dsm):
-    """the bench workload itself: all 100 M vertices projected in float32 (the fast mode) against
-    the float64 numpy oracle, chunk by chunk -- north_star tolerance 1e-5 relative to
-    max(|ref|, image width); float64 mode on one chunk at 1e-9; projecting twice is idempotent"""
+    """the bench workload itself: all 100 M vertices against the float64 numpy oracle, chunk by chunk, in BOTH modes.
+
+    north_star's tolerance is "1e-5 relative".  Two readings, both reported and asserted:
+      strict  |d| <= 1e-5 |ref|                      -- as north_star words it
+      scaled  |d| <= 1e-5 max(|ref|, image width)    -- relative to the size of the image
+    float64 mode (the reference's own arithmetic; 40 B/vertex): meets the STRICT reading on every value of every vertex
+      (and 1e-9 of max(|ref|, 1 px)).
+    float32 mode (the headline `value`; 20 B/vertex as SURVEY 8(d) prices the unit): meets the SCALED reading on every
+      value; the strict one on > 99.9 % -- the floor is the float32 INPUT: a coordinate at distance D is uncertain by
+      D 2^-24, which moves a pixel by ~2e-4 px whatever the arithmetic, more than 1e-5 |ref| below |ref| ~ 20 px.
+    Projecting twice is idempotent."""
     from alproj_amd import synthetic as syn
     n, s = dsm
     xyz = syn.vert_to_xyz_local(s["vert"])
@@ -123,27 +131,35 @@ def test_projection_100m_every_vertex(L, dsm):
     pts.project(L.params_vector(truth))
     u2, v2 = pts.fetch(np.float32)
     assert np.array_equal(u, u2) and np.array_equal(v, v2)
+    del u2, v2
     pts.close()
-    worst = worst_px = 0.0
-    strict_ok = total = 0
+    p64 = L.Points(xyz, origin, "f64")              # the same float32 coordinates, float64 arithmetic and pixels
+    p64.project(L.params_vector(truth))
+    u64, v64 = p64.fetch(np.float64)
+    p64.close()
+    worst = worst_px = worst64 = worst64_strict = 0.0
+    strict_ok = strict64_ok = total = 0
     chunk = 10_000_000
     for a in range(0, len(xyz), chunk):
         ref = orc.project_points(xyz[a:a + chunk].astype(np.float64), truth)
+        assert np.isfinite(ref).all()
         got = np.stack([u[a:a + chunk], v[a:a + chunk]], 1).astype(np.float64)
         d = np.abs(got - ref)
         worst = max(worst, float((d / np.maximum(np.abs(ref), truth["w"])).max()))
         worst_px = max(worst_px, float(d.max()))
         strict_ok += int((d <= 1e-5 * np.abs(ref)).sum())
         total += d.size
-    print(f"[f32 parity] 100 M vertices: max |d| = {worst_px:.3e} px, max |d| / max(|ref|, w) = {worst:.3e}, "
+        d64 = np.abs(np.stack([u64[a:a + chunk], v64[a:a + chunk]], 1) - ref)
+        worst64 = max(worst64, float((d64 / np.maximum(np.abs(ref), 1.0)).max()))
+        strict64_ok += int((d64 <= 1e-5 * np.abs(ref)).sum())
+        nz = np.abs(ref) > 0
+        worst64_strict = max(worst64_strict, float((d64[nz] / np.abs(ref[nz])).max()))
+        del ref, got, d, d64
+    print(f"[f32 parity] 100 M vertices: max |d| = {worst_px:.3e} px, scaled max |d| / max(|ref|, w) = {worst:.3e}, "
           f"strict 1e-5-relative pass fraction = {strict_ok / total:.8f}")
-    assert worst <= 1e-5, worst
-    assert worst_px <= 5e-3 and strict_ok / total > 0.999
-    sub = xyz[:chunk]
-    p64 = L.Points(sub, origin, "f64")
-    p64.project(L.params_vector(truth))
-    u64, v64 = p64.fetch(np.float64)
-    p64.close()
-    ref = orc.project_points(sub.astype(np.float64), truth)
-    rel = np.abs(np.stack([u64, v64], 1) - ref) / np.maximum(np.abs(ref), 1.0)
-    assert float(rel.max()) <= 1e-9
+    print(f"[f64 parity] 100 M vertices: max |d| / max(|ref|, 1 px) = {worst64:.3e}, strict max |d| / |ref| = {worst64_strict:.3e}, "
+          f"strict 1e-5-relative pass fraction = {strict64_ok / total:.10f} ({total - strict64_ok} of {total} values fail)")
+    assert worst <= 1e-5, worst                                     # float32: the scaled reading, every value
+    assert worst_px <= 5e-3 and strict_ok / total > 0.999           # ... and the strict one on all but the small |ref|
+    assert worst64 <= 1e-9, worst64                                 # float64: 1e-9 of max(|ref|, 1 px), every value
+    assert strict64_ok == total and worst64_strict <= 1e-5          # float64: north_star's strict 1e-5 relative, every value

@@ -216,7 +216,10 @@ def test_losses_take_either_table_layout(L):
     prj = obs + rng.normal(0, 6.0, (n, 2))
     forms_o = [obs, np.asfortranarray(obs), pd.DataFrame(obs, columns=["u", "v"]), pd.DataFrame({"u": obs[:, 0], "v": obs[:, 1]}),
                pd.DataFrame({"v": obs[:, 1], "k": 1, "u": obs[:, 0]})]
-    forms_p = [prj, np.asfortranarray(prj), pd.DataFrame(prj, columns=["u", "v"]), pd.DataFrame({"u": prj[:, 0].copy(), "v": prj[:, 1].copy()}, copy=False)]
+    # `projected` is taken BY POSITION like the reference's projected.to_numpy() (optimize.py:175, 203): an unlabelled frame,
+    # other labels, a third column behind the two
+    forms_p = [prj, np.asfortranarray(prj), pd.DataFrame(prj, columns=["u", "v"]), pd.DataFrame({"u": prj[:, 0].copy(), "v": prj[:, 1].copy()}, copy=False),
+               pd.DataFrame(prj), pd.DataFrame(prj, columns=["col", "row"]), pd.DataFrame({"u": prj[:, 0], "v": prj[:, 1], "extra": 7.0})]
     want_r, want_h = orc.mean_distance(obs, prj), orc.huber(obs, prj, 10.0)
     seen = set()
     for a in forms_o:
@@ -225,6 +228,11 @@ def test_losses_take_either_table_layout(L):
     assert len(seen) == 1
     r, h = seen.pop()
     assert r == pytest.approx(want_r, rel=1e-13) and h == pytest.approx(want_h, rel=1e-13)
+    # a frame ordered [v, u] is read as it lies (position 0 against the observed u), as the reference reads it
+    swapped = pd.DataFrame({"v": prj[:, 1], "u": prj[:, 0]})
+    assert opt.rmse(obs, swapped) == pytest.approx(orc.mean_distance(obs, prj[:, ::-1]), rel=1e-13)
+    with pytest.raises(IndexError):
+        opt.rmse(obs, pd.DataFrame({"u": prj[:, 0]}))
     with pytest.raises(ValueError):
         opt.rmse(obs, prj[:-1])
     assert np.isnan(opt.rmse(np.zeros((0, 2)), np.zeros((0, 2))))
@@ -425,6 +433,110 @@ def test_population_nan_semantics(L):
         pts.set_observed(uv)
         losses, amin = pts.eval_population(cands, L.LOSS_MEAN_DIST, 0.0)
     assert np.isnan(losses[0]) and np.isfinite(losses[1]) and amin == 1
+
+
+def _oracle_r2(xyz, p):
+    """r2 of optimize.py:105-108 for every point, formed operation by operation as oracle.ref_numpy.project_points /
+    distort_points form it (so that a denominator built from it is zero in the ORACLE's arithmetic)"""
+    hom = np.vstack((np.asarray(xyz, dtype=np.float64).T, np.ones((1, len(xyz)))))
+    kmat = orc.intrinsic_mat(p["fov"], p["w"], p["h"], p["cx"], p["cy"])
+    emat = orc.extrinsic_mat(p["pan"], p["tilt"], p["roll"], p["x"], p["y"], p["z"])
+    img = np.dot(kmat, np.dot(emat, hom)[:3, :])
+    uv = np.array([p["w"] - img[0, :] / img[2, :], img[1, :] / img[2, :]]).T
+    c = np.array([(p["w"] - 1) / 2, (p["h"] - 1) / 2], dtype="float32")
+    x = (uv[:, 0] - c[0]) / c[0]
+    y = (uv[:, 1] - c[1]) / c[1]
+    return ((x ** 2 + y ** 2) ** 0.5) ** 2
+
+
+@pytest.mark.parametrize("variant", ["shared_pose", "general"])
+@pytest.mark.parametrize("kind,fs", [(0, 0.0), (1, 10.0)], ids=["mean_dist", "huber"])
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_pole_of_one_lens_denominator_is_an_infinite_loss(L, prec, kind, fs, variant):
+    """optimize.py:112-116 at a vertex where EXACTLY ONE denominator of the rational lens model is zero: the reference's
+    coordinate on that axis is +-inf, the other finite, the candidate's loss +inf.  The kernel shares one reciprocal between
+    the two denominators (0 * inf = NaN on the finite axis) and must put that right: +inf, never NaN, never the argmin, and
+    CMA.tell's order the same as with the oracle's inf.
+
+    Construction.  k4 = -0.5, k5 = k6 = 0: den_y = (1 + a2) - r2 / 2 is zero iff 1 + a2 == r2 / 2 bit for bit (the product
+    -0.5 r2 is exact), den_x = 1 - r2 / 2 is not.  r2 of the chosen out-of-frame vertex is known to a few ulps only (the
+    device's reciprocal and, for float32, its rounded coordinates), so the population steps 1 + a2 ulp by ulp through
+    r2 / 2 +- W ulps: one of the candidates sits exactly on the device's pole.  The oracle's own pole is r2_oracle / 2."""
+    from alproj_amd import synthetic as syn
+    from alproj_amd.cma import CMA
+    truth = dict(syn.truth_params(316), k4=-0.5, k5=0.0, k6=0.0)
+    xyz = syn.gcp_points(400, truth, seed=31, margin=-0.25)            # a quarter of the frame beyond each edge
+    r2 = _oracle_r2(xyz, truth)
+    i0 = int(np.argmin(np.abs(r2 - 1.4)))                               # den_x = 1 - r2/2 ~ 0.3 there
+    assert 1.2 < r2[i0] < 1.6
+    # nobody else near a pole of either denominator of the SANE candidates (den_x = 1 - r2/2, den_y = 1 + a2 - r2/2)
+    keep = (np.abs(1 - r2 / 2) > 0.25) & (np.abs(1 + truth["a2"] - r2 / 2) > 0.25)
+    keep[i0] = True
+    i = int(np.count_nonzero(keep[:i0]))
+    xyz, r2 = xyz[keep], r2[keep]
+    assert len(xyz) > 100
+    uv = orc.project_points(xyz, truth) + np.random.default_rng(31).normal(0, 1.0, (len(xyz), 2))
+    assert np.isfinite(uv).all()
+    T = np.float64 if prec == "f64" else np.float32
+    W = 64 if prec == "f64" else 400
+    centre = T(r2[i] / 2)
+    targets = [centre]
+    up = down = centre
+    for _ in range(W):
+        up = np.nextafter(up, T(4))
+        down = np.nextafter(down, T(0))
+        targets += [up, down]
+    a2 = np.array([np.float64(t) - 1.0 for t in targets])              # 1 + a2 == t exactly (Sterbenz: t in [0.5, 2])
+    assert all(T(1.0 + a) == t for a, t in zip(a2, targets))
+    cand = np.tile(L.params_vector(truth), (len(a2) + 2, 1))
+    cand[2:, L.PARAM_KEYS.index("a2")] = a2
+    cand[1, L.PARAM_KEYS.index("a1")] += 0.01                           # two sane candidates in front
+    if variant == "general":
+        cand[0, L.PARAM_KEYS.index("pan")] += 0.01                      # one pose differs: the general kernel variant
+    with L.Points(xyz, [truth["x"], truth["y"], truth["z"]], prec) as pts:
+        pts.set_observed(uv)
+        losses, amin = pts.eval_population(cand, kind, fs)
+        hit = np.flatnonzero(~np.isfinite(losses))
+        assert len(hit) >= 1, "no candidate landed on the device's pole: widen W"
+        assert np.all(np.isposinf(losses[hit])), losses[hit]            # +inf like the reference, not NaN
+        assert amin in (0, 1) and amin == int(np.argmin(losses))
+        # the two sane candidates are untouched by the second walk their wave made for the pole candidate's sake
+        ref2 = np.array([orc.loss_of(xyz, uv, orc.vector_to_params(c), kind, fs) for c in cand[:2]])
+        np.testing.assert_allclose(losses[:2], ref2, rtol=1e-9 if prec == "f64" else 1e-5)
+        # small population: [sane, sane, ON the pole]; the oracle sits on ITS pole (r2 as numpy forms it)
+        small = cand[[0, 1, int(hit[0])]]
+        l_dev, amin_small = pts.eval_population(small, kind, fs)
+    o_pole = cand[int(hit[0])].copy()
+    o_pole[L.PARAM_KEYS.index("a2")] = r2[i] / 2 - 1.0
+    l_ref = np.array(list(ref2) + [orc.loss_of(xyz, uv, orc.vector_to_params(o_pole), kind, fs)])
+    assert np.isposinf(l_ref[2]), "the oracle's own pole candidate must be infinite (optimize.py:115)"
+    assert np.isposinf(l_dev[2]) and amin_small == int(np.argmin(l_ref))
+    orders = []
+    for values in (l_dev, l_ref):
+        es = CMA(mean=np.full(3, 0.5), sigma=0.2, bounds=np.tile([0.0, 1.0], (3, 1)), population_size=3, seed=1)
+        sol = [(np.full(3, 0.1 * (k + 1)), float(v)) for k, v in enumerate(values)]
+        es.tell(sol)
+        orders.append([round(s[0][0] * 10) - 1 for s in sol])
+    assert orders[0] == orders[1] and orders[0][-1] == 2               # same order; the pole candidate last
+
+
+def test_residuals_are_observed_minus_project_bit_for_bit_f64(L):
+    """optimize.py:233-236: compute_residuals IS (img_points - project(...)).flatten(); the float64 kernel keeps the identity
+    to the bit (it runs alp_project's arithmetic), also next to the camera plane and at a pole"""
+    from alproj_amd import synthetic as syn
+    truth = dict(syn.truth_params(316), k4=-0.5, k5=0.01, k6=0.002)
+    xyz = syn.gcp_points(5000, truth, seed=41, margin=-0.3)
+    uv = np.random.default_rng(41).uniform(0, 5000, (5000, 2))
+    with L.Points(xyz, [truth["x"], truth["y"], truth["z"]], "f64") as pts:
+        pts.set_observed(uv)
+        vec = L.params_vector(truth)
+        pts.project(vec)
+        u, v = pts.fetch()
+        res = pts.residuals(vec)
+        batch = pts.residuals_batch(np.stack([vec, vec]))
+    want = (uv - np.stack([u, v], 1)).ravel()
+    assert np.array_equal(res, want)
+    assert np.array_equal(batch[0], want) and np.array_equal(batch[1], want)
 
 
 @pytest.mark.parametrize("prec,rtol", [("f64", 1e-12), ("f32", 2e-6)])

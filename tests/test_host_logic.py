@@ -478,3 +478,18 @@ def test_prefault_leaves_the_buffer_usable():
     big = L.result_empty((40 << 20,), np.uint8)          # a pool miss: populated before it is handed out
     big[:] = 1
     assert int(big[:: 1 << 20].sum()) == 40
+
+
+def test_projected_table_is_taken_by_position():
+    """rmse / huber_loss read `projected` as the reference does -- projected.to_numpy()[:, 0], [:, 1] (optimize.py:175-176,
+    203-206) -- so labels do not matter and an unlabelled frame works (the round-5 advisor's finding: KeyError('u'))"""
+    import pandas as pd
+    from alproj_amd import optimize as opt
+    a = np.arange(12.0).reshape(6, 2)
+    for frame in (pd.DataFrame(a), pd.DataFrame(a, columns=["col", "row"]), pd.DataFrame({"v": a[:, 0], "u": a[:, 1]}),
+                  pd.DataFrame({"u": a[:, 0], "v": a[:, 1], "extra": 1.0}), pd.DataFrame(a.astype(np.float32))):
+        c0, c1 = opt._first_two_columns(frame)
+        assert c0.dtype == np.float64 and c0.flags["C_CONTIGUOUS"] and c1.flags["C_CONTIGUOUS"]
+        assert np.array_equal(c0, a[:, 0]) and np.array_equal(c1, a[:, 1])
+    with pytest.raises(IndexError):
+        opt._first_two_columns(pd.DataFrame({"u": a[:, 0]}))

@@ -174,6 +174,30 @@ def test_a_stranger_at_the_door_does_not_stop_the_hub():
     assert hub.error is None and res == [[0, 1], [0, 1]]
 
 
+def test_a_silent_stranger_who_stays_connected_is_hung_up_on(monkeypatch):
+    """a peer that connects and never answers the key challenge used to park the hub inside Listener.accept's blocking
+    handshake for ever (the listening socket's timeout does not apply to the accepted connection): the ranks behind it in
+    the queue never got in.  Now the handshake has its own deadline."""
+    monkeypatch.setattr(launch, "HANDSHAKE_TIMEOUT_S", 0.5)
+    hub = launch.Hub(2).start()
+    silent = socket.create_connection(hub.address)     # first in the queue, stays open, sends nothing
+    res = []
+
+    def rank(r):
+        c = launch.Control(r, 2, r, launch.Control._connect(lambda: (hub.address, hub.authkey), r, 30.0))
+        res.append(c.gather(r))
+        c.close()
+
+    t0 = time.time()
+    th = [threading.Thread(target=rank, args=(r,)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(30) for t in th]
+    hub.join(5)
+    silent.close()
+    assert hub.error is None and res == [[0, 1], [0, 1]]
+    assert time.time() - t0 < 10
+
+
 def test_nothing_received_is_unpickled():
     """a peer that knows the key and speaks pickle (Connection.send) gets an error; the hub does not build its object"""
     from multiprocessing.connection import Client

@@ -13,6 +13,7 @@ KERNEL_FILTER = comma-separated substrings of kernel names to keep ("" = all but
 import collections
 import json
 import os
+import shutil
 import sqlite3
 import subprocess
 import sys
@@ -22,16 +23,27 @@ out_json, divisor, flt = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 cmd = sys.argv[sys.argv.index("--") + 1:]
 filters = [f for f in flt.split(",") if f]
 res = {}
-made = []                   # the rocprofv3 output directories of this call (removed at the end when PMC_TRAFFIC_CLEANUP is set: bench.py's live pass)
-env = dict(os.environ, TMPDIR="/tmp")
+# where the profiler writes: PMC_TRAFFIC_DIR (bench.py's live pass: a temporary directory outside the checkout, which bench.py
+# removes whatever happens), else gpurun_out/ of the checkout (a hand-run whose output one wants to keep and look at)
+keep = "PMC_TRAFFIC_DIR" not in os.environ
+base = os.environ.get("PMC_TRAFFIC_DIR") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+os.makedirs(base, exist_ok=True)
+env = dict(os.environ)
+env.setdefault("TMPDIR", "/tmp")
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-    d = tempfile.mkdtemp(prefix="pmc_", dir=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"))
-    subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--"] + cmd, check=True, env=env,
-                   stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
-    db = sqlite3.connect(os.path.join(d, "p_results.db"))
-    made.append(d)
-    q = db.execute("select kernel_name, sum(value), count(distinct dispatch_id) from counters_collection where counter_name = ? "
-                   "group by kernel_name", (counter,)).fetchall()
+    d = tempfile.mkdtemp(prefix="pmc_", dir=base)
+    try:
+        subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--"] + cmd, check=True, env=env,
+                       stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+        db = sqlite3.connect(os.path.join(d, "p_results.db"))
+        try:
+            q = db.execute("select kernel_name, sum(value), count(distinct dispatch_id) from counters_collection where counter_name = ? "
+                           "group by kernel_name", (counter,)).fetchall()
+        finally:
+            db.close()
+    finally:
+        if not keep:
+            shutil.rmtree(d, ignore_errors=True)
     for kn, tot, nd in q:
         short = kn.split("(")[0].replace("void ", "")
         if "rocclr" in short and not filters:
@@ -56,8 +68,3 @@ doc = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two p
        "kernels": frame, "hbm_bytes_per_frame": total}
 json.dump(doc, open(out_json, "w"), indent=1)
 print(json.dumps(doc, indent=1))
-if os.environ.get("PMC_TRAFFIC_CLEANUP"):
-    import shutil
-    db.close()
-    for d in made:
-        shutil.rmtree(d, ignore_errors=True)
