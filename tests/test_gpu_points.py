@@ -460,8 +460,8 @@ def test_pole_of_one_lens_denominator_is_an_infinite_loss(L, prec, kind, fs, var
 
     Construction.  k4 = -0.5, k5 = k6 = 0: den_y = (1 + a2) - r2 / 2 is zero iff 1 + a2 == r2 / 2 bit for bit (the product
     -0.5 r2 is exact), den_x = 1 - r2 / 2 is not.  r2 of the chosen out-of-frame vertex is known to a few ulps only (the
-    device's reciprocal and, for float32, its rounded coordinates), so the population steps 1 + a2 ulp by ulp through
-    r2 / 2 +- W ulps: one of the candidates sits exactly on the device's pole.  The oracle's own pole is r2_oracle / 2."""
+    device's own folding of the pose and, for float32, its rounded coordinates), so the population steps 1 + a2 ulp by ulp
+    through r2 / 2 +- W ulps: one of the candidates sits exactly on the device's pole.  The oracle's own pole is r2_oracle / 2."""
     from alproj_amd import synthetic as syn
     from alproj_amd.cma import CMA
     truth = dict(syn.truth_params(316), k4=-0.5, k5=0.0, k6=0.0)
@@ -477,17 +477,14 @@ def test_pole_of_one_lens_denominator_is_an_infinite_loss(L, prec, kind, fs, var
     assert len(xyz) > 100
     uv = orc.project_points(xyz, truth) + np.random.default_rng(31).normal(0, 1.0, (len(xyz), 2))
     assert np.isfinite(uv).all()
-    T = np.float64 if prec == "f64" else np.float32
-    W = 64 if prec == "f64" else 400
-    centre = T(r2[i] / 2)
-    targets = [centre]
-    up = down = centre
-    for _ in range(W):
-        up = np.nextafter(up, T(4))
-        down = np.nextafter(down, T(0))
-        targets += [up, down]
-    a2 = np.array([np.float64(t) - 1.0 for t in targets])              # 1 + a2 == t exactly (Sterbenz: t in [0.5, 2])
-    assert all(T(1.0 + a) == t for a, t in zip(a2, targets))
+    # W: how far the device's r2 may lie from numpy's.  float64: the two fold the pose differently (R.(p - cam) against E.[p;1]
+    # with |t| ~ 4e6: ~1e-12 relative = thousands of ulps); float32: the stored coordinates are rounded (~1e-6 = some ten ulps)
+    T, I, W = (np.float64, np.int64, 1 << 17) if prec == "f64" else (np.float32, np.int32, 400)
+    centre = np.array([r2[i] / 2], dtype=T)
+    targets = (centre.view(I)[0] + np.arange(-W, W + 1, dtype=I)).view(T)   # positive floats: consecutive bit patterns
+    assert np.all(np.diff(targets) > 0) and 0.5 < targets[0] and targets[-1] < 2
+    a2 = targets.astype(np.float64) - 1.0                               # 1 + a2 == t exactly (Sterbenz: t in [0.5, 2])
+    assert np.array_equal((1.0 + a2).astype(T), targets)
     cand = np.tile(L.params_vector(truth), (len(a2) + 2, 1))
     cand[2:, L.PARAM_KEYS.index("a2")] = a2
     cand[1, L.PARAM_KEYS.index("a1")] += 0.01                           # two sane candidates in front

@@ -363,3 +363,40 @@ def test_spawn_returns_the_first_failing_code_and_zero_otherwise(tmp_path):
     t0 = time.time()
     assert launch.spawn([sys.executable, str(bad)], 3, timeout_s=60, log=open(os.devnull, "w")) == 5
     assert time.time() - t0 < 30                                  # the sleeping ranks were ended, not waited for
+
+
+def test_the_commands_of_the_first_multi_gpu_checklist_still_parse(monkeypatch):
+    """README "First multi-GPU run": the five commands an operator is told to type must be ones bench.py accepts, the first
+    one must do what the text says it does on a box without a GPU, and the table must be what bench.expectation_from_one_gpu
+    derives from the committed 1-GPU line it names"""
+    import re
+    import bench
+    text = open(os.path.join(ROOT, "README.md")).read()
+    sec = text[text.index("## First multi-GPU run"):]
+    block = sec[sec.index("```") + 3:]
+    block = block[:block.index("```")]
+    cmds = [re.sub(r"^\s*\d+\s+", "", line).split() for line in block.strip().splitlines()]
+    assert len(cmds) == 5 and all(c[:2] == ["python", "bench.py"] for c in cmds)
+    gpus = []
+    for c in cmds:
+        monkeypatch.setattr(sys, "argv", c[1:])
+        args = bench.parse()                                   # argparse exits (SystemExit) on a flag that is gone
+        gpus.append(args.gpus)
+    assert gpus == [2, 2, 2, 2, 8]
+    monkeypatch.setattr(sys, "argv", cmds[0][1:])
+    assert bench.parse().launch_selftest
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + cmds[0][2:], capture_output=True, text=True, timeout=120,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode == 0
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["selftest"] is True and line["n_gpus"] == 2 and len({x["uid_sha256"] for x in line["ranks"]}) == 1
+    # the table's rows
+    src = re.search(r"`(profiles/r0\d_bench_default_run.json)`", sec).group(1)
+    for n, gpts, gens in re.findall(r"^\| (\d) \| (\d+)[^|]*\| ([\d.]+)[^|]*\|", sec, flags=re.M):
+        if n == "1":
+            continue
+        one = json.load(open(os.path.join(ROOT, src)))
+        k1, c1 = one["roofline"]["kernel_ms"], one["roofline"]["cma_kernel_ms"]
+        host = one["cma"]["ms_per_iter"] - c1
+        assert float(gpts) == pytest.approx(one["config"]["vertices"] / (k1 / int(n) / 1e3) / 1e9, rel=2e-3)
+        assert float(gens) == pytest.approx(1e3 / (c1 / int(n) + 0.0045 + host), rel=6e-3)
