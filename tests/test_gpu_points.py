@@ -499,7 +499,8 @@ def test_pole_of_one_lens_denominator_is_an_infinite_loss(L, prec, kind, fs, var
         assert amin in (0, 1) and amin == int(np.argmin(losses))
         # the two sane candidates are untouched by the second walk their wave made for the pole candidate's sake
         ref2 = np.array([orc.loss_of(xyz, uv, orc.vector_to_params(c), kind, fs) for c in cand[:2]])
-        np.testing.assert_allclose(losses[:2], ref2, rtol=1e-9 if prec == "f64" else 1e-5)
+        # (float32: denominators down to 0.25 amplify its rounding by 1 / den^2 = 16: f32_loss_tolerance's rule)
+        np.testing.assert_allclose(losses[:2], ref2, rtol=1e-9 if prec == "f64" else 1.6e-4)
         # small population: [sane, sane, ON the pole]; the oracle sits on ITS pole (r2 as numpy forms it)
         small = cand[[0, 1, int(hit[0])]]
         l_dev, amin_small = pts.eval_population(small, kind, fs)
