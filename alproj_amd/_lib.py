@@ -203,6 +203,7 @@ _SIGNATURES = {
     "alp_eval_population_enqueue": [_c_void_p, _c_dp, _c_i64, _c_int, _c_double],
     "alp_eval_population_wait": [_c_void_p, _c_dp, ctypes.POINTER(_c_i64)],
     "alp_eval_population_timing": [_c_void_p, _c_fp, _c_fp],
+    "alp_eval_population_info": [_c_void_p, ctypes.POINTER(_c_i64)],
     "alp_loss_uv": [_c_dp, _c_dp, _c_i64, _c_int, _c_double, _c_dp],
     "alp_loss_uv_columns": [_c_dp, _c_dp, _c_dp, _c_dp, _c_i64, _c_int, _c_double, _c_dp],
     "alp_cma_sample": [_c_dp, _c_double, _c_dp, _c_dp, _c_dp, _c_int, _c_i64, _c_int, ctypes.c_uint64, ctypes.c_uint64, _c_dp,
@@ -505,6 +506,14 @@ class Points:
         k, a = ctypes.c_float(), ctypes.c_float()
         check(self._lib.alp_eval_population_timing(self._h, ctypes.byref(k), ctypes.byref(a)))
         return float(k.value), float(a.value)
+
+    POP_VARIANTS = ("general", "shared_pose", "lens_free")
+
+    def eval_population_info(self):
+        """(variant, stripes, tile columns) of the last population evaluation's launch: alp_eval_population_info"""
+        info = (_c_i64 * 3)()
+        check(lib().alp_eval_population_info(self._h, info))
+        return self.POP_VARIANTS[int(info[0])], int(info[1]), int(info[2])
 
     def eval_population_wait(self, P):
         losses = np.empty(P, dtype=np.float64)

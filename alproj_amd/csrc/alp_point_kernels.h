@@ -277,6 +277,17 @@ template <> struct PopCfg<float> : PopCfgT<float, POP_V, POP_TC, POP_MINW> {};
 #define POP_MINWD 3
 #endif
 template <> struct PopCfg<double> : PopCfgT<double, POP_VD, POP_TCD, POP_MINWD> {};
+// lens-free variant (group_loss_sum_lens_free: 16 + 2 instructions per evaluation, five registers per point): more points per lane
+// amortise the record reads and the cross-lane sum over more evaluations
+#ifndef POP_V_LF
+#define POP_V_LF 8
+#endif
+#ifndef POP_VD_LF
+#define POP_VD_LF 6
+#endif
+template <typename T> struct PopCfgLF;
+template <> struct PopCfgLF<float> : PopCfgT<float, POP_V_LF, POP_TC, POP_MINW> {};
+template <> struct PopCfgLF<double> : PopCfgT<double, POP_VD_LF, POP_TCD, POP_MINWD> {};
 // Q2 in the float64 evaluation (profiles/r05_popeval_f64_isa_census.txt: 0 saves 11 instructions of 83 and moves one pole-adjacent
 // fixture value by 1.3e-12 -- kept at 1, the reference's form)
 #ifndef POP_F64_Q2
@@ -420,6 +431,50 @@ __device__ __forceinline__ T group_loss_sum(const T *r, const T (&qx)[V], const 
     return acc;
 }
 
+// LENS-FREE populations (every candidate has k1..k6 = p1 = p2 = s1..s4 = 0: the reference's first optimisation phase,
+// example.py:51-54, BASELINE config 3).  optimize.py:112-118 then reduces to u = c0 x1 + c0, v = c1 y1 (1 + a1) / (1 + a2) + c1,
+// and the host folds -c0 and -c1 (1 + a1) / (1 + a2) into the X' and Y' rows in float64 (host/alp_host.cpp:
+// fold_pose_lens_free): per evaluation 9 FMA (the three rows), one reciprocal, 2 FMA (the residuals, perspective divide
+// included), 2 for the squared distance, one square root and the loss -- 16 full-rate + 2 quarter-rate vector instructions where
+// the general form needs 45 + 3.  What the general form would make of a non-finite value (0 . inf = NaN where a coefficient is
+// zero) is restored by the second walk of popeval_kernel, which runs the GENERAL arithmetic on the general records.
+template <typename T, int LOSS, int V, bool MASKED>
+__device__ __forceinline__ T group_loss_sum_lens_free(const T *r, const T (&qx)[V], const T (&qy)[V], const T (&qz)[V],
+                                                      const T (&uoc)[V], const T (&voc)[V], const bool (&ok)[V], T f_scale) {
+    using N = Num<T>;
+    T zc[V], xn[V], yn[V], d2[V], dist[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        zc[j] = N::fma(r[8], qx[j], N::fma(r[9], qy[j], N::fma(r[10], qz[j], r[11])));
+        xn[j] = N::fma(r[0], qx[j], N::fma(r[1], qy[j], N::fma(r[2], qz[j], r[3])));
+        yn[j] = N::fma(r[4], qx[j], N::fma(r[5], qy[j], N::fma(r[6], qz[j], r[7])));
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) zc[j] = N::rcp_pop(zc[j]);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const T du = N::fma(xn[j], zc[j], uoc[j]);        // (uo - c0) - c0 x1
+        const T dv = N::fma(yn[j], zc[j], voc[j]);
+        d2[j] = N::fma(dv, dv, du * du);
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) dist[j] = N::sqrt_pop(d2[j]);
+    T acc = 0;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        if constexpr (LOSS == ALP_LOSS_MEAN_DIST) {
+            acc += (MASKED && !ok[j]) ? (T)0 : dist[j];
+        } else {                                          // Huber as in group_loss_sum
+            const T c = sizeof(T) == 4 ? (T)__builtin_fminf((float)dist[j], (float)f_scale) : (T)__builtin_fmin((double)dist[j], (double)f_scale);
+            const T t = N::fma((T)2, dist[j], -c);
+            if (MASKED && !ok[j]) continue;
+            acc = N::fma(c, t, acc);
+        }
+    }
+    if constexpr (LOSS != ALP_LOSS_MEAN_DIST) acc *= (T)0.5;
+    return acc;
+}
+
 // ------------------------------------------------------------------ K3: residual vectors of B poses
 // Residual vectors of B poses at once (finite-difference Jacobian of the least-squares path:
 // scipy's 2-point scheme needs D+1 evaluations per iteration, optimize.py:510-528).  Each point
@@ -475,7 +530,7 @@ __global__ __launch_bounds__(256) void residual_batch_kernel(const T *__restrict
 
 // TS = element type of the planes in HBM, T = arithmetic type (TS = float with T = double is the
 // float64 re-evaluation of a float32 point set: alp_eval_population's argmin confirmation)
-template <typename T, int LOSS, int V, bool MASKED, bool SHARED_POSE, typename TS = T, bool EXACT_POLES = false>
+template <typename T, int LOSS, int V, bool MASKED, bool SHARED_POSE, typename TS = T, bool EXACT_POLES = false, bool LENS_FREE = false>
 __device__ __forceinline__ void pop_group(const TS *__restrict__ x, const TS *__restrict__ y,
                                           const TS *__restrict__ z, const TS *__restrict__ uo,
                                           const TS *__restrict__ vo, int64_t base, int64_t end,
@@ -495,17 +550,20 @@ __device__ __forceinline__ void pop_group(const TS *__restrict__ x, const TS *__
         voc[j] = (T)vo[i] - c1;
     }
     NormCoords<T, V> pre;
-    if constexpr (SHARED_POSE) norm_coords<T, V>(s_c[0].v, qx, qy, qz, pre);
+    if constexpr (SHARED_POSE && !LENS_FREE) norm_coords<T, V>(s_c[0].v, qx, qy, qz, pre);
+    constexpr int WORDS = LENS_FREE ? 12 : 32;        // a lens-free record is its three rows
     for (int c = 0; c < tc; ++c) {
-        T r[32];
+        T r[WORDS];
         const typename Num<T>::vec *rv = reinterpret_cast<const typename Num<T>::vec *>(s_c[c].v);
 #pragma unroll
-        for (int k = 0; k < 32 / Num<T>::VEC; ++k) {
+        for (int k = 0; k < WORDS / Num<T>::VEC; ++k) {
             typename Num<T>::vec t = rv[k];
 #pragma unroll
             for (int e = 0; e < Num<T>::VEC; ++e) r[k * Num<T>::VEC + e] = vget<T>(t, e);
         }
-        T acc = group_loss_sum<T, LOSS, V, MASKED, SHARED_POSE, EXACT_POLES>(r, qx, qy, qz, pre, uoc, voc, ok, f_scale);
+        T acc;
+        if constexpr (LENS_FREE) acc = group_loss_sum_lens_free<T, LOSS, V, MASKED>(r, qx, qy, qz, uoc, voc, ok, f_scale);
+        else acc = group_loss_sum<T, LOSS, V, MASKED, SHARED_POSE, EXACT_POLES>(r, qx, qy, qz, pre, uoc, voc, ok, f_scale);
         acc = wave_sum_to_lane63(acc);
         if (lane == 63) s_sum_wave[c] += (double)acc;
     }
@@ -513,7 +571,7 @@ __device__ __forceinline__ void pop_group(const TS *__restrict__ x, const TS *__
 
 // one workgroup's stripe [beg, end) against the tc staged records: wide groups of V rows, the rows they leave over two at a
 // time, the ragged last row masked
-template <typename T, int LOSS, int V, bool SHARED_POSE, typename TS, bool EXACT_POLES>
+template <typename T, int LOSS, int V, bool SHARED_POSE, typename TS, bool EXACT_POLES, bool LENS_FREE = false>
 __device__ __forceinline__ void pop_walk_stripe(const TS *__restrict__ x, const TS *__restrict__ y, const TS *__restrict__ z,
                                                 const TS *__restrict__ uo, const TS *__restrict__ vo, int64_t beg, int64_t end,
                                                 const PoseRec<T> *recs, double *s_sum_wave, int tc, T f_scale) {
@@ -522,19 +580,21 @@ __device__ __forceinline__ void pop_walk_stripe(const TS *__restrict__ x, const 
     constexpr int VW = EXACT_POLES ? 1 : V;
     int64_t base = beg;
     for (; base + 256 * VW <= end; base += 256 * VW)
-        pop_group<T, LOSS, VW, false, SHARED_POSE, TS, EXACT_POLES>(x, y, z, uo, vo, base, end, recs, s_sum_wave, tc, f_scale);
+        pop_group<T, LOSS, VW, false, SHARED_POSE, TS, EXACT_POLES, LENS_FREE>(x, y, z, uo, vo, base, end, recs, s_sum_wave, tc, f_scale);
     if constexpr (VW > 2)      // the rows left over by the wide groups, two at a time
         for (; base + 512 <= end; base += 512)
-            pop_group<T, LOSS, 2, false, SHARED_POSE, TS, EXACT_POLES>(x, y, z, uo, vo, base, end, recs, s_sum_wave, tc, f_scale);
+            pop_group<T, LOSS, 2, false, SHARED_POSE, TS, EXACT_POLES, LENS_FREE>(x, y, z, uo, vo, base, end, recs, s_sum_wave, tc, f_scale);
     for (; base < end; base += 256)
-        pop_group<T, LOSS, 1, true, SHARED_POSE, TS, EXACT_POLES>(x, y, z, uo, vo, base, end, recs, s_sum_wave, tc, f_scale);
+        pop_group<T, LOSS, 1, true, SHARED_POSE, TS, EXACT_POLES, LENS_FREE>(x, y, z, uo, vo, base, end, recs, s_sum_wave, tc, f_scale);
 }
 
-template <typename T, int LOSS, typename Cfg = PopCfg<T>, bool SHARED_POSE = false, typename TS = T>
+// LENS_FREE: `cands` holds the lens-free records (fold_pose_lens_free) the first walk runs on, `cands_general` the general ones
+// (fold_pose) of the same candidates for the second walk; otherwise both are the general records.
+template <typename T, int LOSS, typename Cfg = PopCfg<T>, bool SHARED_POSE = false, typename TS = T, bool LENS_FREE = false>
 __global__ __launch_bounds__(256, Cfg::MINW) void popeval_kernel(
     const TS *__restrict__ x, const TS *__restrict__ y, const TS *__restrict__ z, const TS *__restrict__ uo,
     const TS *__restrict__ vo, int64_t n, const PoseRec<T> *__restrict__ cands, int P, T f_scale,
-    double *__restrict__ partials) {
+    double *__restrict__ partials, const PoseRec<T> *__restrict__ cands_general) {
     constexpr int TC = Cfg::TC;
     constexpr int V = Cfg::V;
     __shared__ PoseRec<T> s_c[TC];
@@ -561,7 +621,7 @@ __global__ __launch_bounds__(256, Cfg::MINW) void popeval_kernel(
             for (int i = tid; i < 4 * TC; i += 256) (&s_sum[0][0])[i] = 0.0;
         }
         __syncthreads();
-        pop_walk_stripe<T, LOSS, V, SHARED_POSE, TS, false>(x, y, z, uo, vo, beg, end, s_c, s_sum[wave], tc, f_scale);
+        pop_walk_stripe<T, LOSS, V, SHARED_POSE, TS, false, LENS_FREE>(x, y, z, uo, vo, beg, end, s_c, s_sum[wave], tc, f_scale);
         // A sum that is not finite stays so (inf and NaN are sticky under +): looked for ONCE per wave, tile and stripe -- nothing
         // in the loop above pays for it.  The wave's rows are its own (lane t owns points t, t + 256, ...), so are its sums:
         // it clears them and walks its share again with a reciprocal per denominator (distort_group), no barrier needed.
@@ -572,7 +632,10 @@ __global__ __launch_bounds__(256, Cfg::MINW) void popeval_kernel(
         if (__builtin_amdgcn_ballot_w64(bad) != 0) {
             for (int c = tid & 63; c < tc; c += 64) s_sum[wave][c] = 0.0;
             __builtin_amdgcn_wave_barrier();
-            pop_walk_stripe<T, LOSS, V, SHARED_POSE, TS, true>(x, y, z, uo, vo, beg, end, s_c, s_sum[wave], tc, f_scale);
+            // (a lens-free tile: the LDS holds the folded rows only, so the general records are read where they lie in HBM --
+            // wave-uniform loads, slow and rare; SHARED_POSE's hoisted coordinates are not used by either walk then)
+            if constexpr (LENS_FREE) pop_walk_stripe<T, LOSS, V, false, TS, true>(x, y, z, uo, vo, beg, end, cands_general + c0, s_sum[wave], tc, f_scale);
+            else pop_walk_stripe<T, LOSS, V, SHARED_POSE, TS, true>(x, y, z, uo, vo, beg, end, s_c, s_sum[wave], tc, f_scale);
         }
         __syncthreads();
         if (tid < tc)

@@ -48,6 +48,7 @@ struct alp_points {
     int64_t partials_cap = 0;
     double *sums_dev = nullptr;    // cand_cap + 1
     double *sums_host = nullptr;   // pinned, cand_cap + 1
+    int64_t last_info[3] = {0, 0, 0};     // alp_eval_population_info: variant, stripes, tile columns of the last launch
     int64_t pending_P = 0;
     int pending_loss = 0;
     double pending_f_scale = 0;
@@ -184,8 +185,9 @@ int ensure_pop_scratch(alp_points *p, int64_t P, int nblk) {
         p->sums_dev = p->sums_host = nullptr;
         p->cand_cap = 0;
         const size_t rec = POSE_WORDS * p->esize();
-        ALP_HIP(hipMalloc(&p->cand_dev, (size_t)cap * rec));
-        ALP_HIP(hipHostMalloc(&p->cand_host, (size_t)cap * rec, hipHostMallocDefault));
+        // two records per candidate: the general one and, behind all of those, the lens-free one (enqueue_popeval)
+        ALP_HIP(hipMalloc(&p->cand_dev, (size_t)cap * rec * 2));
+        ALP_HIP(hipHostMalloc(&p->cand_host, (size_t)cap * rec * 2, hipHostMallocDefault));
         ALP_HIP(hipMalloc((void **)&p->sums_dev, (size_t)(cap + 1) * sizeof(double)));
         ALP_HIP(hipHostMalloc((void **)&p->sums_host, (size_t)(cap + 1) * sizeof(double), hipHostMallocDefault));
         p->cand_cap = cap;
@@ -215,20 +217,31 @@ int enqueue_popeval(alp_points *p, const double *cand, int64_t P, int loss_kind,
         if (cand[i * ALP_NPARAM + 21] != cand[21] || cand[i * ALP_NPARAM + 22] != cand[22])
             return fail(ALP_EINVAL, "alp_eval_population: candidates %lld and 0 differ in w or h", (long long)i);
     for (int64_t i = 0; i < P; ++i) fold_pose_t<T>(cand + i * ALP_NPARAM, p->origin, &h[i]);
+    // lens-free populations (no candidate has a lens coefficient other than a1, a2: the reference's first phase, example.py:51-54;
+    // BASELINE config 3) take the kernel variant that runs on rows with the lens folded in: its records follow the general ones
+    bool lens_free = !getenv("ALP_POP_NO_LENS_FREE");
+    for (int64_t i = 0; i < P && lens_free; ++i) lens_free = pose_is_lens_free(cand + i * ALP_NPARAM);
+    if (lens_free)
+        for (int64_t i = 0; i < P; ++i) fold_pose_lens_free_t<T>(cand + i * ALP_NPARAM, p->origin, &h[p->cand_cap + i]);
     ALP_HIP(hipMemcpyAsync(p->cand_dev, h, (size_t)P * sizeof(PoseRec<T>), hipMemcpyHostToDevice, ctx().stream));
+    if (lens_free)
+        ALP_HIP(hipMemcpyAsync((PoseRec<T> *)p->cand_dev + p->cand_cap, h + p->cand_cap, (size_t)P * sizeof(PoseRec<T>), hipMemcpyHostToDevice,
+                               ctx().stream));
     // distortion-only populations (the reference's second phase, example.py:75-78) share the
     // folded 3x4 matrix: its 12 words are identical in every record, and the kernel then
     // computes the normalised coordinates once per point instead of once per candidate
-    bool shared_pose = P > 1;
+    bool shared_pose = P > 1 && !lens_free;
     for (int64_t i = 1; i < P && shared_pose; ++i)
         shared_pose = memcmp(h[i].v, h[0].v, 12 * sizeof(T)) == 0;
     using Kernel = void (*)(const T *, const T *, const T *, const T *, const T *, int64_t, const PoseRec<T> *, int, T,
-                            double *);
-    const int which = (loss_kind == ALP_LOSS_HUBER ? 2 : 0) + (shared_pose ? 1 : 0);
-    const Kernel kernels[4] = {popeval_kernel<T, ALP_LOSS_MEAN_DIST, PopCfg<T>, false>,
+                            double *, const PoseRec<T> *);
+    const int which = (loss_kind == ALP_LOSS_HUBER ? 3 : 0) + (lens_free ? 2 : (shared_pose ? 1 : 0));
+    const Kernel kernels[6] = {popeval_kernel<T, ALP_LOSS_MEAN_DIST, PopCfg<T>, false>,
                                popeval_kernel<T, ALP_LOSS_MEAN_DIST, PopCfg<T>, true>,
+                               popeval_kernel<T, ALP_LOSS_MEAN_DIST, PopCfgLF<T>, false, T, true>,
                                popeval_kernel<T, ALP_LOSS_HUBER, PopCfg<T>, false>,
-                               popeval_kernel<T, ALP_LOSS_HUBER, PopCfg<T>, true>};
+                               popeval_kernel<T, ALP_LOSS_HUBER, PopCfg<T>, true>,
+                               popeval_kernel<T, ALP_LOSS_HUBER, PopCfgLF<T>, false, T, true>};
     // one workgroup per stripe of ~24 rows of 256 points (four groups of V = 6), between 4 and 64
     // workgroups per CU: a stripe is re-read once per tile of 128 candidates and a short one stays
     // in cache between those passes.  Measured, 100 M x 2048 float32: 4 workgroups per CU 244 ms,
@@ -237,8 +250,9 @@ int enqueue_popeval(alp_points *p, const double *cand, int64_t P, int loss_kind,
     int nblk = ctx().cu_count * (sizeof(T) == 8 ? 24 : 4);
     int ytiles = 1;
     const int64_t rows = (p->n + 255) / 256;
+    const int VV = lens_free ? PopCfgLF<T>::V : PopCfg<T>::V;       // rows of a full group
     if (sizeof(T) == 4) {
-        const int64_t want = (rows + 23) / 24;
+        const int64_t want = (rows + 4 * VV - 1) / (4 * VV);            // ~four full groups per stripe
         const int64_t lo = (int64_t)ctx().cu_count * 4, hi = (int64_t)ctx().cu_count * 64;
         // whole rounds of the 4 workgroups a CU holds at once while the grid is only a few rounds deep
         const int64_t rounded = (want + lo - 1) / lo * lo;
@@ -255,10 +269,10 @@ int enqueue_popeval(alp_points *p, const double *cand, int64_t P, int loss_kind,
         // the shape: float64 additions of float32 group sums of this magnitude are exact.
         const int tiles = (int)((P + POP_TC - 1) / POP_TC);
         if (tiles >= 2 && tiles <= 8 && want * tiles < 8 * lo) {
-            int64_t k = (int64_t)((double)rows / (6.0 * 2.12 * (double)lo) + 0.5);      // groups of 6 rows per stripe
+            int64_t k = (int64_t)((double)rows / ((double)VV * 2.12 * (double)lo) + 0.5);      // groups of V rows per stripe
             if (k < 1) k = 1;
             if (k > 4) k = 4;
-            const int64_t stripes = (rows + 6 * k - 1) / (6 * k);
+            const int64_t stripes = (rows + VV * k - 1) / (VV * k);
             if (stripes * tiles >= 4 * lo) {
                 nblk = (int)stripes;
                 ytiles = tiles;
@@ -292,10 +306,14 @@ int enqueue_popeval(alp_points *p, const double *cand, int64_t P, int loss_kind,
             }
         for (int k = 0; k < 3; ++k) p->ev[k] = ev[k];
     }
+    p->last_info[0] = lens_free ? ALP_POP_LENS_FREE : (shared_pose ? ALP_POP_SHARED_POSE : ALP_POP_GENERAL);
+    p->last_info[1] = nblk;
+    p->last_info[2] = ytiles;
     ALP_HIP(hipEventRecord(p->ev[0], ctx().stream));
+    const PoseRec<T> *recs_general = (const PoseRec<T> *)p->cand_dev;
     hipLaunchKernelGGL(kernels[which], dim3(nblk, ytiles), dim3(256), 0, ctx().stream, (const T *)p->x, (const T *)p->y,
-                       (const T *)p->z, (const T *)p->uo, (const T *)p->vo, p->n, (const PoseRec<T> *)p->cand_dev,
-                       (int)P, (T)f_scale, p->partials);
+                       (const T *)p->z, (const T *)p->uo, (const T *)p->vo, p->n, lens_free ? recs_general + p->cand_cap : recs_general,
+                       (int)P, (T)f_scale, p->partials, recs_general);
     ALP_HIP(hipGetLastError());
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((P + 31) / 32)), dim3(256), 0, ctx().stream,
                        p->partials, nblk, (int)P, (double)p->n, p->sums_dev);
@@ -339,10 +357,10 @@ int confirm_losses(alp_points *p, const double *cand, const int64_t *which, int 
     const float *uo = (const float *)p->uo, *vo = (const float *)p->vo;
     if (loss_kind == ALP_LOSS_HUBER)
         hipLaunchKernelGGL((popeval_kernel<double, ALP_LOSS_HUBER, PopCfg<double>, false, float>), dim3(nblk), dim3(256), 0,
-                           ctx().stream, x, y, z, uo, vo, p->n, recs_dev, K, f_scale, partials);
+                           ctx().stream, x, y, z, uo, vo, p->n, recs_dev, K, f_scale, partials, recs_dev);
     else
         hipLaunchKernelGGL((popeval_kernel<double, ALP_LOSS_MEAN_DIST, PopCfg<double>, false, float>), dim3(nblk), dim3(256),
-                           0, ctx().stream, x, y, z, uo, vo, p->n, recs_dev, K, f_scale, partials);
+                           0, ctx().stream, x, y, z, uo, vo, p->n, recs_dev, K, f_scale, partials, recs_dev);
     ALP_HIP(hipGetLastError());
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, ctx().stream, partials, nblk, K, (double)p->n, sums_dev);
     ALP_HIP(hipGetLastError());
@@ -766,6 +784,13 @@ int alp_eval_population_timing(alp_points_t *p, float *kernel_ms, float *allredu
     ALP_HIP(hipEventElapsedTime(&b, p->ev[1], p->ev[2]));
     if (kernel_ms) *kernel_ms = a;
     if (allreduce_ms) *allreduce_ms = b;
+    return ALP_OK;
+}
+
+int alp_eval_population_info(alp_points_t *p, int64_t info[3]) {
+    ALP_REQUIRE(p && info, "NULL argument");
+    if (!p->timed) return fail(ALP_ESTATE, "alp_eval_population_info: no population evaluation yet");
+    for (int k = 0; k < 3; ++k) info[k] = p->last_info[k];
     return ALP_OK;
 }
 

@@ -96,6 +96,26 @@ void fold_pose(const double p[ALP_NPARAM], const double origin[3], double rec[PO
     rec[30] = rec[31] = 0;
 }
 
+bool pose_is_lens_free(const double p[ALP_NPARAM]) {
+    for (int i = 9; i <= 20; ++i)
+        if (p[i] != 0.0) return false;             // k1..k6, p1, p2, s1..s4 (NaN compares unequal: not lens-free)
+    return true;
+}
+
+void fold_pose_lens_free(const double p[ALP_NPARAM], const double origin[3], double rec[POSE_WORDS]) {
+    double g[POSE_WORDS];
+    fold_pose(p, origin, g);
+    const double sy = g[18] / g[19];               // (1 + a1) / (1 + a2)  (a2 = -1: inf / NaN rows, and losses, like the reference's division)
+    for (int i = 0; i < POSE_WORDS; ++i) rec[i] = 0;
+    for (int j = 0; j < 4; ++j) {
+        rec[0 + j] = g[28] * g[0 + j];             // -c0 X'
+        rec[4 + j] = (g[29] * sy) * g[4 + j];      // -c1 (1 + a1) / (1 + a2) Y'
+        rec[8 + j] = g[8 + j];
+    }
+    rec[26] = g[26];
+    rec[27] = g[27];
+}
+
 namespace host {
 
 // ------------------------------------------------------------------ content hash of a host array

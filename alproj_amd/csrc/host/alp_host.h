@@ -68,6 +68,22 @@ struct alignas(16) PoseRec {
 // params: the 25 ABI parameters; origin: local origin of the point set (absolute coords).
 void fold_pose(const double params[ALP_NPARAM], const double origin[3], double rec[POSE_WORDS]);
 
+// A LENS-FREE pose (k1..k6 = p1 = p2 = s1..s4 = 0: every candidate of the reference's first optimisation phase, example.py:51-54,
+// whose targets are position, angles, fov, a1, a2) folded further: with those coefficients optimize.py:112-118 is
+//   u = c0 x1 + c0,   v = c1 y1 (1 + a1) / (1 + a2) + c1
+// so the residual needs no lens arithmetic at all:  uo - u = (uo - c0) + (X''.[q;1]) / (Z.[q;1])  with X'' = -c0 X',
+// vo - v = (vo - c1) + (Y''.[q;1]) / (Z.[q;1])  with Y'' = -c1 (1 + a1) / (1 + a2) Y'  (scaled here in float64).
+// rec[0..3] = X'', rec[4..7] = Y'', rec[8..11] = Z, rec[26], rec[27] = c0, c1 as in fold_pose, everything else 0.
+bool pose_is_lens_free(const double params[ALP_NPARAM]);
+void fold_pose_lens_free(const double params[ALP_NPARAM], const double origin[3], double rec[POSE_WORDS]);
+
+template <typename T>
+inline void fold_pose_lens_free_t(const double params[ALP_NPARAM], const double origin[3], PoseRec<T> *out) {
+    double r[POSE_WORDS];
+    fold_pose_lens_free(params, origin, r);
+    for (int i = 0; i < POSE_WORDS; ++i) out->v[i] = (T)r[i];
+}
+
 template <typename T>
 inline void fold_pose_t(const double params[ALP_NPARAM], const double origin[3], PoseRec<T> *out) {
     double r[POSE_WORDS];

@@ -160,6 +160,22 @@ void check_fold_pose() {
             if (std::fabs(z) < 1) continue;                    // next to the camera plane the quotient amplifies rounding
             CHECK(std::fabs(x1f - x1) <= 1e-9 * std::max(1.0, std::fabs(x1)), "x1 %.17g vs %.17g", x1f, x1);
             CHECK(std::fabs(y1f - y1) <= 1e-9 * std::max(1.0, std::fabs(y1)), "y1 %.17g vs %.17g", y1f, y1);
+            // the lens-free folding of the same pose with its lens coefficients set to zero: optimize.py:112-118 is then
+            // u = c0 x1 + c0, v = c1 y1 (1 + a1) / (1 + a2) + c1, and the folded rows give the residual against any (uo, vo)
+            double pl[ALP_NPARAM];
+            memcpy(pl, p, sizeof(pl));
+            for (int i = 9; i <= 20; ++i) pl[i] = 0;
+            CHECK(pose_is_lens_free(pl) && !pose_is_lens_free(p), "pose_is_lens_free");
+            double lf[POSE_WORDS];
+            fold_pose_lens_free(pl, origin, lf);
+            const double uo = 5616 * U(rng), vo = 3744 * U(rng);
+            const double u_ref = c0 * x1 + c0, v_ref = c1 * (y1 * (1 + pl[7]) / (1 + pl[8])) + c1;
+            const double zl = lf[8] * q[0] + lf[9] * q[1] + lf[10] * q[2] + lf[11];
+            const double du = (uo - lf[26]) + (lf[0] * q[0] + lf[1] * q[1] + lf[2] * q[2] + lf[3]) / zl;
+            const double dv = (vo - lf[27]) + (lf[4] * q[0] + lf[5] * q[1] + lf[6] * q[2] + lf[7]) / zl;
+            CHECK(std::fabs(du - (uo - u_ref)) <= 1e-8 * std::max(1.0, std::fabs(u_ref)), "lens-free du %.17g vs %.17g", du, uo - u_ref);
+            CHECK(std::fabs(dv - (vo - v_ref)) <= 1e-8 * std::max(1.0, std::fabs(v_ref)), "lens-free dv %.17g vs %.17g", dv, vo - v_ref);
+            CHECK(zl == zf && lf[26] == c0 && lf[27] == c1 && lf[12] == 0 && lf[31] == 0, "lens-free record layout");
         }
     }
 }

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ALP_ABI_VERSION 6
+#define ALP_ABI_VERSION 7
 
 /* x,y,z,fov,pan,tilt,roll,a1,a2,k1..k6,p1,p2,s1..s4,w,h,cx,cy */
 #define ALP_NPARAM 25
@@ -231,6 +231,15 @@ int alp_eval_population_wait(alp_points_t *pts, double *loss_out, int64_t *argmi
  * reports as the collective's share of a CMA-ES generation (src/alproj/optimize.py:418-424 has no
  * counterpart: the reference is one process). */
 int alp_eval_population_timing(alp_points_t *pts, float *kernel_ms, float *allreduce_ms);
+/* (ABI 7) Which kernel variant the last population evaluation of this handle was given, and its launch shape:
+ * info[0] = ALP_POP_GENERAL, ALP_POP_SHARED_POSE (every candidate has the same position / angles / fov: the reference's second
+ * phase, example.py:75-78 -- the transform is hoisted out of the candidate loop) or ALP_POP_LENS_FREE (no candidate has a lens
+ * coefficient other than a1, a2: the reference's first phase, example.py:51-54 -- the lens is folded into the pose rows on
+ * the host and optimize.py:112-118 costs no arithmetic per point); info[1] = stripes of points, info[2] = columns of
+ * candidate tiles of the launch grid.  The losses of one candidate agree between the variants to the tolerances of the
+ * precision mode (float64: 1e-12 relative; float32: 2e-6), not bit for bit. */
+enum alp_pop_variant { ALP_POP_GENERAL = 0, ALP_POP_SHARED_POSE = 1, ALP_POP_LENS_FREE = 2 };
+int alp_eval_population_info(alp_points_t *pts, int64_t info[3]);
 
 /* The candidate sampler of the CMA-ES loop on the device: replaces the `population_size` calls of
  * `optimizer.ask()` per generation, src/alproj/optimize.py:420-421 (third-party cmaes==0.12.0,

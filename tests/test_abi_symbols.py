@@ -40,7 +40,7 @@ def test_ctypes_table_matches_header():
     assert sorted(_lib._SIGNATURES) == header_functions()
     lib = _lib.load()
     version = int(re.search(r"#define ALP_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
-    assert lib.alp_abi_version() == version == 6
+    assert lib.alp_abi_version() == version == 7
 
 
 def test_header_cites_reference_for_each_entry_point():
