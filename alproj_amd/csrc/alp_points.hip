@@ -216,13 +216,19 @@ int enqueue_popeval(alp_points *p, const double *cand, int64_t P, int loss_kind,
     for (int64_t i = 1; i < P; ++i)
         if (cand[i * ALP_NPARAM + 21] != cand[21] || cand[i * ALP_NPARAM + 22] != cand[22])
             return fail(ALP_EINVAL, "alp_eval_population: candidates %lld and 0 differ in w or h", (long long)i);
-    for (int64_t i = 0; i < P; ++i) fold_pose_t<T>(cand + i * ALP_NPARAM, p->origin, &h[i]);
     // lens-free populations (no candidate has a lens coefficient other than a1, a2: the reference's first phase, example.py:51-54;
     // BASELINE config 3) take the kernel variant that runs on rows with the lens folded in: its records follow the general ones
     bool lens_free = !getenv("ALP_POP_NO_LENS_FREE");
     for (int64_t i = 0; i < P && lens_free; ++i) lens_free = pose_is_lens_free(cand + i * ALP_NPARAM);
-    if (lens_free)
-        for (int64_t i = 0; i < P; ++i) fold_pose_lens_free_t<T>(cand + i * ALP_NPARAM, p->origin, &h[p->cand_cap + i]);
+    for (int64_t i = 0; i < P; ++i) {
+        double g[POSE_WORDS], lf[POSE_WORDS];
+        fold_pose(cand + i * ALP_NPARAM, p->origin, g);
+        for (int k = 0; k < POSE_WORDS; ++k) h[i].v[k] = (T)g[k];
+        if (lens_free) {
+            lens_free_from_general(g, lf);
+            for (int k = 0; k < POSE_WORDS; ++k) h[p->cand_cap + i].v[k] = (T)lf[k];
+        }
+    }
     ALP_HIP(hipMemcpyAsync(p->cand_dev, h, (size_t)P * sizeof(PoseRec<T>), hipMemcpyHostToDevice, ctx().stream));
     if (lens_free)
         ALP_HIP(hipMemcpyAsync((PoseRec<T> *)p->cand_dev + p->cand_cap, h + p->cand_cap, (size_t)P * sizeof(PoseRec<T>), hipMemcpyHostToDevice,

@@ -102,9 +102,7 @@ bool pose_is_lens_free(const double p[ALP_NPARAM]) {
     return true;
 }
 
-void fold_pose_lens_free(const double p[ALP_NPARAM], const double origin[3], double rec[POSE_WORDS]) {
-    double g[POSE_WORDS];
-    fold_pose(p, origin, g);
+void lens_free_from_general(const double g[POSE_WORDS], double rec[POSE_WORDS]) {
     const double sy = g[18] / g[19];               // (1 + a1) / (1 + a2)  (a2 = -1: inf / NaN rows, and losses, like the reference's division)
     for (int i = 0; i < POSE_WORDS; ++i) rec[i] = 0;
     for (int j = 0; j < 4; ++j) {
@@ -114,6 +112,12 @@ void fold_pose_lens_free(const double p[ALP_NPARAM], const double origin[3], dou
     }
     rec[26] = g[26];
     rec[27] = g[27];
+}
+
+void fold_pose_lens_free(const double p[ALP_NPARAM], const double origin[3], double rec[POSE_WORDS]) {
+    double g[POSE_WORDS];
+    fold_pose(p, origin, g);
+    lens_free_from_general(g, rec);
 }
 
 namespace host {

@@ -76,13 +76,8 @@ void fold_pose(const double params[ALP_NPARAM], const double origin[3], double r
 // rec[0..3] = X'', rec[4..7] = Y'', rec[8..11] = Z, rec[26], rec[27] = c0, c1 as in fold_pose, everything else 0.
 bool pose_is_lens_free(const double params[ALP_NPARAM]);
 void fold_pose_lens_free(const double params[ALP_NPARAM], const double origin[3], double rec[POSE_WORDS]);
-
-template <typename T>
-inline void fold_pose_lens_free_t(const double params[ALP_NPARAM], const double origin[3], PoseRec<T> *out) {
-    double r[POSE_WORDS];
-    fold_pose_lens_free(params, origin, r);
-    for (int i = 0; i < POSE_WORDS; ++i) out->v[i] = (T)r[i];
-}
+// the same from the general record `g` of fold_pose (the sines and cosines are not formed twice)
+void lens_free_from_general(const double g[POSE_WORDS], double rec[POSE_WORDS]);
 
 template <typename T>
 inline void fold_pose_t(const double params[ALP_NPARAM], const double origin[3], PoseRec<T> *out) {

@@ -51,6 +51,11 @@ VALU_PEAK = 157.3e12       # flop/s fp32 vector (MI355X_MICROARCH.md)
 VALU_PEAK_F64 = 78.6e12    # flop/s fp64 vector (MI355X_MICROARCH.md)
 BYTES_PER_VERTEX = {"f32": 20, "f64": 40}     # 3 coordinates in + 2 pixel coordinates out
 EVAL_FLOPS = 76            # flop per point-candidate evaluation (Huber): 30 fma + 12 + 4 transcendental (+ 1/6 multiply), DESIGN.md section 4 (K2)
+# ... and of the lens-free variant (every candidate has k = p = s = 0: the reference's first phase, BASELINE config 3): 9 fma (rows)
+# + reciprocal + 2 fma (residuals) + mul + fma (squared distance) + sqrt + min + 2 fma (Huber) = 32; the mean distance needs an add
+# instead of min + 2 fma: 28.  The general arithmetic on the same population: 76 / 72.
+EVAL_FLOPS_BY_VARIANT = {("lens_free", "huber"): 32, ("lens_free", "mean"): 28, ("general", "huber"): 76, ("general", "mean"): 72,
+                         ("shared_pose", "huber"): 76, ("shared_pose", "mean"): 72}
 PROFILES = os.path.join(ROOT, "profiles")
 ROUNDS = ("r06", "r05", "r04", "r03", "r02", "r01")      # committed counter summaries: the newest round wins
 
@@ -899,14 +904,32 @@ def main():
                 k_g = args.c3_steps                        # 100 generations
                 wc, _ = timed(ctl, L, g10, k_g, 3)
                 ek, _ = p10.eval_population_timing()
+                variant = p10.eval_population_info()[0]
+                flop = EVAL_FLOPS_BY_VARIANT[(variant, "huber" if kind == L.LOSS_HUBER else "mean")]
                 c3[tag] = {"iters_per_s": k_g / wc, "ms_per_iter": wc / k_g * 1e3, "generations_timed": k_g, "kernel_ms": ek,
                            "point_candidate_evals_per_s": len(x10) * 256 * k_g / wc,
                            "host_ms_per_generation": {"ask": st10["t_ask"] / st10["n"] * 1e3, "tell": st10["t_tell"] / st10["n"] * 1e3},
-                           "valu_frac": len(x10) * 256 * EVAL_FLOPS / (ek / 1e3) / VALU_PEAK}
+                           "kernel_variant": variant, "flop_per_eval": flop,
+                           "valu_frac": len(x10) * 256 * flop / (ek / 1e3) / VALU_PEAK}
+            # the same population through the GENERAL arithmetic (what rounds 1-5 measured at this shape; a D = 9 population around a
+            # camera WITH a lens takes it): forced for ten generations
+            os.environ["ALP_POP_NO_LENS_FREE"] = "1"
+            try:
+                g10, _ = cma_loop(L, CMA, p10, b10, syn.TARGETS_D9, bounds_to_array, 256, L.LOSS_HUBER, 10.0)
+                wc, _ = timed(ctl, L, g10, 20, 3)
+                ek, _ = p10.eval_population_timing()
+                c3["huber_f10_general_arithmetic"] = {"iters_per_s": 20 / wc, "kernel_ms": ek, "kernel_variant": p10.eval_population_info()[0],
+                                                      "flop_per_eval": EVAL_FLOPS, "valu_frac": len(x10) * 256 * EVAL_FLOPS / (ek / 1e3) / VALU_PEAK}
+            finally:
+                del os.environ["ALP_POP_NO_LENS_FREE"]
         out["c2_c3_10m"] = {"c2_projection": c2, "c3_cma": c3}
         out["roofline"].update({"c3_iters_per_s": c3["huber_f10"]["iters_per_s"], "c3_kernel_ms": c3["huber_f10"]["kernel_ms"],
                                 "c3_evals_per_s": c3["huber_f10"]["point_candidate_evals_per_s"], "c3_valu_frac": c3["huber_f10"]["valu_frac"],
-                                "c3_generations_timed": args.c3_steps, "c3_mean_distance_iters_per_s": c3["mean_distance"]["iters_per_s"]})
+                                "c3_generations_timed": args.c3_steps, "c3_mean_distance_iters_per_s": c3["mean_distance"]["iters_per_s"],
+                                "c3_kernel_variant": c3["huber_f10"]["kernel_variant"], "c3_flop_per_eval": c3["huber_f10"]["flop_per_eval"],
+                                "c3_general_arithmetic_kernel_ms": c3["huber_f10_general_arithmetic"]["kernel_ms"],
+                                "c3_general_arithmetic_iters_per_s": c3["huber_f10_general_arithmetic"]["iters_per_s"],
+                                "c3_general_arithmetic_valu_frac": c3["huber_f10_general_arithmetic"]["valu_frac"]})
         del s10, x10, o10
 
     # ---------------------------------------------------------------- depth raster (1 GPU)

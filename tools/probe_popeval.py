@@ -35,6 +35,8 @@ cand = np.tile(L.params_vector(base), (P, 1))
 w = np.array([30, 30, 30, 45, 45, 45, 45] + [0.2] * 14)
 if len(sys.argv) > 5 and sys.argv[5] == "distonly":
     w[:7] = 0          # distortion-only population: every candidate shares the pose
+if len(sys.argv) > 5 and sys.argv[5] == "d9":
+    w[9:] = 0          # the reference's first phase (x, y, z, fov, pan, tilt, roll, a1, a2): a lens-free population
 cand[:, cols] += rng.uniform(-0.1, 0.1, (P, 21)) * w
 best = 1e9
 for r in range(reps):
@@ -46,5 +48,6 @@ for r in range(reps):
     best = min(best, ms)
     print(f"rep {r}: {ms:.3f} ms")
 ev = len(xyz) * P
+print(f"variant {pts.eval_population_info()}")
 print(f"N={len(xyz)} P={P} {prec}: best {best:.3f} ms  {ev / best / 1e6:.1f} G evals/s  "
       f"{ev * 77 / best / 1e9:.1f} TFLOP/s(77/eval)  finite losses: {np.isfinite(losses).sum()}/{P}")
