@@ -33,11 +33,16 @@ while time.time() < t_end:
                  k3=float(rng.uniform(-0.01, 0.01)), k4=float(rng.uniform(-0.02, 0.02)), k5=float(rng.uniform(-0.01, 0.01)), k6=float(rng.uniform(-0.003, 0.003)),
                  p1=float(rng.uniform(-3e-3, 3e-3)), p2=float(rng.uniform(-3e-3, 3e-3)), s1=float(rng.uniform(-2e-3, 2e-3)), s2=float(rng.uniform(-1e-3, 1e-3)),
                  s3=float(rng.uniform(-2e-3, 2e-3)), s4=float(rng.uniform(-1e-3, 1e-3)))
+    # round 6: a third of the cases are the reference's FIRST phase (example.py:51-54) -- no lens coefficient but a1, a2 anywhere,
+    # targets D9: the lens-free kernel variant; a point of every tenth such case sits AT a candidate's camera (NaN, second walk)
+    lens_free_case = rng.random() < 0.33
+    if lens_free_case:
+        truth.update({k: 0.0 for k in L.DIST_KEYS[2:]})
     n = int(rng.choice([1, 2, 63, 64, 255, 257, 1127, 4096, 50_001]))
     xyz = syn.gcp_points(n, truth, seed=int(rng.integers(1 << 30)), depth=(float(rng.uniform(20, 200)), float(rng.uniform(500, 6000))))
     ref = orc.project_points(xyz, truth)
     uv = ref + rng.normal(0, 1.5, ref.shape)
-    targets = syn.TARGETS_D21 if rng.random() < 0.6 else syn.TARGETS_D9
+    targets = syn.TARGETS_D9 if lens_free_case else (syn.TARGETS_D21 if rng.random() < 0.6 else syn.TARGETS_D9)
     init = dict(truth)
     P = int(rng.choice([1, 7, 50, 129, 300]))
     bounds = orc.bounds_to_array(init, targets)
@@ -50,6 +55,8 @@ while time.time() < t_end:
         X[P // 2] = X[0]                                  # an exact tie: the first index must win
     cand = np.tile(L.params_vector(init), (P, 1))
     cand[:, [L.PARAM_KEYS.index(t) for t in targets]] = X * (bounds[:, 1] - bounds[:, 0]) + bounds[:, 0]
+    if lens_free_case and P > 3 and n > 2 and rng.random() < 0.1:
+        xyz[n // 2] = cand[1, :3]                         # candidate 1's camera position exactly: its loss is NaN in the reference
     fs = None if rng.random() < 0.4 else float(rng.choice([1.0, 10.0, 1000.0]))
     with np.errstate(all="ignore"):
         ref_l, ref_amin = orc.population_losses(xyz, uv, init, targets, bounds, X, fs)
@@ -69,6 +76,14 @@ while time.time() < t_end:
             err = np.abs(got - ref) / np.maximum(np.abs(ref), w)
             pts.set_observed(uv)
             losses, amin = pts.eval_population(cand, kind, 0.0 if fs is None else fs)
+            variant = pts.eval_population_info()[0]
+            worst["variant_" + variant] = worst.get("variant_" + variant, 0) + 1
+            if lens_free_case and variant != "lens_free":
+                print(f"a lens-free population was given the {variant} variant")
+                sys.exit(1)
+            if (prec == "f64" or lens_free_case) and not np.array_equal(np.isnan(losses), np.isnan(ref_l)):
+                print(f"MISMATCH ({prec}): NaN pattern {np.flatnonzero(np.isnan(losses))} vs {np.flatnonzero(np.isnan(ref_l))} ({variant})")
+                sys.exit(1)
             fin = np.isfinite(ref_l)
             lerr = np.abs(losses[fin] - ref_l[fin]) / np.abs(ref_l[fin])
             if prec == "f64":
