@@ -34,7 +34,9 @@ while time.time() < t_end:
                  p1=float(rng.uniform(-3e-3, 3e-3)), p2=float(rng.uniform(-3e-3, 3e-3)), s1=float(rng.uniform(-2e-3, 2e-3)), s2=float(rng.uniform(-1e-3, 1e-3)),
                  s3=float(rng.uniform(-2e-3, 2e-3)), s4=float(rng.uniform(-1e-3, 1e-3)))
     # round 6: a third of the cases are the reference's FIRST phase (example.py:51-54) -- no lens coefficient but a1, a2 anywhere,
-    # targets D9: the lens-free kernel variant; a point of every tenth such case sits AT a candidate's camera (NaN, second walk)
+    # targets D9: the lens-free kernel variant.  (A vertex exactly AT a camera is left to the unit tests: whether the reference's
+    # own R.p + t cancels to an exact 0 / 0 there depends on the BLAS's order of additions -- a planted case came out NaN for one
+    # seed and 1e16 px for the next, in the REFERENCE's arithmetic.)
     lens_free_case = rng.random() < 0.33
     if lens_free_case:
         truth.update({k: 0.0 for k in L.DIST_KEYS[2:]})
@@ -55,8 +57,6 @@ while time.time() < t_end:
         X[P // 2] = X[0]                                  # an exact tie: the first index must win
     cand = np.tile(L.params_vector(init), (P, 1))
     cand[:, [L.PARAM_KEYS.index(t) for t in targets]] = X * (bounds[:, 1] - bounds[:, 0]) + bounds[:, 0]
-    if lens_free_case and P > 3 and n > 2 and rng.random() < 0.1:
-        xyz[n // 2] = cand[1, :3]                         # candidate 1's camera position exactly: its loss is NaN in the reference
     fs = None if rng.random() < 0.4 else float(rng.choice([1.0, 10.0, 1000.0]))
     with np.errstate(all="ignore"):
         ref_l, ref_amin = orc.population_losses(xyz, uv, init, targets, bounds, X, fs)
@@ -73,7 +73,10 @@ while time.time() < t_end:
             pts.project(L.params_vector(truth))
             u, v = pts.fetch()
             got = np.stack([u, v], 1)
-            err = np.abs(got - ref) / np.maximum(np.abs(ref), w)
+            if not np.array_equal(np.isnan(got), np.isnan(ref)):
+                print(f"MISMATCH ({prec}): NaN rows of the projection {np.flatnonzero(np.isnan(got).any(1))} vs {np.flatnonzero(np.isnan(ref).any(1))}")
+                sys.exit(1)
+            err = np.nan_to_num(np.abs(got - ref) / np.maximum(np.abs(ref), w), nan=0.0)
             pts.set_observed(uv)
             losses, amin = pts.eval_population(cand, kind, 0.0 if fs is None else fs)
             variant = pts.eval_population_info()[0]
@@ -94,7 +97,9 @@ while time.time() < t_end:
                 if fin.any() and (dens[fin] < 0.25).any():
                     worst["f64_loss_pole"] = max(worst.get("f64_loss_pole", 0.0), float(lerr[dens[fin] < 0.25].max()))
                 res = pts.residuals(L.params_vector(truth))
-                ok = ok and np.abs(res - orc.residual_vector(xyz, uv, truth)).max() <= 1e-9 * w
+                with np.errstate(all="ignore"):
+                    rref = orc.residual_vector(xyz, uv, truth)
+                ok = ok and np.array_equal(np.isnan(res), np.isnan(rref)) and np.nanmax(np.abs(res - rref), initial=0.0) <= 1e-9 * w
                 worst["f64_proj"] = max(worst["f64_proj"], float(err.max()))
                 if fin.any() and (dens[fin] >= 0.25).any():
                     worst["f64_loss"] = max(worst["f64_loss"], float(lerr[dens[fin] >= 0.25].max()))
