@@ -25,7 +25,7 @@ def L():
 
 def test_counts_events_and_timers(L):
     from alproj_amd import synthetic as syn
-    assert L.device_count() >= 1 and L.load().alp_abi_version() == 6
+    assert L.device_count() >= 1 and L.load().alp_abi_version() == 7
     truth = syn.truth_params(316)
     xyz = syn.gcp_points(20_000, truth, seed=1)
     uv = orc.project_points(xyz, truth)
