@@ -204,6 +204,11 @@ def test_float32_observations_into_a_float64_set(L):
         np.testing.assert_array_equal(a.residuals(cand[1]), b.residuals(cand[1]))
     ref = orc.huber(uv32.astype(np.float64), orc.project_points(xyz, orc.vector_to_params(cand[1])), 10.0)
     assert la[1] == pytest.approx(ref, rel=1e-9)
+    # ... and float32 pixels on a float32 set are taken as they are (the same planes as their float64 copy rounds to)
+    with L.Points(xyz, [truth["x"], truth["y"], truth["z"]], "f32") as a, L.Points(xyz, [truth["x"], truth["y"], truth["z"]], "f32") as b:
+        a.set_observed(uv32)
+        b.set_observed(uv32.astype(np.float64))
+        np.testing.assert_array_equal(a.eval_population(cand, L.LOSS_HUBER, 10.0)[0], b.eval_population(cand, L.LOSS_HUBER, 10.0)[0])
 
 
 def test_losses_take_either_table_layout(L):
