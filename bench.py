@@ -824,6 +824,21 @@ def main():
                                 "cma_valu_frac": out["cma"]["roofline"]["frac"], "cma_valu_frac_at_survey_100_flop": out["cma"]["roofline"]["frac_at_survey_flops"],
                                 "cma_all_reduce_ms": ar_ms, "cma_all_reduce_share": out["cma"]["all_reduce_share_of_generation"]})
 
+        # the reference's FIRST phase at this scale (example.py:51-54: targets x, y, z, fov, pan, tilt, roll, a1, a2 around a camera
+        # without lens coefficients): the lens-free kernel variant, every rank on its rows, the same all-reduce -- ten generations
+        if len(targets) == 21 and not any(base.get(k, 0.0) for k in L.DIST_KEYS[2:]):
+            gen9, st9 = cma_loop(L, CMA, pts, base, syn.TARGETS_D9, bounds_to_array, args.pop, L.LOSS_HUBER, 10.0)
+            wall9, _ = timed(ctl, L, gen9, 10, 1)
+            e9, _ = pts.eval_population_timing()
+            e9 = ctl.max(e9)
+            variant9 = pts.eval_population_info()[0]
+            flop9 = EVAL_FLOPS_BY_VARIANT[(variant9, "huber")]
+            out["cma"]["d9_first_phase"] = {"iters_per_s": 10 / wall9, "kernel_ms": e9, "generations_timed": 10, "dims": 9, "population": args.pop,
+                                            "kernel_variant": variant9, "flop_per_eval": flop9,
+                                            "valu_frac": evals * flop9 / (e9 / 1e3) / VALU_PEAK}
+            out["roofline"].update({"cma_d9_first_phase_iters_per_s": 10 / wall9, "cma_d9_first_phase_kernel_ms": e9,
+                                    "cma_d9_first_phase_kernel_variant": variant9})
+
     # ---------------------------------------------------------------- float64 parity mode (1 GPU)
     if ctl.world == 1 and not args.no_f64 and args.precision == "f32":
         p64 = L.Points(xyz_l, origin, "f64")
