@@ -282,6 +282,25 @@ def test_population_golden(L, name, prec, rtol):
             assert losses[3] == losses[7]               # identical candidates -> identical sums
 
 
+@pytest.mark.parametrize("prec,rtol", [("f64", 1e-9), ("f32", 1e-5)])
+def test_first_phase_population_golden(L, prec, rtol):
+    """g19: the REFERENCE's own losses of its first optimisation phase (example.py:19-22, 51-54: no lens coefficients, targets
+    x, y, z, fov, pan, tilt, roll, a1, a2; 140 candidates = two tiles, the second ragged) -- the population the lens-free kernel
+    variant exists for; argmin bit-exact (the truth at row 11, a tie between rows 3 and 7)"""
+    g = load("g19_first_phase.npz")
+    init = orc.vector_to_params(g["params_init"])
+    tgt = [str(t) for t in g["targets"]]
+    cand = _cand_matrix(L, init, tgt, g["bounds"], g["X"])
+    with L.Points(g["xyz"], [init["x"], init["y"], init["z"]], prec) as pts:
+        pts.set_observed(g["uv_obs"])
+        for tag, kind, fs in (("md", L.LOSS_MEAN_DIST, 0.0), ("hub", L.LOSS_HUBER, 10.0)):
+            losses, amin = pts.eval_population(cand, kind, fs)
+            assert pts.eval_population_info()[0] == "lens_free"
+            np.testing.assert_allclose(losses, g[tag], rtol=rtol)
+            assert amin == int(np.argmin(g[tag])) == 11
+            assert losses[3] == losses[7]
+
+
 def test_population_golden_wild_f64(L):
     """stress set: points mostly outside the image, losses ~1e10 dominated by a few exploding
     distortion polynomials -- float64 mode still tracks the reference"""

@@ -94,6 +94,21 @@ def test_g5_population(name):
         assert losses[3] == losses[7]           # the planted tie
 
 
+def test_g19_first_phase_population():
+    """the reference's first optimisation phase (example.py:19-22, 51-54: a camera without lens coefficients, targets x, y, z, fov,
+    pan, tilt, roll, a1, a2): its own `_loss_function` over 140 candidates -- every one of them lens-free"""
+    g = load("g19_first_phase.npz")
+    init = orc.vector_to_params(g["params_init"])
+    assert all(init[k] == 0.0 for k in ("k1", "k2", "k3", "k4", "k5", "k6", "p1", "p2", "s1", "s2", "s3", "s4"))
+    tgt = [str(t) for t in g["targets"]]
+    bounds = orc.bounds_to_array(init, tgt)
+    np.testing.assert_array_equal(bounds, g["bounds"])
+    for tag, fs in (("md", None), ("hub", 10.0)):
+        losses, amin = orc.population_losses(g["xyz"], g["uv_obs"], init, tgt, bounds, g["X"], fs)
+        np.testing.assert_allclose(losses, g[tag], rtol=1e-12)
+        assert amin == int(np.argmin(g[tag])) == 11 and losses[3] == losses[7]
+
+
 def test_g6_bounds():
     g = load("g6_bounds.npz")
     p = orc.vector_to_params(g["params"])

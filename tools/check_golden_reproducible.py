@@ -38,6 +38,7 @@ GENERATORS = [
     ("gen_golden_gl_c4.py", ["g16_gl_c4_frame"]),
     ("gen_golden_geotiff_float.py", ["g17_geotiff_float"]),
     ("gen_golden_geotiff_bytes.py", ["g18_geotiff_bytes"]),
+    ("gen_golden_first_phase.py", ["g19_first_phase"]),
 ]
 
 
