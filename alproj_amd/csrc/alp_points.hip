@@ -263,21 +263,22 @@ int enqueue_popeval(alp_points *p, const double *cand, int64_t P, int loss_kind,
         // whole rounds of the 4 workgroups a CU holds at once while the grid is only a few rounds deep
         const int64_t rounded = (want + lo - 1) / lo * lo;
         nblk = (int)(want < lo ? lo : (want > hi ? hi : (want < 4 * lo ? rounded : want)));
-        // Few candidate tiles and a grid only a few rounds deep (10 M x 256: 2 tiles, 1954 stripes of 20 rows = 1.9
-        // rounds of the 1024 resident workgroups): the last round's idle slots and the rows a stripe leaves over for
-        // the narrow groups (20 = 3 x 6 + 2) cost 10 % against the 100 M x 2048 shape.  Then the grid becomes
-        // stripes x tiles -- a workgroup runs ONE tile of 128 candidates over a stripe of whole groups of V = 6 rows,
-        // about two stripes per resident workgroup slot: short enough for the dispatcher's greedy order to leave a
-        // small tail, long enough to amortise the staging of the tile's records.  Measured at 10 M points
-        // (tools/sweep_popeval_grid.py, ms for P = 256 / 384 / 512): one column of 2048 stripes x all tiles (round 2)
-        // 3.15 / 4.64 / 6.14; stripes of 6 rows x tiles 3.02 / 4.39 / 5.72; 12 rows 2.96 / 4.35 / 5.63; 18 rows
-        // 2.90 / 4.33 / 5.61; 24 rows 2.97 / 4.44 / 5.70; 36 rows 3.10 / 4.37 / 5.64.  The sums do not depend on
-        // the shape: float64 additions of float32 group sums of this magnitude are exact.
+        // Two candidate tiles or more: the grid is stripes x tiles -- a workgroup runs ONE tile of 128 candidates over a stripe of
+        // whole groups of V rows.  Round 3 introduced it for populations of a few tiles whose one-column grid was only a few
+        // rounds deep (10 M x 256: 1954 stripes of 20 rows = 1.9 rounds of the 1024 resident workgroups, 2 rows of every 20 in
+        // the narrow groups; tools/sweep_popeval_grid.py, ms for P = 256 / 384 / 512 at 10 M points: one column of 2048 stripes
+        // 3.15 / 4.64 / 6.14; stripes of 18 rows x tiles 2.90 / 4.33 / 5.61).  Round 6 measured it at every other shape as well
+        // (profiles/r06_popeval_grid_sweep.txt, one column -> stripes x tiles, general | lens-free variant): 10 M x 1024 12.2 ->
+        // 11.0 | 5.81 -> 4.91 ms; 10 M x 2048 24.6 -> 21.7 | 11.5 -> 9.64; 30 M x 1024 34.9 -> 32.5 | 15.8 -> 14.4; 100 M x 2048
+        // 219.5 -> 215.2 | 95.7 -> 93.4 -- never slower, so it is the rule.  Stripes of k groups, k grown with the point count
+        // (about two stripes per resident slot and tile column for small sets, up to 16 groups = ~25 000 points for large ones:
+        // the timings are flat from 4 to 16 groups and the partial-sum buffer shrinks with the stripe count).
+        // The sums depend on the shape in the last bits only (1e-9 relative between shapes: other group boundaries).
         const int tiles = (int)((P + POP_TC - 1) / POP_TC);
-        if (tiles >= 2 && tiles <= 8 && want * tiles < 8 * lo) {
+        if (tiles >= 2) {
             int64_t k = (int64_t)((double)rows / ((double)VV * 2.12 * (double)lo) + 0.5);      // groups of V rows per stripe
             if (k < 1) k = 1;
-            if (k > 4) k = 4;
+            if (k > 16) k = 16;
             const int64_t stripes = (rows + VV * k - 1) / (VV * k);
             if (stripes * tiles >= 4 * lo) {
                 nblk = (int)stripes;

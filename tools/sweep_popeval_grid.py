@@ -31,8 +31,9 @@ for P in Ps:
     cand = np.tile(L.params_vector(base), (P, 1))
     cand[:, cols] += rng.uniform(-0.1, 0.1, (P, 9)) * np.array([30, 30, 30, 45, 45, 45, 45, 0.2, 0.2])
     tiles = (P + 127) // 128
-    shapes = [None] + [(1024 * r, 1) for r in (1, 2, 3, 4)] + [((rows + 6 * k - 1) // (6 * k), tiles) for k in (1, 2, 3, 4, 6)] + \
-             [((rows + 6 * k - 1) // (6 * k), 1) for k in (1, 2, 3, 4)]
+    G = int(os.environ.get("SWEEP_GROUP_ROWS", "6"))      # rows of a full group: 6 for the general variant, 8 for the lens-free one
+    shapes = [None] + [(1024 * r, 1) for r in (1, 2, 3, 4)] + [((rows + G * k - 1) // (G * k), tiles) for k in (1, 2, 3, 4, 6)] + \
+             [((rows + G * k - 1) // (G * k), 1) for k in (1, 2, 3, 4)]
     ref = None
     for shp in shapes:
         if shp is None:
@@ -49,5 +50,5 @@ for P in Ps:
         if ref is None:
             ref = losses
         dev = np.nanmax(np.abs(losses - ref) / np.abs(ref))
-        print(f"N={len(xyz)} P={P} grid={'shipped' if shp is None else shp}: {best:.3f} ms  {len(xyz) * P / best / 1e6:.0f} G evals/s  "
+        print(f"N={len(xyz)} P={P} {pts.eval_population_info()} grid={'shipped' if shp is None else shp}: {best:.3f} ms  {len(xyz) * P / best / 1e6:.0f} G evals/s  "
               f"(losses vs shipped: {dev:.1e})", flush=True)
