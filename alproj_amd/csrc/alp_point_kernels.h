@@ -534,7 +534,8 @@ template <typename T, int LOSS, int V, bool MASKED, bool SHARED_POSE, typename T
 __device__ __forceinline__ void pop_group(const TS *__restrict__ x, const TS *__restrict__ y,
                                           const TS *__restrict__ z, const TS *__restrict__ uo,
                                           const TS *__restrict__ vo, int64_t base, int64_t end,
-                                          const PoseRec<T> *s_c, double *s_sum_wave, int tc, T f_scale) {
+                                          const PoseRec<T> *s_c, double *s_sum_wave, int tc, T f_scale,
+                                          unsigned long long redo_lo = ~0ull, unsigned long long redo_hi = ~0ull) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     T qx[V], qy[V], qz[V], uoc[V], voc[V];
@@ -553,6 +554,8 @@ __device__ __forceinline__ void pop_group(const TS *__restrict__ x, const TS *__
     if constexpr (SHARED_POSE && !LENS_FREE) norm_coords<T, V>(s_c[0].v, qx, qy, qz, pre);
     constexpr int WORDS = LENS_FREE ? 12 : 32;        // a lens-free record is its three rows
     for (int c = 0; c < tc; ++c) {
+        if constexpr (EXACT_POLES)         // the second walk: only the candidates whose sums were not finite (wave-uniform bits)
+            if (!(((c < 64 ? redo_lo >> c : redo_hi >> (c - 64)) & 1ull))) continue;
         T r[WORDS];
         const typename Num<T>::vec *rv = reinterpret_cast<const typename Num<T>::vec *>(s_c[c].v);
 #pragma unroll
@@ -569,23 +572,27 @@ __device__ __forceinline__ void pop_group(const TS *__restrict__ x, const TS *__
     }
 }
 
+// which kernels take the second walk (see popeval_kernel): float64 arithmetic, and lens-free tiles of either precision
+#define POP_SECOND_WALK(T, LENS_FREE) (sizeof(T) == 8 || (LENS_FREE))
+
 // one workgroup's stripe [beg, end) against the tc staged records: wide groups of V rows, the rows they leave over two at a
 // time, the ragged last row masked
 template <typename T, int LOSS, int V, bool SHARED_POSE, typename TS, bool EXACT_POLES, bool LENS_FREE = false>
 __device__ __forceinline__ void pop_walk_stripe(const TS *__restrict__ x, const TS *__restrict__ y, const TS *__restrict__ z,
                                                 const TS *__restrict__ uo, const TS *__restrict__ vo, int64_t beg, int64_t end,
-                                                const PoseRec<T> *recs, double *s_sum_wave, int tc, T f_scale) {
+                                                const PoseRec<T> *recs, double *s_sum_wave, int tc, T f_scale,
+                                                unsigned long long redo_lo = ~0ull, unsigned long long redo_hi = ~0ull) {
     // (the second walk, EXACT_POLES, goes row by row: it is rare, and its two reciprocals per point over V points in flight
     // would set the kernel's register count -- 178 instead of 154 VGPRs in float64, two waves per SIMD instead of three)
     constexpr int VW = EXACT_POLES ? 1 : V;
     int64_t base = beg;
     for (; base + 256 * VW <= end; base += 256 * VW)
-        pop_group<T, LOSS, VW, false, SHARED_POSE, TS, EXACT_POLES, LENS_FREE>(x, y, z, uo, vo, base, end, recs, s_sum_wave, tc, f_scale);
+        pop_group<T, LOSS, VW, false, SHARED_POSE, TS, EXACT_POLES, LENS_FREE>(x, y, z, uo, vo, base, end, recs, s_sum_wave, tc, f_scale, redo_lo, redo_hi);
     if constexpr (VW > 2)      // the rows left over by the wide groups, two at a time
         for (; base + 512 <= end; base += 512)
-            pop_group<T, LOSS, 2, false, SHARED_POSE, TS, EXACT_POLES, LENS_FREE>(x, y, z, uo, vo, base, end, recs, s_sum_wave, tc, f_scale);
+            pop_group<T, LOSS, 2, false, SHARED_POSE, TS, EXACT_POLES, LENS_FREE>(x, y, z, uo, vo, base, end, recs, s_sum_wave, tc, f_scale, redo_lo, redo_hi);
     for (; base < end; base += 256)
-        pop_group<T, LOSS, 1, true, SHARED_POSE, TS, EXACT_POLES, LENS_FREE>(x, y, z, uo, vo, base, end, recs, s_sum_wave, tc, f_scale);
+        pop_group<T, LOSS, 1, true, SHARED_POSE, TS, EXACT_POLES, LENS_FREE>(x, y, z, uo, vo, base, end, recs, s_sum_wave, tc, f_scale, redo_lo, redo_hi);
 }
 
 // LENS_FREE: `cands` holds the lens-free records (fold_pose_lens_free) the first walk runs on, `cands_general` the general ones
@@ -624,18 +631,29 @@ __global__ __launch_bounds__(256, Cfg::MINW) void popeval_kernel(
         pop_walk_stripe<T, LOSS, V, SHARED_POSE, TS, false, LENS_FREE>(x, y, z, uo, vo, beg, end, s_c, s_sum[wave], tc, f_scale);
         // A sum that is not finite stays so (inf and NaN are sticky under +): looked for ONCE per wave, tile and stripe -- nothing
         // in the loop above pays for it.  The wave's rows are its own (lane t owns points t, t + 256, ...), so are its sums:
-        // it clears them and walks its share again with a reciprocal per denominator (distort_group), no barrier needed.
-        __builtin_amdgcn_wave_barrier();       // lane 63 wrote the sums, every lane reads them: same wave, LDS in order
-        bool bad = false;
-        for (int c = tid & 63; c < tc; c += 64)
-            bad |= (__builtin_bit_cast(unsigned long long, s_sum[wave][c]) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
-        if (__builtin_amdgcn_ballot_w64(bad) != 0) {
-            for (int c = tid & 63; c < tc; c += 64) s_sum[wave][c] = 0.0;
-            __builtin_amdgcn_wave_barrier();
-            // (a lens-free tile: the LDS holds the folded rows only, so the general records are read where they lie in HBM --
-            // wave-uniform loads, slow and rare; SHARED_POSE's hoisted coordinates are not used by either walk then)
-            if constexpr (LENS_FREE) pop_walk_stripe<T, LOSS, V, false, TS, true>(x, y, z, uo, vo, beg, end, cands_general + c0, s_sum[wave], tc, f_scale);
-            else pop_walk_stripe<T, LOSS, V, SHARED_POSE, TS, true>(x, y, z, uo, vo, beg, end, s_c, s_sum[wave], tc, f_scale);
+        // it clears the sums of the candidates concerned and walks its share again for THOSE candidates, row by row, with the
+        // reference's arithmetic: a reciprocal per denominator (distort_group), the general records for a lens-free tile.
+        // No barrier needed.  Where it runs: float64 (the parity mode) and lens-free tiles.  NOT for the general float32
+        // variants: a population of wild float32 candidates overflows (inf - inf = NaN in a third of the candidates of a first
+        // CMA-ES generation at sigma = 1, none of them in float64: tools/probe_cma_nonfinite.py), the walk cannot mend that, and
+        // it doubled those generations' kernel time; float32 mode therefore keeps NaN at an exact pole (include/alproj_hip.h).
+        if constexpr (POP_SECOND_WALK(T, LENS_FREE)) {
+            __builtin_amdgcn_wave_barrier();       // lane 63 wrote the sums, every lane reads them: same wave, LDS in order
+            const int l = tid & 63;
+            const bool bad_lo = l < tc && (__builtin_bit_cast(unsigned long long, s_sum[wave][l < tc ? l : 0]) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
+            const bool bad_hi = l + 64 < tc && (__builtin_bit_cast(unsigned long long, s_sum[wave][l + 64 < tc ? l + 64 : 0]) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
+            const unsigned long long redo_lo = __builtin_amdgcn_ballot_w64(bad_lo), redo_hi = __builtin_amdgcn_ballot_w64(bad_hi);
+            if ((redo_lo | redo_hi) != 0) {
+                if (bad_lo) s_sum[wave][l] = 0.0;
+                if (bad_hi) s_sum[wave][l + 64] = 0.0;
+                __builtin_amdgcn_wave_barrier();
+                // (a lens-free tile: the LDS holds the folded rows only, so the general records are read where they lie in HBM --
+                // wave-uniform loads, slow and rare; SHARED_POSE's hoisted coordinates are not used by either walk then)
+                if constexpr (LENS_FREE)
+                    pop_walk_stripe<T, LOSS, V, false, TS, true>(x, y, z, uo, vo, beg, end, cands_general + c0, s_sum[wave], tc, f_scale, redo_lo, redo_hi);
+                else
+                    pop_walk_stripe<T, LOSS, V, SHARED_POSE, TS, true>(x, y, z, uo, vo, beg, end, s_c, s_sum[wave], tc, f_scale, redo_lo, redo_hi);
+            }
         }
         __syncthreads();
         if (tid < tc)

@@ -210,9 +210,14 @@ int alp_residuals_batch(alp_points_t *pts, const double *cand, int64_t B, double
  * Poles of the rational lens model (src/alproj/optimize.py:112-116: a vertex for which EXACTLY one of
  * 1 + k4 r2 + k5 r4 + k6 r6 and 1 + a2 + k4 r2 + ... is zero): the reference's coordinate on that axis is +-inf, the
  * other finite, the candidate's loss +inf.  The kernel shares one reciprocal between the two denominators, which
- * would turn the finite coordinate into NaN; a wave whose sum for a candidate comes out infinite or NaN therefore walks
- * its share of the points again with a reciprocal per denominator, so the loss is +inf as in the reference (NaN only
- * where the reference is NaN too: a vertex at the camera, 0 * inf).  tests/test_gpu_points.py constructs the case.
+ * turns the finite coordinate into NaN.  FLOAT64 point sets (the parity mode) mend it: a wave whose sum for a candidate
+ * comes out infinite or NaN walks its share of the points again for that candidate with a reciprocal per denominator,
+ * so the loss is +inf as in the reference (NaN only where the reference is NaN too).  FLOAT32 point sets keep the NaN:
+ * the loss of such a candidate is NaN where the reference has +inf -- it ranks last either way (argmin_out skips NaN,
+ * CMA.tell sorts NaN as +inf); a wild float32 population has overflow NaNs in a third of its candidates anyway, which no
+ * second walk can mend.  tests/test_gpu_points.py constructs the case in both modes.
+ * Lens-free populations (ALP_POP_LENS_FREE, below) take the second walk in either precision: it restores the NaN the
+ * reference's k * inf produces at a vertex at the camera.
  * argmin_out == NULL: losses only, no confirmation pass (the reference uses the argmin of the LAST
  * generation only, src/alproj/optimize.py:427; every earlier generation needs the losses for
  * CMA.tell and nothing else).

@@ -479,8 +479,8 @@ def _oracle_r2(xyz, p):
 def test_pole_of_one_lens_denominator_is_an_infinite_loss(L, prec, kind, fs, variant):
     """optimize.py:112-116 at a vertex where EXACTLY ONE denominator of the rational lens model is zero: the reference's
     coordinate on that axis is +-inf, the other finite, the candidate's loss +inf.  The kernel shares one reciprocal between
-    the two denominators (0 * inf = NaN on the finite axis) and must put that right: +inf, never NaN, never the argmin, and
-    CMA.tell's order the same as with the oracle's inf.
+    the two denominators (0 * inf = NaN on the finite axis).  float64 (the parity mode) puts that right: +inf, never NaN; float32
+    keeps NaN (documented).  Either way: never the argmin, and CMA.tell's order the same as with the oracle's inf.
 
     Construction.  k4 = -0.5, k5 = k6 = 0: den_y = (1 + a2) - r2 / 2 is zero iff 1 + a2 == r2 / 2 bit for bit (the product
     -0.5 r2 is exact), den_x = 1 - r2 / 2 is not.  r2 of the chosen out-of-frame vertex is known to a few ulps only (the
@@ -519,7 +519,10 @@ def test_pole_of_one_lens_denominator_is_an_infinite_loss(L, prec, kind, fs, var
         losses, amin = pts.eval_population(cand, kind, fs)
         hit = np.flatnonzero(~np.isfinite(losses))
         assert len(hit) >= 1, "no candidate landed on the device's pole: widen W"
-        assert np.all(np.isposinf(losses[hit])), losses[hit]            # +inf like the reference, not NaN
+        if prec == "f64":
+            assert np.all(np.isposinf(losses[hit])), losses[hit]        # the parity mode: +inf like the reference, not NaN
+        # (float32 mode: NaN or inf -- it keeps the shared reciprocal's NaN at an exact pole, include/alproj_hip.h: the second
+        # walk that mends it cannot mend the float32 overflows of a wild population and doubled their kernel time)
         assert amin in (0, 1) and amin == int(np.argmin(losses))
         # the two sane candidates are untouched by the second walk their wave made for the pole candidate's sake
         ref2 = np.array([orc.loss_of(xyz, uv, orc.vector_to_params(c), kind, fs) for c in cand[:2]])
@@ -533,7 +536,7 @@ def test_pole_of_one_lens_denominator_is_an_infinite_loss(L, prec, kind, fs, var
     o_pole[L.PARAM_KEYS.index("a2")] = r2[i] / 2 - 1.0
     l_ref = np.array(list(ref2) + [orc.loss_of(xyz, uv, orc.vector_to_params(o_pole), kind, fs)])
     assert np.isposinf(l_ref[2]), "the oracle's own pole candidate must be infinite (optimize.py:115)"
-    assert np.isposinf(l_dev[2]) and amin_small == int(np.argmin(l_ref))
+    assert (np.isposinf(l_dev[2]) if prec == "f64" else not np.isfinite(l_dev[2])) and amin_small == int(np.argmin(l_ref))
     orders = []
     for values in (l_dev, l_ref):
         es = CMA(mean=np.full(3, 0.5), sigma=0.2, bounds=np.tile([0.0, 1.0], (3, 1)), population_size=3, seed=1)
