@@ -523,7 +523,7 @@ def test_pole_of_one_lens_denominator_is_an_infinite_loss(L, prec, kind, fs, var
             assert np.all(np.isposinf(losses[hit])), losses[hit]        # the parity mode: +inf like the reference, not NaN
         # (float32 mode: NaN or inf -- it keeps the shared reciprocal's NaN at an exact pole, include/alproj_hip.h: the second
         # walk that mends it cannot mend the float32 overflows of a wild population and doubled their kernel time)
-        assert amin in (0, 1) and amin == int(np.argmin(losses))
+        assert amin in (0, 1) and amin == int(np.argmin(np.where(np.isnan(losses), np.inf, losses)))
         # the two sane candidates are untouched by the second walk their wave made for the pole candidate's sake
         ref2 = np.array([orc.loss_of(xyz, uv, orc.vector_to_params(c), kind, fs) for c in cand[:2]])
         # (float32: the losses here are the 1-px noise itself -- 1.0 px mean distance, 1.0 Huber -- so the float32 pixel floor of
