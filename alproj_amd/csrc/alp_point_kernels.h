@@ -604,6 +604,7 @@ __global__ __launch_bounds__(256, Cfg::MINW) void popeval_kernel(
     double *__restrict__ partials, const PoseRec<T> *__restrict__ cands_general) {
     constexpr int TC = Cfg::TC;
     constexpr int V = Cfg::V;
+    static_assert(TC <= 128, "the second walk's candidate mask is two 64-bit words");
     __shared__ PoseRec<T> s_c[TC];
     __shared__ double s_sum[4][TC];
     const int tid = threadIdx.x;
