@@ -34,9 +34,17 @@ def test_counts_events_and_timers(L):
         L.check(L.lib().alp_points_count(p._h, ctypes.byref(n)))
         assert n.value == 20_000 == p.n
         p.set_observed(uv)
+        with pytest.raises(L.AlprojHipError) as e:            # nothing evaluated yet: no variant, no shape to report
+            p.eval_population_info()
+        assert e.value.code == -6
+        info = (ctypes.c_int64 * 3)()
+        assert L.lib().alp_eval_population_info(None, info) == -1 and L.lib().alp_eval_population_info(p._h, None) == -1
         L.event_record(0)
         p.project(L.params_vector(truth))
         losses, _ = p.eval_population(np.stack([L.params_vector(truth)] * 3), L.LOSS_MEAN_DIST, 0.0)
+        # three identical candidates WITH a lens: they share the pose rows -> the shared-pose variant, one stripe per 256 points at most
+        variant, stripes, tile_cols = p.eval_population_info()
+        assert variant == "shared_pose" and 1 <= stripes <= (20_000 + 255) // 256 and tile_cols == 1
         L.event_record(1)
         L.synchronize()
         assert 0.0 < L.event_elapsed_ms(0, 1) < 1000.0
