@@ -10,7 +10,8 @@ import subprocess
 import sys
 import tempfile
 
-F64 = len(sys.argv) > 1 and sys.argv[1] == "f64"
+F64 = len(sys.argv) > 1 and sys.argv[1] in ("f64", "lf64")
+LF = len(sys.argv) > 1 and sys.argv[1] in ("lf", "lf64")          # the lens-free variant (round 6)
 DEFS = [a for a in sys.argv[1:] if a.startswith("-D")]
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,7 +20,9 @@ subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++
                 "--cuda-device-only", "-S", f"{ROOT}/alproj_amd/csrc/alp_points.hip", "-o", asm] + DEFS, check=True,
                stderr=subprocess.DEVNULL)
 lines = open(asm).read().split("\n")
-sym = r"^_ZN3alp14popeval_kernelIdLi1ENS_6PopCfgIdEELb0EdEE.*:" if F64 else r"^_ZN3alp14popeval_kernelIfLi1ENS_6PopCfgIfEELb0EfEE.*:"
+sym = r"^_ZN3alp14popeval_kernelIdLi1ENS_6PopCfgIdEELb0EdLb0EE.*:" if F64 else r"^_ZN3alp14popeval_kernelIfLi1ENS_6PopCfgIfEELb0EfLb0EE.*:"
+if LF:
+    sym = r"^_ZN3alp14popeval_kernelIdLi1ENS_8PopCfgLFIdEELb0EdLb1EE.*:" if F64 else r"^_ZN3alp14popeval_kernelIfLi1ENS_8PopCfgLFIfEELb0EfLb1EE.*:"
 start = next(i for i, l in enumerate(lines) if re.match(sym, l))
 end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
 body = lines[start:end]
@@ -30,13 +33,13 @@ last = next(i for i in range(first + 1, len(body)) if "s_cbranch" in body[i] and
 loop = [l.split()[0] for l in body[first + 1:last + 1] if l.strip() and not l.strip().startswith((";", "."))]
 hist = collections.Counter(loop)
 valu = sum(v for k, v in hist.items() if k.startswith("v_"))
-V = 6
+V = 8 if LF else 6
 if F64:
-    V = 5
+    V = 6 if LF else 5
     for d in DEFS:
         if d.startswith("-DPOP_VD="):
             V = int(d.split("=")[1])
-print(f"popeval_kernel<{'double' if F64 else 'float'}, HUBER, V = {V}, TC = 128>{' ' + ' '.join(DEFS) if DEFS else ''}: "
+print(f"popeval_kernel<{'double' if F64 else 'float'}, HUBER, V = {V}, TC = 128{', LENS_FREE' if LF else ''}>{' ' + ' '.join(DEFS) if DEFS else ''}: "
       f"innermost loop = ONE candidate against the {V} points of a lane")
 print(f"instructions in the loop body: {len(loop)}; vector ALU: {valu} = {valu / V:.1f} per evaluation\n")
 groups = collections.OrderedDict([
